@@ -1,0 +1,288 @@
+/*
+ * limo_hip.h — C-ABI of the MI355X-native LIMO hot path (keyframe bundle adjustment + LiDAR depth assignment).
+ *
+ * This header is the drop-in boundary.  Everything above it (window bookkeeping, landmark/keyframe
+ * selection, ROS I/O) stays in the host language; everything below it runs as hand-written HIP kernels
+ * on gfx950.  Plain pointers and sizes only; no C++ types, no torch types, nothing thrown across it.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference tree):
+ *
+ *   limo_ba_solve / limo_ba_batch_*     the body of BundleAdjusterKeyframes::solve() between "selection
+ *                                       done" and "return report":
+ *                                       keyframe_bundle_adjustment/src/bundle_adjuster_keyframes.cpp:695-766
+ *                                       (problem build :498-627, :769-818, :890-904; constness :198-219,
+ *                                       :722-736; trimming schedule :740-758; solveTrimmed call :765) and
+ *                                       robust_optimization/src/robust_solving.cpp:140-248 + ceres::Solve
+ *                                       (Ceres 1.13, DENSE_SCHUR, Levenberg-Marquardt).
+ *   limo_ba_adjust_pose_only            BundleAdjusterKeyframes::adjustPoseOnly(),
+ *                                       bundle_adjuster_keyframes.cpp:820-888.
+ *   limo_ba_evaluate                    ceres::Problem::Evaluate as used at
+ *                                       robust_optimization/src/robust_solving.cpp:44 and
+ *                                       keyframe_bundle_adjustment/src/definitions.cpp:94 (residuals, cost) plus
+ *                                       the Jacobians Ceres builds inside Solve for the blocks created at
+ *                                       bundle_adjuster_keyframes.cpp:584-620
+ *                                       (internal/cost_functors_ceres.hpp:53-222).
+ *   limo_landmark_init                  BundleAdjusterKeyframes::calculateLandmark (both overloads),
+ *                                       bundle_adjuster_keyframes.cpp:332-382, internal/triangulator.hpp:51-75.
+ *   limo_trim_quantile                  TrimmerQuantile::getOutliers,
+ *                                       robust_optimization/include/robust_optimization/internal/trimmer_quantile.hpp:40-63.
+ *   limo_depth_estimate                 the (un-vendored) mono_lidar_depth DepthEstimator as pinned by
+ *                                       demo_keyframe_bundle_adjustment_meta/res/mono_lidar_fusion_parameters.yaml:1-185;
+ *                                       contract = FeaturePoint::d, matches_msg_types/include/matches_msg_types/feature_point.hpp:24-26.
+ *
+ * Conventions (reference: internal/definitions.hpp:23,75-83, keyframe.hpp:181-182):
+ *   pose   = (qw,qx,qy,qz,tx,ty,tz), x' = R(q) x + t, keyframe <- origin.  Camera extrinsic = camera <- vehicle.
+ *   All parameters are double; measurements are float and are widened exactly as the reference does
+ *   (bundle_adjuster_keyframes.cpp:585,606-607).  A measurement without depth carries d < 0 (the solve
+ *   uses d > 0.0f, :578).
+ *
+ * Return codes: 0 = ok, < 0 = invalid input / runtime error (see limo_last_error), > 0 reserved.
+ * Threading: one limo_ctx per (thread, GPU, stream); calls on one ctx are serialised by the caller.
+ */
+#ifndef LIMO_HIP_H_
+#define LIMO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIMO_ABI_VERSION 1
+
+/* Keyframe::FixationStatus, keyframe.hpp:30 */
+enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
+
+/* error codes */
+enum limo_status {
+    LIMO_OK = 0,
+    LIMO_ERR_INVALID = -1,      /* null pointer, negative size, index out of range        */
+    LIMO_ERR_NOT_ENOUGH_KF = -2, /* solve() with < 3 keyframes (NotEnoughKeyframesException) */
+    LIMO_ERR_RUNTIME = -3,      /* HIP runtime error                                       */
+    LIMO_ERR_NO_DEVICE = -4     /* no gfx950 device / extension cannot run                 */
+};
+
+/* Termination of one Ceres-style solve (ceres::TerminationType restated). */
+enum limo_termination { LIMO_CONVERGENCE = 0, LIMO_NO_CONVERGENCE = 1, LIMO_FAILURE = 2 };
+
+/*
+ * One optimisation window, flattened (struct of arrays).  The caller owns every buffer; the library keeps
+ * no pointer after a call returns.  Arrays marked inout are optimised in place, exactly like Ceres does
+ * through the raw pointers the reference hands it (bundle_adjuster_keyframes.cpp:592-593,555-556).
+ *
+ * Keyframes are the ACTIVE keyframes in ascending keyframe-id (timestamp) order — the order of
+ * active_keyframe_ids_ (std::set) that the regularisers iterate (:775,:892).
+ * Landmarks are the SELECTED landmarks that exist in landmarks_, ascending landmark id.
+ * Observations: one per (keyframe, landmark, camera) measurement of a selected landmark in an active
+ * keyframe (:569-576); any order.
+ */
+typedef struct limo_ba_window {
+    int32_t n_kf;
+    int32_t n_cam;
+    int32_t n_lm;
+    int32_t n_obs;
+
+    double* kf_pose;            /* [n_kf*7] inout                                         */
+    double* kf_plane_dir;       /* [n_kf*3] inout  Plane::direction                        */
+    double* kf_plane_dist;      /* [n_kf]   inout  Plane::distance (< -10: no ground plane) */
+    const int32_t* kf_fixation; /* [n_kf] enum limo_fixation                               */
+
+    const double* cam;          /* [n_cam*10] f, cx, cy, qw,qx,qy,qz, tx,ty,tz (camera<-vehicle) */
+
+    double* lm_pos;             /* [n_lm*3] inout                                          */
+    const double* lm_weight;    /* [n_lm]  Landmark::weight                                */
+    const uint8_t* lm_is_ground;/* [n_lm]  Landmark::is_ground_plane                       */
+
+    const int32_t* obs_kf;      /* [n_obs] index into keyframes of this window             */
+    const int32_t* obs_lm;      /* [n_obs] index into landmarks of this window             */
+    const int32_t* obs_cam;     /* [n_obs] index into cameras of this window               */
+    const float* obs_u;         /* [n_obs]                                                 */
+    const float* obs_v;         /* [n_obs]                                                 */
+    const float* obs_d;         /* [n_obs] depth along camera z, < 0 = none                */
+} limo_ba_window;
+
+/*
+ * Options.  Defaults (limo_ba_default_options) are the reference's: OutlierRejectionOptions
+ * (bundle_adjuster_keyframes.hpp:79-89), robust_optimization::getStandardSolverOptions
+ * (robust_solving.hpp:93-108), bundle_adjuster_keyframes.cpp:740-764, and Ceres 1.13 Solver::Options defaults.
+ */
+typedef struct limo_ba_options {
+    double depth_thres;            /* 0.16  Cauchy scale, depth blocks        */
+    double reprojection_thres;     /* 1.6   Cauchy scale, reprojection blocks */
+    double depth_quantile;         /* 0.95                                    */
+    double reprojection_quantile;  /* 0.95                                    */
+    int32_t num_trim_rounds;       /* 1   outlier_rejection_options_.num_iterations */
+    int32_t trim_solver_iterations;/* 2   entries of number_iterations        */
+    int32_t min_landmarks_for_trimming; /* 100: trimming only if n_lm > this (solve); 30 for pose-only */
+    int32_t minimum_number_residual_groups; /* 30 */
+    int32_t max_num_iterations;    /* 100 */
+    double max_solver_time_sec;    /* wall-clock cap per ceres-style solve; <= 0 disables it (deterministic). */
+    /* Ceres 1.13 trust-region defaults */
+    double function_tolerance;     /* 1e-6  */
+    double gradient_tolerance;     /* 1e-10 */
+    double parameter_tolerance;    /* 1e-8  */
+    double initial_trust_region_radius; /* 1e4  */
+    double max_trust_region_radius;     /* 1e16 */
+    double min_trust_region_radius;     /* 1e-32 */
+    double min_lm_diagonal;        /* 1e-6  */
+    double max_lm_diagonal;        /* 1e32  */
+    double min_relative_decrease;  /* 1e-3  */
+    int32_t max_num_consecutive_invalid_steps; /* 5 */
+    int32_t jacobi_scaling;        /* 1 */
+} limo_ba_options;
+
+/* What the reference returns as a FullReport() string, as numbers. */
+typedef struct limo_ba_report {
+    int32_t termination;         /* enum limo_termination of the FINAL solve                    */
+    int32_t num_solves;          /* ceres-style solves executed (trim rounds [+retries] + final) */
+    int32_t iterations_total;    /* LM iterations over all solves (iteration 0 not counted)      */
+    int32_t iterations_final;    /* LM iterations of the final solve                             */
+    int32_t successful_steps;    /* accepted steps over all solves                               */
+    int32_t n_depth_blocks;      /* residual blocks built (before trimming)                      */
+    int32_t n_repr_blocks;
+    int32_t n_gp_blocks;
+    int32_t n_trimmed_landmarks; /* landmarks removed by trimming                                */
+    int32_t reserved;
+    double initial_cost;         /* cost of the first solve at x0 (incl. fixed cost)             */
+    double final_cost;           /* cost after the final solve (incl. fixed cost)                */
+    double time_sec;             /* wall time inside the library for this window / batch         */
+} limo_ba_report;
+
+typedef struct limo_ctx limo_ctx;
+typedef struct limo_ba_batch limo_ba_batch;
+
+/* --- context ------------------------------------------------------------------------------------ */
+int limo_abi_version(void);
+int limo_ctx_create(int device, limo_ctx** out);
+void limo_ctx_destroy(limo_ctx* ctx);
+/* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own. */
+int limo_ctx_set_stream(limo_ctx* ctx, void* hip_stream);
+const char* limo_last_error(const limo_ctx* ctx);
+
+void limo_ba_default_options(limo_ba_options* out);
+
+/* --- bundle adjustment --------------------------------------------------------------------------- */
+/* One window, host buffers in, optimised in place.  = batch_create(1) + solve + download + destroy. */
+int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report);
+
+/*
+ * Many independent windows per launch sequence (ragged sizes allowed).  create() packs and uploads;
+ * solve() runs entirely from HBM-resident data; reset() restores the uploaded initial parameters on the
+ * device (so a batch can be re-solved, e.g. for benchmarking); download() writes the optimised parameters
+ * back into the callers' windows (same shapes as at create) and fills n reports (either may be NULL).
+ */
+int limo_ba_batch_create(limo_ctx* ctx, int32_t n_windows, const limo_ba_window* windows, limo_ba_batch** out);
+int limo_ba_batch_solve(limo_ba_batch* batch, const limo_ba_options* opts);
+int limo_ba_batch_reset(limo_ba_batch* batch);
+int limo_ba_batch_download(limo_ba_batch* batch, limo_ba_window* windows_out, limo_ba_report* reports);
+void limo_ba_batch_destroy(limo_ba_batch* batch);
+/* Device time (ms, HIP events on the batch's stream) and launch count of the Jacobian-evaluation kernel
+ * accumulated since create()/the last call with reset != 0; either output may be NULL. */
+int limo_ba_batch_kernel_stats(limo_ba_batch* batch, int reset, double* linearize_ms, int64_t* linearize_launches,
+                               double* total_ms);
+
+/*
+ * Evaluate the reprojection / depth residual blocks of a window at its current parameters
+ * (Problem::Evaluate semantics).  Outputs are per observation in the caller's observation order; rows
+ * 0,1 = reprojection (u,v), row 2 = depth (zero when the observation has no depth):
+ *   residuals [n_obs*3]
+ *   jac_pose  [n_obs*3*6]  d r / d (rotation tangent 3, translation 3)  — local parameterisation applied
+ *   jac_lm    [n_obs*3*3]  d r / d landmark
+ *   valid     [n_obs]      0 where the reference functor returns false (|z| < 0.01, cost_functors_ceres.hpp:78-83)
+ * apply_loss != 0 applies the Ceres corrector (sqrt(rho') scaling) of the block's loss; cost = 1/2 sum rho.
+ * Any output pointer may be NULL.
+ */
+int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_options* opts, int apply_loss,
+                     double* cost, double* residuals, double* jac_pose, double* jac_lm, uint8_t* valid);
+
+/*
+ * Motion-only adjustment of ONE new keyframe against fixed landmarks (adjustPoseOnly).
+ * window: n_kf == 1 (the new keyframe; its pose is optimised in place), landmarks constant.
+ * Optional speed prior (SpeedRegularizationVector2, cost_functors_ceres.hpp:300-353): enabled when
+ * speed_weight > 0: residual (t_new - R_new R_b^T t_b)/dt_cur - vel_prev with pose_before = (q_b,t_b).
+ */
+typedef struct limo_speed_prior {
+    double speed_weight;     /* 1 - rot_diff/0.03, <= 0 disables (bundle_adjuster_keyframes.cpp:842-843) */
+    double dt_cur;           /* seconds                                                                */
+    double vel_prev[3];      /* translation(pose_before * pose_before2^-1) / dt_before                  */
+    double pose_before[7];
+} limo_speed_prior;
+int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_speed_prior* prior,
+                             const limo_ba_options* opts, limo_ba_report* report);
+
+/* --- landmark initialisation ----------------------------------------------------------------------- */
+/*
+ * For each of n landmarks: rays are given as n_rays_off CSR over (pose_cam_origin [7], u, v, d, f, cx, cy).
+ * If the FIRST listed measurement with d >= 0 exists in the landmark's own (newest) keyframe the caller
+ * should pass it as mode 0 (depth back-projection, :332-355); else mode 1 = midpoint triangulation over all
+ * rays (:358-382; needs >= 2 rays).  ok[i] = 0 where no position could be computed.
+ */
+typedef struct limo_ray {
+    double pose_cam_origin[7]; /* camera <- origin = T_cam_veh * T_kf_origin */
+    double f, cx, cy;
+    float u, v, d;
+    float pad;
+} limo_ray;
+int limo_landmark_init(limo_ctx* ctx, int32_t n, const int32_t* ray_off /* [n+1] */, const limo_ray* rays,
+                       const uint8_t* use_depth /* [n] */, double* pos_out /* [n*3] */, uint8_t* ok /* [n] */);
+
+/* --- trimming --------------------------------------------------------------------------------------- */
+/* Quantile trimmer: n (id, value) pairs; outliers = everything from sorted position int(n*q) upwards
+ * (ties broken by id so the result is deterministic).  Returns the number of outliers written. */
+int limo_trim_quantile(int32_t n, const int64_t* ids, const double* values, double quantile, int64_t* outliers_out);
+
+/* --- LiDAR depth assignment -------------------------------------------------------------------------- */
+/* Parameters mirror mono_lidar_fusion_parameters.yaml key by key (defaults = that file). */
+typedef struct limo_depth_params {
+    int32_t pixelarea_search_width;        /* 6   yaml:14 */
+    int32_t pixelarea_search_height;       /* 9   yaml:17 */
+    int32_t pixelarea_search_offset_x;     /* 0   yaml:21 */
+    int32_t pixelarea_search_offset_y;     /* 0   yaml:24 */
+    int32_t neighbors_count_min;           /* 3   yaml:48 */
+    int32_t do_use_histogram_segmentation; /* 1   yaml:58 */
+    double histogram_segmentation_bin_width;   /* 0.3 yaml:61 */
+    int32_t histogram_segmentation_min_pointcount; /* 1 yaml:63 */
+    int32_t treshold_depth_enabled;        /* 1   yaml:97  */
+    double treshold_depth_max;             /* 100 yaml:101 */
+    double treshold_depth_min;             /* 0   yaml:103 */
+    int32_t treshold_depth_local_enabled;  /* 1   yaml:108 */
+    int32_t treshold_depth_local_valuetype;/* 1 = relative yaml:112 */
+    double treshold_depth_local_value;     /* 0.5 yaml:114 */
+    int32_t do_use_cut_behind_camera;      /* 1   yaml:168 */
+    int32_t do_use_triangle_size_maximation; /* 1 yaml:171 */
+    int32_t do_check_triangleplanar_condition; /* 1 yaml:173 */
+    double triangleplanar_crossnorm_treshold;  /* 0.1 yaml:176 */
+    double viewray_plane_orthoganality_treshold; /* 0.1 yaml:178 */
+    /* ground plane (yaml:125-163) */
+    int32_t do_use_ransac_plane;           /* 1   */
+    double ransac_plane_distance_treshold; /* 0.2 */
+    double ransac_plane_min_z;             /* -3.5 (lidar frame) */
+    double ransac_plane_max_z;             /* -1.0 */
+    int32_t ransac_plane_max_iterations;   /* 600 */
+    double ransac_plane_probability;       /* 0.99 */
+    int32_t ransac_plane_use_refinement;   /* 1   */
+    double ransac_plane_refinement_treshold;   /* 10.2 */
+    double ransac_plane_point_distance_treshold; /* 0.2 */
+    int32_t plane_estimator_use_mestimator; /* 1  */
+    uint64_t ransac_seed;                  /* ours: RANSAC sampling seed (deterministic) */
+} limo_depth_params;
+void limo_depth_default_params(limo_depth_params* out);
+
+/*
+ * Assign a depth to each feature of one frame from one LiDAR sweep.
+ *   cloud_xyzi  [n_pts*4] float, KITTI velodyne .bin layout (x,y,z,intensity), lidar frame
+ *   T_cam_lidar [7]       camera <- lidar
+ *   feat_uv     [n_feat*2] float pixel coordinates
+ *   feat_is_ground [n_feat] optional (NULL = none): features labelled as ground use the ground-plane path
+ *   depth_out   [n_feat]  metres along camera z, -1 where no depth could be assigned
+ */
+int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar,
+                        double f, double cx, double cy, int32_t img_w, int32_t img_h, const float* feat_uv,
+                        size_t n_feat, const uint8_t* feat_is_ground, const limo_depth_params* params,
+                        float* depth_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIMO_HIP_H_ */

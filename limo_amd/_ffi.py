@@ -1,0 +1,244 @@
+"""ctypes mirror of include/limo_hip.h and loader of the C-ABI shared library.
+
+This is plumbing only: every structure below is a field-for-field copy of the C declaration it names.
+The product path has NO CPU fallback: if `liblimo_hip.so` is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblimo_hip.so")
+
+LIMO_FIX_POSE, LIMO_FIX_SCALE, LIMO_FIX_NONE = 0, 1, 2
+LIMO_OK, LIMO_ERR_INVALID, LIMO_ERR_NOT_ENOUGH_KF, LIMO_ERR_RUNTIME, LIMO_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+LIMO_CONVERGENCE, LIMO_NO_CONVERGENCE, LIMO_FAILURE = 0, 1, 2
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class BaWindow(C.Structure):  # struct limo_ba_window
+    _fields_ = [
+        ("n_kf", C.c_int32),
+        ("n_cam", C.c_int32),
+        ("n_lm", C.c_int32),
+        ("n_obs", C.c_int32),
+        ("kf_pose", c_double_p),
+        ("kf_plane_dir", c_double_p),
+        ("kf_plane_dist", c_double_p),
+        ("kf_fixation", c_int32_p),
+        ("cam", c_double_p),
+        ("lm_pos", c_double_p),
+        ("lm_weight", c_double_p),
+        ("lm_is_ground", c_uint8_p),
+        ("obs_kf", c_int32_p),
+        ("obs_lm", c_int32_p),
+        ("obs_cam", c_int32_p),
+        ("obs_u", c_float_p),
+        ("obs_v", c_float_p),
+        ("obs_d", c_float_p),
+    ]
+
+
+class BaOptions(C.Structure):  # struct limo_ba_options
+    _fields_ = [
+        ("depth_thres", C.c_double),
+        ("reprojection_thres", C.c_double),
+        ("depth_quantile", C.c_double),
+        ("reprojection_quantile", C.c_double),
+        ("num_trim_rounds", C.c_int32),
+        ("trim_solver_iterations", C.c_int32),
+        ("min_landmarks_for_trimming", C.c_int32),
+        ("minimum_number_residual_groups", C.c_int32),
+        ("max_num_iterations", C.c_int32),
+        ("max_solver_time_sec", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+    ]
+
+
+class BaReport(C.Structure):  # struct limo_ba_report
+    _fields_ = [
+        ("termination", C.c_int32),
+        ("num_solves", C.c_int32),
+        ("iterations_total", C.c_int32),
+        ("iterations_final", C.c_int32),
+        ("successful_steps", C.c_int32),
+        ("n_depth_blocks", C.c_int32),
+        ("n_repr_blocks", C.c_int32),
+        ("n_gp_blocks", C.c_int32),
+        ("n_trimmed_landmarks", C.c_int32),
+        ("reserved", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("time_sec", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SpeedPrior(C.Structure):  # struct limo_speed_prior
+    _fields_ = [
+        ("speed_weight", C.c_double),
+        ("dt_cur", C.c_double),
+        ("vel_prev", C.c_double * 3),
+        ("pose_before", C.c_double * 7),
+    ]
+
+
+class Ray(C.Structure):  # struct limo_ray
+    _fields_ = [
+        ("pose_cam_origin", C.c_double * 7),
+        ("f", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+        ("u", C.c_float),
+        ("v", C.c_float),
+        ("d", C.c_float),
+        ("pad", C.c_float),
+    ]
+
+
+class DepthParams(C.Structure):  # struct limo_depth_params
+    _fields_ = [
+        ("pixelarea_search_width", C.c_int32),
+        ("pixelarea_search_height", C.c_int32),
+        ("pixelarea_search_offset_x", C.c_int32),
+        ("pixelarea_search_offset_y", C.c_int32),
+        ("neighbors_count_min", C.c_int32),
+        ("do_use_histogram_segmentation", C.c_int32),
+        ("histogram_segmentation_bin_width", C.c_double),
+        ("histogram_segmentation_min_pointcount", C.c_int32),
+        ("treshold_depth_enabled", C.c_int32),
+        ("treshold_depth_max", C.c_double),
+        ("treshold_depth_min", C.c_double),
+        ("treshold_depth_local_enabled", C.c_int32),
+        ("treshold_depth_local_valuetype", C.c_int32),
+        ("treshold_depth_local_value", C.c_double),
+        ("do_use_cut_behind_camera", C.c_int32),
+        ("do_use_triangle_size_maximation", C.c_int32),
+        ("do_check_triangleplanar_condition", C.c_int32),
+        ("triangleplanar_crossnorm_treshold", C.c_double),
+        ("viewray_plane_orthoganality_treshold", C.c_double),
+        ("do_use_ransac_plane", C.c_int32),
+        ("ransac_plane_distance_treshold", C.c_double),
+        ("ransac_plane_min_z", C.c_double),
+        ("ransac_plane_max_z", C.c_double),
+        ("ransac_plane_max_iterations", C.c_int32),
+        ("ransac_plane_probability", C.c_double),
+        ("ransac_plane_use_refinement", C.c_int32),
+        ("ransac_plane_refinement_treshold", C.c_double),
+        ("ransac_plane_point_distance_treshold", C.c_double),
+        ("plane_estimator_use_mestimator", C.c_int32),
+        ("ransac_seed", C.c_uint64),
+    ]
+
+
+# every symbol include/limo_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "limo_abi_version",
+    "limo_ctx_create",
+    "limo_ctx_destroy",
+    "limo_ctx_set_stream",
+    "limo_last_error",
+    "limo_ba_default_options",
+    "limo_ba_solve",
+    "limo_ba_batch_create",
+    "limo_ba_batch_solve",
+    "limo_ba_batch_reset",
+    "limo_ba_batch_download",
+    "limo_ba_batch_destroy",
+    "limo_ba_batch_kernel_stats",
+    "limo_ba_evaluate",
+    "limo_ba_adjust_pose_only",
+    "limo_landmark_init",
+    "limo_trim_quantile",
+    "limo_depth_default_params",
+    "limo_depth_estimate",
+]
+
+_lib = None
+
+
+def load():
+    """Load liblimo_hip.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "limo_amd: %s not found - run `python -c 'import __graft_entry__ as g; g.build()'` first. "
+            "There is no CPU fallback for the product path." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.limo_abi_version.restype = C.c_int
+    lib.limo_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.limo_ctx_destroy.argtypes = [vp]
+    lib.limo_ctx_destroy.restype = None
+    lib.limo_ctx_set_stream.argtypes = [vp, vp]
+    lib.limo_last_error.argtypes = [vp]
+    lib.limo_last_error.restype = C.c_char_p
+    lib.limo_ba_default_options.argtypes = [C.POINTER(BaOptions)]
+    lib.limo_ba_default_options.restype = None
+    lib.limo_ba_solve.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaOptions), C.POINTER(BaReport)]
+    lib.limo_ba_batch_create.argtypes = [vp, C.c_int32, C.POINTER(BaWindow), C.POINTER(vp)]
+    lib.limo_ba_batch_solve.argtypes = [vp, C.POINTER(BaOptions)]
+    lib.limo_ba_batch_reset.argtypes = [vp]
+    lib.limo_ba_batch_download.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaReport)]
+    lib.limo_ba_batch_destroy.argtypes = [vp]
+    lib.limo_ba_batch_destroy.restype = None
+    lib.limo_ba_batch_kernel_stats.argtypes = [vp, C.c_int, c_double_p, c_int64_p, c_double_p]
+    lib.limo_ba_evaluate.argtypes = [
+        vp,
+        C.POINTER(BaWindow),
+        C.POINTER(BaOptions),
+        C.c_int,
+        c_double_p,
+        c_double_p,
+        c_double_p,
+        c_double_p,
+        c_uint8_p,
+    ]
+    lib.limo_ba_adjust_pose_only.argtypes = [
+        vp,
+        C.POINTER(BaWindow),
+        C.POINTER(SpeedPrior),
+        C.POINTER(BaOptions),
+        C.POINTER(BaReport),
+    ]
+    lib.limo_landmark_init.argtypes = [vp, C.c_int32, c_int32_p, C.POINTER(Ray), c_uint8_p, c_double_p, c_uint8_p]
+    lib.limo_trim_quantile.argtypes = [C.c_int32, c_int64_p, c_double_p, C.c_double, c_int64_p]
+    lib.limo_depth_default_params.argtypes = [C.POINTER(DepthParams)]
+    lib.limo_depth_default_params.restype = None
+    lib.limo_depth_estimate.argtypes = [
+        vp,
+        c_float_p,
+        C.c_size_t,
+        c_double_p,
+        C.c_double,
+        C.c_double,
+        C.c_double,
+        C.c_int32,
+        C.c_int32,
+        c_float_p,
+        C.c_size_t,
+        c_uint8_p,
+        C.POINTER(DepthParams),
+        c_float_p,
+    ]
+    _lib = lib
+    return lib

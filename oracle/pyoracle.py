@@ -1,0 +1,157 @@
+"""ctypes binding of oracle/_build/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from limo_amd import _ffi  # noqa: E402  (struct layouts only)
+
+LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, u8p = _ffi.c_double_p, _ffi.c_int32_p, _ffi.c_uint8_p
+    lib.oracle_ba_default_options.argtypes = [C.POINTER(_ffi.BaOptions)]
+    lib.oracle_ba_default_options.restype = None
+    lib.oracle_ba_solve.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.c_int, dp]
+    lib.oracle_ba_adjust_pose_only.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.SpeedPrior), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int]
+    lib.oracle_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+    lib.oracle_ba_problem_cost.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), dp, ip]
+    lib.oracle_trim_quantile.argtypes = [C.c_int32, _ffi.c_int64_p, dp, C.c_double, _ffi.c_int64_p]
+    lib.oracle_trim_fix.argtypes = [C.c_int32, _ffi.c_int64_p, dp, C.c_double, _ffi.c_int64_p]
+    lib.oracle_landmark_init.argtypes = [C.c_int32, ip, C.POINTER(_ffi.Ray), u8p, dp, u8p]
+    lib.oracle_functor.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp]
+    lib.oracle_loss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp]
+    lib.oracle_loss.restype = None
+    lib.oracle_plus.argtypes = [C.c_int, dp, dp, dp, dp]
+    lib.oracle_plus.restype = None
+    lib.oracle_robust_test_solve_trimmed.argtypes = [C.c_int, C.c_int, C.c_double, ip, C.c_int, C.c_double]
+    lib.oracle_robust_test_solve_trimmed.restype = C.c_double
+    lib.oracle_num_procs.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_ffi.c_double_p)
+
+
+def solve(window, opts, num_threads=1, num_linear_solver_threads=1):
+    """Run the restated solve() on `window` IN PLACE.  Returns (report dict, phase_times[4])."""
+    lib = load()
+    s = window.as_struct()
+    rep = _ffi.BaReport()
+    pt = np.zeros(4)
+    rc = lib.oracle_ba_solve(C.byref(s), C.byref(opts), C.byref(rep), num_threads, num_linear_solver_threads, _dp(pt))
+    if rc != 0:
+        raise RuntimeError("oracle_ba_solve rc=%d" % rc)
+    return rep.as_dict(), pt
+
+
+def adjust_pose_only(window, prior, opts, num_threads=1):
+    lib = load()
+    s = window.as_struct()
+    rep = _ffi.BaReport()
+    rc = lib.oracle_ba_adjust_pose_only(C.byref(s), None if prior is None else C.byref(prior), C.byref(opts), C.byref(rep), num_threads)
+    if rc != 0:
+        raise RuntimeError("oracle_ba_adjust_pose_only rc=%d" % rc)
+    return rep.as_dict()
+
+
+def evaluate(window, opts, apply_loss=True):
+    lib = load()
+    s = window.as_struct()
+    M = window.n_obs
+    cost = np.zeros(1)
+    res = np.zeros((M, 3))
+    jp = np.zeros((M, 3, 6))
+    jl = np.zeros((M, 3, 3))
+    valid = np.zeros(M, np.uint8)
+    rc = lib.oracle_ba_evaluate(C.byref(s), C.byref(opts), int(apply_loss), _dp(cost), _dp(res), _dp(jp), _dp(jl), valid.ctypes.data_as(_ffi.c_uint8_p))
+    if rc != 0:
+        raise RuntimeError("oracle_ba_evaluate rc=%d" % rc)
+    return float(cost[0]), res, jp, jl, valid
+
+
+def problem_cost(window, opts):
+    lib = load()
+    s = window.as_struct()
+    cost = np.zeros(1)
+    counts = np.zeros(3, np.int32)
+    lib.oracle_ba_problem_cost(C.byref(s), C.byref(opts), _dp(cost), counts.ctypes.data_as(_ffi.c_int32_p))
+    return float(cost[0]), counts
+
+
+def functor(kind, consts, *params, nres=3):
+    lib = load()
+    consts = np.ascontiguousarray(consts if consts is not None else [0.0], np.float64)
+    ps = [np.ascontiguousarray(p, np.float64) for p in params] + [None] * (4 - len(params))
+    out = np.zeros(3)
+    ok = lib.oracle_functor(kind, _dp(consts), _dp(ps[0]), _dp(ps[1]), _dp(ps[2]), _dp(ps[3]), _dp(out))
+    return ok, out[:nres]
+
+
+def loss(kind, a, weight, s):
+    lib = load()
+    rho = np.zeros(3)
+    lib.oracle_loss(kind, a, weight, s, _dp(rho))
+    return rho
+
+
+def plus(kind, x, delta):
+    lib = load()
+    x = np.ascontiguousarray(x, np.float64)
+    delta = np.ascontiguousarray(delta, np.float64)
+    n = 7 if kind == 0 else 3
+    l = 6 if kind == 0 else 3
+    out = np.zeros(n)
+    jac = np.zeros((n, l))
+    lib.oracle_plus(kind, _dp(x), _dp(delta), _dp(out), _dp(jac))
+    return out, jac
+
+
+def trim_quantile(ids, values, q):
+    lib = load()
+    ids = np.ascontiguousarray(ids, np.int64)
+    values = np.ascontiguousarray(values, np.float64)
+    out = np.zeros(len(ids), np.int64)
+    n = lib.oracle_trim_quantile(len(ids), ids.ctypes.data_as(_ffi.c_int64_p), _dp(values), q, out.ctypes.data_as(_ffi.c_int64_p))
+    return out[:n]
+
+
+def trim_fix(ids, values, thres):
+    lib = load()
+    ids = np.ascontiguousarray(ids, np.int64)
+    values = np.ascontiguousarray(values, np.float64)
+    out = np.zeros(len(ids), np.int64)
+    n = lib.oracle_trim_fix(len(ids), ids.ctypes.data_as(_ffi.c_int64_p), _dp(values), thres, out.ctypes.data_as(_ffi.c_int64_p))
+    return out[:n]
+
+
+def landmark_init(ray_off, rays, use_depth):
+    lib = load()
+    n = len(ray_off) - 1
+    ray_off = np.ascontiguousarray(ray_off, np.int32)
+    use_depth = np.ascontiguousarray(use_depth, np.uint8)
+    pos = np.zeros((n, 3))
+    ok = np.zeros(n, np.uint8)
+    lib.oracle_landmark_init(n, ray_off.ctypes.data_as(_ffi.c_int32_p), rays, use_depth.ctypes.data_as(_ffi.c_uint8_p), _dp(pos), ok.ctypes.data_as(_ffi.c_uint8_p))
+    return pos, ok
