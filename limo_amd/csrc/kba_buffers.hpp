@@ -1,0 +1,101 @@
+// kba_buffers.hpp — the list of buffers behind a BatchView, written once so the HIP library (hipMalloc /
+// hipMemcpy) and the test emulator (malloc / memcpy) allocate exactly the same layout.
+#pragma once
+#include <cstddef>
+
+#include "kba_pack.hpp"
+
+namespace kba {
+
+// f(void** slot, size_t bytes, const void* init /* may be null: zero-fill */)
+template <typename F>
+void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
+    bv.n_win = P.n_win;
+    bv.TK = P.TK;
+    bv.TL = P.TL;
+    bv.TO = P.TO;
+    bv.TV = P.TV;
+    bv.TG = P.TG;
+    bv.n_blk = P.n_blk;
+    bv.n_lblk = P.n_lblk;
+    bv.n_sblk = P.n_sblk;
+    bv.Vmax = P.Vmax;
+    bv.SO = P.SO;
+    bv.SL = P.SL;
+    bv.SG = P.SG;
+    const size_t D = sizeof(double), I = sizeof(int32_t);
+    const size_t TK = (size_t)(P.TK > 0 ? P.TK : 1), TL = (size_t)(P.TL > 0 ? P.TL : 1), TO = (size_t)(P.TO > 0 ? P.TO : 1),
+                 TV = (size_t)(P.TV > 0 ? P.TV : 1), TG = (size_t)(P.TG > 0 ? P.TG : 1);
+    const size_t NB = (size_t)(P.n_blk > 0 ? P.n_blk : 1), NL = (size_t)(P.n_lblk > 0 ? P.n_lblk : 1),
+                 NS = (size_t)(P.n_sblk > 0 ? P.n_sblk : 1), NW = (size_t)P.n_win;
+#define KBA_BUF(field, bytes, init) f((void**)&bv.field, (size_t)(bytes), (const void*)(init))
+    KBA_BUF(win, NW * sizeof(WinDesc), P.win.data());
+    KBA_BUF(st, NW * sizeof(WinState), nullptr);
+    KBA_BUF(red, NW * sizeof(WinRed), nullptr);
+    KBA_BUF(pose, TK * 7 * D, P.pose.data());
+    KBA_BUF(pdir, TK * 3 * D, P.pdir.data());
+    KBA_BUF(pdist, TK * D, P.pdist.data());
+    KBA_BUF(lm, TL * 3 * D, P.lm.data());
+    KBA_BUF(pose_c, TK * 7 * D, P.pose.data());
+    KBA_BUF(pdir_c, TK * 3 * D, P.pdir.data());
+    KBA_BUF(pdist_c, TK * D, P.pdist.data());
+    KBA_BUF(lm_c, TL * 3 * D, P.lm.data());
+    KBA_BUF(kf_win, TK * I, P.kf_win.data());
+    KBA_BUF(cmask, TK * kCamSlots, P.cmask.data());
+    KBA_BUF(cpresent, TK * kCamSlots, P.cpresent.data());
+    KBA_BUF(lm_win, TL * I, P.lm_win.data());
+    KBA_BUF(lm_weight, TL * D, P.lm_weight.data());
+    KBA_BUF(lm_state, TL, P.lm_state.data());
+    KBA_BUF(lm_gp, TL * I, P.lm_gp.data());
+    KBA_BUF(lm_slot, P.lm_slot.size() * I, P.lm_slot.data());
+    KBA_BUF(view_kf, TV * I, P.view_kf.data());
+    KBA_BUF(view_win, TV * I, P.view_win.data());
+    KBA_BUF(view_cam, TV * 16 * D, P.view_cam.data());
+    KBA_BUF(blk_view, NB * I, P.blk_view.data());
+    KBA_BUF(blk_obs0, NB * I, P.blk_obs0.data());
+    KBA_BUF(blk_n, NB * I, P.blk_n.data());
+    KBA_BUF(obs_lm, TO * I, P.obs_lm.data());
+    KBA_BUF(obs_u, TO * sizeof(float), P.obs_u.data());
+    KBA_BUF(obs_v, TO * sizeof(float), P.obs_v.data());
+    KBA_BUF(obs_d, TO * sizeof(float), P.obs_d.data());
+    KBA_BUF(lblk_win, NL * I, P.lblk_win.data());
+    KBA_BUF(lblk_lm0, NL * I, P.lblk_lm0.data());
+    KBA_BUF(lblk_n, NL * I, P.lblk_n.data());
+    KBA_BUF(sblk_win, NS * I, P.sblk_win.data());
+    KBA_BUF(sblk_lm0, NS * I, P.sblk_lm0.data());
+    KBA_BUF(sblk_n, NS * I, P.sblk_n.data());
+    KBA_BUF(gp_lm, TG * I, P.gp_lm.data());
+    KBA_BUF(gp_kf, TG * I, P.gp_kf.data());
+    KBA_BUF(gp_w, TG * D, P.gp_w.data());
+    KBA_BUF(gp_r, (size_t)P.SG * D, nullptr);
+    KBA_BUF(gp_F, (size_t)P.SG * 10 * D, nullptr);
+    KBA_BUF(gp_E, (size_t)P.SG * 3 * D, nullptr);
+    KBA_BUF(gp_cost, TG * D, nullptr);
+    KBA_BUF(gp_cost_c, TG * D, nullptr);
+    KBA_BUF(obs_r, (size_t)P.SO * 3 * D, nullptr);
+    KBA_BUF(obs_Jp, (size_t)P.SO * 18 * D, nullptr);
+    KBA_BUF(obs_Jl, (size_t)P.SO * 9 * D, nullptr);
+    KBA_BUF(blk_part, NB * kLinPartial * D, nullptr);
+    KBA_BUF(blk_fail, NB * I, nullptr);
+    KBA_BUF(blk_cost_c, NB * D, nullptr);
+    KBA_BUF(blk_fail_c, NB * I, nullptr);
+    KBA_BUF(lm_V, (size_t)P.SL * 6 * D, nullptr);
+    KBA_BUF(lm_g, (size_t)P.SL * 3 * D, nullptr);
+    KBA_BUF(lm_scale, (size_t)P.SL * 3 * D, nullptr);
+    KBA_BUF(lm_Li, (size_t)P.SL * 6 * D, nullptr);
+    KBA_BUF(lm_t, (size_t)P.SL * 3 * D, nullptr);
+    KBA_BUF(lblk_part, NL * 8 * D, nullptr);
+    KBA_BUF(Hcc, (size_t)(P.hcc_total > 0 ? P.hcc_total : 1) * D, nullptr);
+    KBA_BUF(gc, TK * kCamSlots * D, nullptr);
+    KBA_BUF(scale_c, TK * kCamSlots * D, nullptr);
+    KBA_BUF(yc, TK * kCamSlots * D, nullptr);
+    KBA_BUF(delta_c, TK * kCamSlots * D, nullptr);
+    KBA_BUF(S_part, (size_t)(P.spart_total > 0 ? P.spart_total : 1) * D, nullptr);
+    KBA_BUF(reg_cost, NW * 2 * D, nullptr);
+    KBA_BUF(trim_rep, TL * D, nullptr);
+    KBA_BUF(trim_dep, TL * D, nullptr);
+    KBA_BUF(n_active, 4 * I, nullptr);
+#undef KBA_BUF
+}
+
+}  // namespace kba

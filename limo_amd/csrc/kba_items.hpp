@@ -1,0 +1,885 @@
+// kba_items.hpp — the work each lane / workgroup does in every kernel of the batched BA pipeline.
+//
+// Lane-level items are plain functions of (batch view, item index); cooperative (workgroup-per-window) items
+// take (tid, nthreads) and a scratch pointer and use KBA_SYNC between phases, so the same statements run
+//   * on gfx950 inside the __global__ wrappers of kba_kernels.hip (tid = threadIdx.x, scratch = LDS), and
+//   * serially in tests/cpp/emu_pipeline.cpp (tid = 0, nthreads = 1) for CPU-side unit tests of the host logic.
+// Reference rows: B1/B2 linearize_lane, B3 gp_lane, B4 cam_regs, B5 losses (kba_math.hpp),
+// B6 manifolds, B7 trim_*, B8 lm_accum/lm_damp/schur_*/cam_assemble/cam_solve/backsub_lane.
+#pragma once
+#include "kba_layout.hpp"
+#include "kba_lm.hpp"
+#include "kba_math.hpp"
+
+#ifndef KBA_SYNC
+#define KBA_SYNC() ((void)0)
+#endif
+
+namespace kba {
+
+// ======================================================================================= observations
+struct LinLane {
+    double cost;
+    int fail;
+    double U[21];  // upper triangle of Jp^T Jp (6x6), row-major
+    double g[6];   // Jp^T r
+};
+
+// Lane t of linearize workgroup b: residuals + Jacobians of one observation at the CURRENT parameters.
+KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out) {
+    out.cost = 0.0;
+    out.fail = 0;
+    for (int i = 0; i < 21; ++i) out.U[i] = 0.0;
+    for (int i = 0; i < 6; ++i) out.g[i] = 0.0;
+    if (t >= bv.blk_n[b]) return;
+    const int view = bv.blk_view[b];
+    const int64_t o = bv.blk_obs0[b] + t;
+    const int gl = bv.obs_lm[o];
+    ObsOut oo;
+    bool live = bv.lm_state[gl] != 0;
+    bool ok = true;
+    if (live) {
+        const double* cam = bv.view_cam + 16 * (int64_t)view;
+        ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
+                                   bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
+                                   c.a_rep, c.a_dep, true, &oo);
+    }
+    if (!live || !ok) {
+        for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
+        for (int i = 0; i < 18; ++i) oo.Jp[i] = 0.0;
+        for (int i = 0; i < 9; ++i) oo.Jl[i] = 0.0;
+        oo.cost = 0.0;
+        if (live) out.fail = 1;
+    }
+    for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
+    for (int i = 0; i < 18; ++i) bv.obs_Jp[i * bv.SO + o] = oo.Jp[i];
+    for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
+    out.cost = oo.cost;
+    int k = 0;
+    for (int a = 0; a < 6; ++a) {
+        for (int bb = a; bb < 6; ++bb)
+            out.U[k++] = oo.Jp[a] * oo.Jp[bb] + oo.Jp[6 + a] * oo.Jp[6 + bb] + oo.Jp[12 + a] * oo.Jp[12 + bb];
+        out.g[a] = oo.Jp[a] * oo.r[0] + oo.Jp[6 + a] * oo.r[1] + oo.Jp[12 + a] * oo.r[2];
+    }
+}
+
+// Cost of one observation at the CANDIDATE parameters.
+KBA_HD void cost_lane(const BatchView& bv, const SolveConsts& c, int b, int t, double& cost, int& fail) {
+    cost = 0.0;
+    fail = 0;
+    if (t >= bv.blk_n[b]) return;
+    const int view = bv.blk_view[b];
+    const int64_t o = bv.blk_obs0[b] + t;
+    const int gl = bv.obs_lm[o];
+    if (!bv.lm_state[gl]) return;
+    const double* cam = bv.view_cam + 16 * (int64_t)view;
+    double cst;
+    if (!obs_cost(bv.pose_c + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
+                  bv.lm_c + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl], c.a_rep, c.a_dep,
+                  &cst)) {
+        fail = 1;
+        return;
+    }
+    cost = cst;
+}
+
+// Un-robustified residual norms for trimming (robust_solving.cpp:24-44 with apply_loss = false).
+KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_rep, double* plane_dep) {
+    if (t >= bv.blk_n[b]) return;
+    const int view = bv.blk_view[b];
+    const int64_t o = bv.blk_obs0[b] + t;
+    const int gl = bv.obs_lm[o];
+    double nr = -1.0, nd = -1.0;
+    if (bv.lm_state[gl]) {
+        const double* cam = bv.view_cam + 16 * (int64_t)view;
+        double ruv[2], rd;
+        if (obs_residual(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
+                         bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], ruv, &rd, nullptr)) {
+            nr = sqrt(ruv[0] * ruv[0] + ruv[1] * ruv[1]);
+            if (bv.obs_d[o] > 0.0f) nd = sqrt(rd * rd);
+        } else {
+            nr = INFINITY;
+            if (bv.obs_d[o] > 0.0f) nd = INFINITY;
+        }
+    }
+    plane_rep[o] = nr;
+    plane_dep[o] = nd;
+}
+
+// ======================================================================================= ground plane
+KBA_HD void gp_lane(const BatchView& bv, int g, bool candidate, double* cost_out) {
+    const int gl = bv.gp_lm[g];
+    const int gk = bv.gp_kf[g];
+    GpOut o;
+    if (!bv.lm_state[gl]) {
+        if (!candidate) {
+            bv.gp_r[g] = 0.0;
+            for (int i = 0; i < 10; ++i) bv.gp_F[i * bv.SG + g] = 0.0;
+            for (int i = 0; i < 3; ++i) bv.gp_E[i * bv.SG + g] = 0.0;
+        }
+        cost_out[g] = 0.0;
+        return;
+    }
+    if (candidate) {
+        gp_residual_jacobian(bv.pose_c + 7 * (int64_t)gk, bv.pdir_c + 3 * (int64_t)gk, bv.pdist_c[gk],
+                             bv.lm_c + 3 * (int64_t)gl, bv.gp_w[g], true, false, &o);
+        cost_out[g] = o.cost;
+        return;
+    }
+    gp_residual_jacobian(bv.pose + 7 * (int64_t)gk, bv.pdir + 3 * (int64_t)gk, bv.pdist[gk], bv.lm + 3 * (int64_t)gl,
+                         bv.gp_w[g], true, true, &o);
+    bv.gp_r[g] = o.r;
+    for (int i = 0; i < 10; ++i) bv.gp_F[i * bv.SG + g] = o.F[i];
+    for (int i = 0; i < 3; ++i) bv.gp_E[i * bv.SG + g] = o.E[i];
+    cost_out[g] = o.cost;
+}
+
+// ======================================================================================= landmarks
+// V = sum E^T E, g = sum E^T r over the landmark's observations (+ its ground-plane row).
+// part: [0] max|g| (gradient inf-norm part), [1] |x|^2
+KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, double* part) {
+    part[0] = 0.0;
+    part[1] = 0.0;
+    if (bv.lm_state[gl] != 1) return;
+    const int w = bv.lm_win[gl];
+    const WinDesc& wd = bv.win[w];
+    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int j = 0; j < wd.n_view; ++j) {
+        const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+        if (s < 0) continue;
+        double E[9], r[3];
+        for (int i = 0; i < 9; ++i) E[i] = bv.obs_Jl[i * bv.SO + s];
+        for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
+        for (int row = 0; row < 3; ++row) {
+            const double e0 = E[row * 3], e1 = E[row * 3 + 1], e2 = E[row * 3 + 2];
+            V[0] += e0 * e0;
+            V[1] += e0 * e1;
+            V[2] += e0 * e2;
+            V[3] += e1 * e1;
+            V[4] += e1 * e2;
+            V[5] += e2 * e2;
+            g[0] += e0 * r[row];
+            g[1] += e1 * r[row];
+            g[2] += e2 * r[row];
+        }
+    }
+    const int gg = bv.lm_gp[gl];
+    if (gg >= 0) {
+        const double e0 = bv.gp_E[0 * bv.SG + gg], e1 = bv.gp_E[1 * bv.SG + gg], e2 = bv.gp_E[2 * bv.SG + gg];
+        const double r = bv.gp_r[gg];
+        V[0] += e0 * e0;
+        V[1] += e0 * e1;
+        V[2] += e0 * e2;
+        V[3] += e1 * e1;
+        V[4] += e1 * e2;
+        V[5] += e2 * e2;
+        g[0] += e0 * r;
+        g[1] += e1 * r;
+        g[2] += e2 * r;
+    }
+    for (int i = 0; i < 6; ++i) bv.lm_V[i * bv.SL + gl] = V[i];
+    for (int i = 0; i < 3; ++i) bv.lm_g[i * bv.SL + gl] = g[i];
+    if (bv.st[w].compute_scale) {
+        const double d[3] = {V[0], V[3], V[5]};
+        for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
+    }
+    part[0] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    const double* x = bv.lm + 3 * (int64_t)gl;
+    part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+}
+
+// (V' + D^2) = L L^T with V' = S V S (Jacobi-scaled), D^2 = clamp(diag V')/radius;  stores L^-1 and t = L^-1 S g.
+// Returns 1 on Cholesky failure.
+KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
+    if (bv.lm_state[gl] != 1) return 0;
+    const int w = bv.lm_win[gl];
+    const double radius = bv.st[w].radius;
+    double s[3], V[6], g[3];
+    for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) g[i] = s[i] * bv.lm_g[i * bv.SL + gl];
+    double A[6] = {s[0] * s[0] * V[0], s[0] * s[1] * V[1], s[0] * s[2] * V[2],
+                   s[1] * s[1] * V[3], s[1] * s[2] * V[4], s[2] * s[2] * V[5]};
+    A[0] += fmin(fmax(A[0], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+    A[3] += fmin(fmax(A[3], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+    A[5] += fmin(fmax(A[5], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+    double Li[6];
+    int fail = 0;
+    if (!chol3_inv(A, Li)) {
+        fail = 1;
+        for (int i = 0; i < 6; ++i) Li[i] = 0.0;
+    }
+    for (int i = 0; i < 6; ++i) bv.lm_Li[i * bv.SL + gl] = Li[i];
+    bv.lm_t[0 * bv.SL + gl] = Li[0] * g[0];
+    bv.lm_t[1 * bv.SL + gl] = Li[1] * g[0] + Li[2] * g[1];
+    bv.lm_t[2 * bv.SL + gl] = Li[3] * g[0] + Li[4] * g[1] + Li[5] * g[2];
+    return fail;
+}
+
+// ======================================================================================= Schur tiles
+// Z tile layout: Z[k * ld + row], k = 3*li + c' (li = landmark within tile), row = camera slot of the window.
+// Y' = W' L^-T with W' = S_c F^T E S_l;  sum_i Y'_i Y'_i^T = W' (V'+D^2)^-1 W'^T.
+// Adds landmark gl's contribution for view j into the tile (caller guarantees exclusive ownership of the
+// (landmark, keyframe) rows, see kba_kernels.hip).
+KBA_HD void schur_fill_view(const BatchView& bv, const WinDesc& wd, int gl, int li, int j, double* Z, int ld) {
+    const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+    if (s < 0) return;
+    const int gk = bv.view_kf[wd.view0 + j];
+    const int row0 = (gk - wd.kf0) * kCamSlots;
+    double sl[3], Li[6];
+    for (int i = 0; i < 3; ++i) sl[i] = bv.lm_scale[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
+    double E[9];
+    for (int i = 0; i < 9; ++i) E[i] = bv.obs_Jl[i * bv.SO + s];
+    for (int a = 0; a < 6; ++a) {
+        if (!bv.cmask[(int64_t)gk * kCamSlots + a]) continue;
+        const double f0 = bv.obs_Jp[(0 * 6 + a) * bv.SO + s], f1 = bv.obs_Jp[(1 * 6 + a) * bv.SO + s],
+                     f2 = bv.obs_Jp[(2 * 6 + a) * bv.SO + s];
+        const double sc = bv.scale_c[(int64_t)gk * kCamSlots + a];
+        const double w0 = sc * (f0 * E[0] + f1 * E[3] + f2 * E[6]) * sl[0];
+        const double w1 = sc * (f0 * E[1] + f1 * E[4] + f2 * E[7]) * sl[1];
+        const double w2 = sc * (f0 * E[2] + f1 * E[5] + f2 * E[8]) * sl[2];
+        // Y'[a][c'] = sum_c W[a][c] Li[c'][c]
+        Z[(3 * li + 0) * ld + row0 + a] += w0 * Li[0];
+        Z[(3 * li + 1) * ld + row0 + a] += w0 * Li[1] + w1 * Li[2];
+        Z[(3 * li + 2) * ld + row0 + a] += w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+    }
+}
+
+KBA_HD void schur_fill_gp(const BatchView& bv, const WinDesc& wd, int gl, int li, double* Z, int ld) {
+    const int gg = bv.lm_gp[gl];
+    if (gg < 0) return;
+    const int gk = bv.gp_kf[gg];
+    const int row0 = (gk - wd.kf0) * kCamSlots;
+    double sl[3], Li[6], E[3];
+    for (int i = 0; i < 3; ++i) sl[i] = bv.lm_scale[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) E[i] = bv.gp_E[i * bv.SG + gg];
+    for (int a = 0; a < kCamSlots; ++a) {
+        if (!bv.cmask[(int64_t)gk * kCamSlots + a]) continue;
+        const double f = bv.gp_F[a * bv.SG + gg] * bv.scale_c[(int64_t)gk * kCamSlots + a];
+        const double w0 = f * E[0] * sl[0], w1 = f * E[1] * sl[1], w2 = f * E[2] * sl[2];
+        Z[(3 * li + 0) * ld + row0 + a] += w0 * Li[0];
+        Z[(3 * li + 1) * ld + row0 + a] += w0 * Li[1] + w1 * Li[2];
+        Z[(3 * li + 2) * ld + row0 + a] += w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+    }
+}
+
+// ======================================================================================= back-substitution
+// y_l = (V'+D^2)^-1 (g' - W'^T y_c);  delta_l = -S_l y_l;  candidate = lm + delta_l.
+// part: [2] model-cost-change part, [3] |x - x_cand|^2, [4] |x_cand|^2
+KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
+    part[2] = part[3] = part[4] = 0.0;
+    double* xc = bv.lm_c + 3 * (int64_t)gl;
+    const double* x = bv.lm + 3 * (int64_t)gl;
+    if (bv.lm_state[gl] != 1) {
+        xc[0] = x[0];
+        xc[1] = x[1];
+        xc[2] = x[2];
+        return;
+    }
+    const int w = bv.lm_win[gl];
+    const WinDesc& wd = bv.win[w];
+    double a[3] = {0, 0, 0};
+    for (int j = 0; j < wd.n_view; ++j) {
+        const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+        if (s < 0) continue;
+        const int gk = bv.view_kf[wd.view0 + j];
+        const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
+        double q[3];
+        for (int row = 0; row < 3; ++row) {
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += bv.obs_Jp[(row * 6 + k) * bv.SO + s] * dc[k];
+            q[row] = acc;
+        }
+        for (int cc = 0; cc < 3; ++cc)
+            a[cc] += bv.obs_Jl[(0 * 3 + cc) * bv.SO + s] * q[0] + bv.obs_Jl[(1 * 3 + cc) * bv.SO + s] * q[1] +
+                     bv.obs_Jl[(2 * 3 + cc) * bv.SO + s] * q[2];
+    }
+    const int gg = bv.lm_gp[gl];
+    if (gg >= 0) {
+        const int gk = bv.gp_kf[gg];
+        const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
+        double q = 0.0;
+        for (int k = 0; k < kCamSlots; ++k) q += bv.gp_F[k * bv.SG + gg] * dc[k];
+        for (int cc = 0; cc < 3; ++cc) a[cc] += bv.gp_E[cc * bv.SG + gg] * q;
+    }
+    double s[3], Li[6], t[3], V[6], g[3];
+    for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) t[i] = bv.lm_t[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
+    // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c)
+    const double b0 = s[0] * a[0], b1 = s[1] * a[1], b2 = s[2] * a[2];
+    const double t0 = t[0] + Li[0] * b0;
+    const double t1 = t[1] + Li[1] * b0 + Li[2] * b1;
+    const double t2 = t[2] + Li[3] * b0 + Li[4] * b1 + Li[5] * b2;
+    // y = L^-T t
+    const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
+    const double y1 = Li[2] * t1 + Li[4] * t2;
+    const double y2 = Li[5] * t2;
+    const double d0 = -s[0] * y0, d1 = -s[1] * y1, d2 = -s[2] * y2;
+    xc[0] = x[0] + d0;
+    xc[1] = x[1] + d1;
+    xc[2] = x[2] + d2;
+    const double Vd0 = V[0] * d0 + V[1] * d1 + V[2] * d2;
+    const double Vd1 = V[1] * d0 + V[3] * d1 + V[4] * d2;
+    const double Vd2 = V[2] * d0 + V[4] * d1 + V[5] * d2;
+    part[2] = -(g[0] * d0 + g[1] * d1 + g[2] * d2) - (a[0] * d0 + a[1] * d1 + a[2] * d2) -
+              0.5 * (d0 * Vd0 + d1 * Vd1 + d2 * Vd2);
+    const double e0 = x[0] - xc[0], e1 = x[1] - xc[1], e2 = x[2] - xc[2];
+    part[3] = e0 * e0 + e1 * e1 + e2 * e2;
+    part[4] = xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
+}
+
+// ======================================================================================= camera-only rows
+// Regulariser rows of a window (bundle_adjuster_keyframes.cpp:769-818, :890-904, :835-853; functors
+// cost_functors_ceres.hpp:224-250, 300-353, 394-438, 507-555), analytic, as sparse rows over the window's camera
+// slots: up to 16 (column, value) pairs per row.  Row residuals/Jacobians are multiplied by sqrt(weight)
+// (ScaledLoss(TrivialLoss, w) => rho = w s, corrector = sqrt(w)).
+struct RegRow {
+    double r;
+    int n;
+    int col[16];
+    double val[16];
+};
+
+KBA_HD void quat_apply_jac(const double* q, const double* p, double* A) {  // A[3][4] = d(R(q)p)/d(w,x,y,z)
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double p0 = p[0], p1 = p[1], p2 = p[2];
+    A[0] = 2.0 * (y * p2 - z * p1);
+    A[4] = 2.0 * (z * p0 - x * p2);
+    A[8] = 2.0 * (x * p1 - y * p0);
+    A[1] = 2.0 * (y * p1 + z * p2);
+    A[5] = 2.0 * (y * p0 - 2.0 * x * p1 - w * p2);
+    A[9] = 2.0 * (z * p0 + w * p1 - 2.0 * x * p2);
+    A[2] = 2.0 * (-2.0 * y * p0 + x * p1 + w * p2);
+    A[6] = 2.0 * (x * p0 + z * p2);
+    A[10] = 2.0 * (-w * p0 + z * p1 - 2.0 * y * p2);
+    A[3] = 2.0 * (-2.0 * z * p0 - w * p1 + x * p2);
+    A[7] = 2.0 * (w * p0 - 2.0 * z * p1 + y * p2);
+    A[11] = 2.0 * (x * p0 + y * p1);
+}
+
+// N (3x3) = d(R(q)^T v)/d(rot tangent):  R(q)^T = R(conj q) for the polynomial form.
+KBA_HD void rotT_tangent_jac(const double* q, const double* v, double* N) {
+    const double qc[4] = {q[0], -q[1], -q[2], -q[3]};
+    double A[12];
+    quat_apply_jac(qc, v, A);
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    for (int i = 0; i < 3; ++i) {
+        const double aw = A[i * 4 + 0], ax = -A[i * 4 + 1], ay = -A[i * 4 + 2], az = -A[i * 4 + 3];
+        N[i * 3 + 0] = -aw * x + ax * w - ay * z + az * y;
+        N[i * 3 + 1] = -aw * y + ax * z + ay * w - az * x;
+        N[i * 3 + 2] = -aw * z - ax * y + ay * x + az * w;
+    }
+}
+
+// d = t_a - R_a R_b^T t_b (translation of T_a * T_b^-1) and its derivatives wrt both tangents.
+// Ja[3][6], Jb[3][6] (rot 3, trans 3)
+KBA_HD void rel_translation(const double* pa, const double* pb, double* d, double* Ja, double* Jb, bool want_jac) {
+    double Ra[9], Rb[9], u[3], Ru[3];
+    quat_R(pa, Ra);
+    quat_R(pb, Rb);
+    // u = R_b^T t_b
+    for (int i = 0; i < 3; ++i) u[i] = Rb[0 + i] * pb[4] + Rb[3 + i] * pb[5] + Rb[6 + i] * pb[6];
+    mat3_vec(Ra, u, Ru);
+    for (int i = 0; i < 3; ++i) d[i] = pa[4 + i] - Ru[i];
+    if (!want_jac) return;
+    double M[9], N[9];
+    rot_tangent_jac(pa, u, M);
+    rotT_tangent_jac(pb, pb + 4, N);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Ja[i * 6 + j] = -M[i * 3 + j];
+            Ja[i * 6 + 3 + j] = (i == j) ? 1.0 : 0.0;
+            Jb[i * 6 + j] = -(Ra[i * 3 + 0] * N[0 + j] + Ra[i * 3 + 1] * N[3 + j] + Ra[i * 3 + 2] * N[6 + j]);
+            // -R_a R_b^T
+            Jb[i * 6 + 3 + j] = -(Ra[i * 3 + 0] * Rb[j * 3 + 0] + Ra[i * 3 + 1] * Rb[j * 3 + 1] + Ra[i * 3 + 2] * Rb[j * 3 + 2]);
+        }
+}
+
+// Number of regulariser rows of a window and evaluation of row `idx`.
+// Row order: [scale reg] then per consecutive pair k0: normal diff (3), dist diff (1), motion (1); then per
+// keyframe global normal (3); pose-only: speed prior (3).
+KBA_HD int reg_row_count(const WinDesc& wd) {
+    int n = 0;
+    if (wd.has_scale_reg) n += 1;
+    if (wd.has_gp_reg) n += (wd.n_kf - 1) * 5 + wd.n_kf * 3;
+    if (wd.pose_only && wd.speed_w > 0.0) n += 3;
+    return n;
+}
+
+// Evaluates row idx at (pose, pdir, pdist) arrays indexed by GLOBAL keyframe.  Columns are LOCAL camera slots.
+// all_const receives 1 if every parameter block of the row's residual block is constant (fixed cost).
+KBA_HD void reg_row_eval(const WinDesc& wd, const uint8_t* cmask, const double* pose, const double* pdir,
+                         const double* pdist, int idx, bool want_jac, RegRow& row, int& all_const) {
+    row.n = 0;
+    row.r = 0.0;
+    all_const = 0;
+    auto blk_free = [&](int kf_local, int slot) { return cmask[(int64_t)(wd.kf0 + kf_local) * kCamSlots + slot] != 0; };
+    auto push = [&](int kf_local, int slot, double v) {
+        row.col[row.n] = kf_local * kCamSlots + slot;
+        row.val[row.n] = v;
+        row.n++;
+    };
+    int i = idx;
+    if (wd.has_scale_reg) {
+        if (i == 0) {  // PoseRegularization(pose[1], pose[0]), weight scale_w
+            const double sw = sqrt(wd.scale_w);
+            double d[3], Ja[18], Jb[18];
+            rel_translation(pose + 7 * (int64_t)(wd.kf0 + 1), pose + 7 * (int64_t)wd.kf0, d, Ja, Jb, want_jac);
+            const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            row.r = sw * (nrm - wd.scale_s0);
+            all_const = !blk_free(1, 0) && !blk_free(0, 0);
+            if (want_jac) {
+                const double e[3] = {d[0] / nrm, d[1] / nrm, d[2] / nrm};
+                for (int k = 0; k < 6; ++k) push(1, k, sw * (e[0] * Ja[k] + e[1] * Ja[6 + k] + e[2] * Ja[12 + k]));
+                for (int k = 0; k < 6; ++k) push(0, k, sw * (e[0] * Jb[k] + e[1] * Jb[6 + k] + e[2] * Jb[12 + k]));
+            }
+            return;
+        }
+        i -= 1;
+    }
+    if (wd.has_gp_reg) {
+        const int npair = wd.n_kf - 1;
+        if (i < npair * 5) {
+            const int k0 = i / 5, sub = i % 5, k1 = k0 + 1;
+            const double* n0 = pdir + 3 * (int64_t)(wd.kf0 + k0);
+            const double* n1 = pdir + 3 * (int64_t)(wd.kf0 + k1);
+            if (sub < 3) {  // VectorDifferenceRegularization(n1, n0), weight 30
+                const double sw = sqrt(30.0);
+                row.r = sw * (n1[sub] - n0[sub]);
+                all_const = !blk_free(k1, 6) && !blk_free(k0, 6);
+                if (want_jac) {
+                    double P1[9], P0[9];
+                    unitvec_plus_jac(n1, P1);
+                    unitvec_plus_jac(n0, P0);
+                    for (int k = 0; k < 3; ++k) push(k1, 6 + k, sw * P1[sub * 3 + k]);
+                    for (int k = 0; k < 3; ++k) push(k0, 6 + k, -sw * P0[sub * 3 + k]);
+                }
+            } else if (sub == 3) {  // GroundPlaneDistanceRegularization(h1, h0), weight 10
+                const double sw = sqrt(10.0);
+                row.r = sw * (pdist[wd.kf0 + k1] - pdist[wd.kf0 + k0]);
+                all_const = !blk_free(k1, 9) && !blk_free(k0, 9);
+                if (want_jac) {
+                    push(k1, 9, sw);
+                    push(k0, 9, -sw);
+                }
+            } else {  // GroundPlaneMotionRegularization(pose_k0, pose_k1, n_k0), weight 20
+                const double sw = sqrt(20.0);
+                double d[3], Ja[18], Jb[18];
+                rel_translation(pose + 7 * (int64_t)(wd.kf0 + k0), pose + 7 * (int64_t)(wd.kf0 + k1), d, Ja, Jb, want_jac);
+                const double z = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                double dn[3] = {d[0], d[1], d[2]};
+                double inv = 1.0;
+                if (z > 0.0) {
+                    inv = 1.0 / sqrt(z);
+                    for (int k = 0; k < 3; ++k) dn[k] *= inv;
+                }
+                row.r = sw * (n0[0] * dn[0] + n0[1] * dn[1] + n0[2] * dn[2]);
+                all_const = !blk_free(k0, 0) && !blk_free(k1, 0) && !blk_free(k0, 6);
+                if (want_jac) {
+                    // d r / d d = n0^T (I - dn dn^T) / |d|   (identity when |d| == 0: normalize() is skipped)
+                    double e[3];
+                    if (z > 0.0) {
+                        const double ndn = n0[0] * dn[0] + n0[1] * dn[1] + n0[2] * dn[2];
+                        for (int k = 0; k < 3; ++k) e[k] = (n0[k] - ndn * dn[k]) * inv;
+                    } else {
+                        for (int k = 0; k < 3; ++k) e[k] = n0[k];
+                    }
+                    double P0[9];
+                    unitvec_plus_jac(n0, P0);
+                    for (int k = 0; k < 6; ++k) push(k0, k, sw * (e[0] * Ja[k] + e[1] * Ja[6 + k] + e[2] * Ja[12 + k]));
+                    for (int k = 0; k < 6; ++k) push(k1, k, sw * (e[0] * Jb[k] + e[1] * Jb[6 + k] + e[2] * Jb[12 + k]));
+                    for (int k = 0; k < 3; ++k)
+                        push(k0, 6 + k, sw * (dn[0] * P0[0 + k] + dn[1] * P0[3 + k] + dn[2] * P0[6 + k]));
+                }
+            }
+            return;
+        }
+        i -= npair * 5;
+        if (i < wd.n_kf * 3) {  // VectorDifferenceRegularization2((0,0,1), n_k), weight 10
+            const int k = i / 3, sub = i % 3;
+            const double sw = sqrt(10.0);
+            const double* n = pdir + 3 * (int64_t)(wd.kf0 + k);
+            const double tgt[3] = {0.0, 0.0, 1.0};
+            row.r = sw * (tgt[sub] - n[sub]);
+            all_const = !blk_free(k, 6);
+            if (want_jac) {
+                double P[9];
+                unitvec_plus_jac(n, P);
+                for (int kk = 0; kk < 3; ++kk) push(k, 6 + kk, -sw * P[sub * 3 + kk]);
+            }
+            return;
+        }
+        i -= wd.n_kf * 3;
+    }
+    if (wd.pose_only && wd.speed_w > 0.0 && i < 3) {
+        // SpeedRegularizationVector2: r = (R_new (-R_b^T t_b) + t_new)/dt - vel_prev
+        const double sw = sqrt(wd.speed_w);
+        const double* p = pose + 7 * (int64_t)wd.kf0;
+        double u[3], R[9], Ru[3];
+        for (int k = 0; k < 3; ++k)
+            u[k] = -(wd.speed_Rb[0 + k] * wd.speed_tb[0] + wd.speed_Rb[3 + k] * wd.speed_tb[1] + wd.speed_Rb[6 + k] * wd.speed_tb[2]);
+        quat_R(p, R);
+        mat3_vec(R, u, Ru);
+        row.r = sw * ((Ru[i] + p[4 + i]) / wd.speed_dt - wd.speed_vel[i]);
+        all_const = !blk_free(0, 0);
+        if (want_jac) {
+            double M[9];
+            rot_tangent_jac(p, u, M);
+            for (int k = 0; k < 3; ++k) push(0, k, sw * M[i * 3 + k] / wd.speed_dt);
+            for (int k = 0; k < 3; ++k) push(0, 3 + k, sw * ((i == k) ? 1.0 : 0.0) / wd.speed_dt);
+        }
+        return;
+    }
+}
+
+// ======================================================================================= camera system
+// |x - Plus(x, -g)|_inf for one camera-side block.
+KBA_HD double block_grad_inf(int kind, const double* x, const double* g) {
+    double out[7], d[6], m = 0.0;
+    if (kind == 0) {
+        for (int i = 0; i < 6; ++i) d[i] = -g[i];
+        pose_plus(x, d, out);
+        for (int i = 0; i < 7; ++i) m = fmax(m, fabs(x[i] - out[i]));
+    } else if (kind == 1) {
+        for (int i = 0; i < 3; ++i) d[i] = -g[i];
+        unitvec_plus(x, d, out);
+        for (int i = 0; i < 3; ++i) m = fmax(m, fabs(x[i] - out[i]));
+    } else {
+        m = fabs(g[0]);
+    }
+    return m;
+}
+
+// Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
+// Jacobi scaling of the camera columns, cost / gradient-norm / |x| reductions.  H (nc*nc) lives in scratch.
+// lin partial inputs: blk_part (per linearize workgroup), gp planes, lblk_part (per landmark workgroup).
+KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* H) {
+    const WinDesc& wd = bv.win[w];
+    const int nc = wd.nc;
+    double* gc = bv.gc + (int64_t)wd.cam0;
+    for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
+    for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
+    KBA_SYNC();
+    // (1) observation blocks: U_k (6x6) and g_k per keyframe, summed over the workgroups of its views.
+    //     One lane per (keyframe, entry) so every output has a single writer and a fixed summation order.
+    for (int e = tid; e < wd.n_kf * 27; e += nt) {
+        const int kl = e / 27, q = e % 27;
+        double acc = 0.0;
+        for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
+            if (bv.view_kf[bv.blk_view[b]] != wd.kf0 + kl) continue;
+            acc += bv.blk_part[(int64_t)b * kLinPartial + 1 + q];
+        }
+        if (q < 21) {
+            int a = 0, rem = q;
+            while (rem >= 6 - a) {
+                rem -= 6 - a;
+                ++a;
+            }
+            const int bb = a + rem;
+            H[(kl * kCamSlots + a) * nc + kl * kCamSlots + bb] += acc;
+            if (bb != a) H[(kl * kCamSlots + bb) * nc + kl * kCamSlots + a] += acc;
+        } else {
+            gc[kl * kCamSlots + (q - 21)] += acc;
+        }
+    }
+    KBA_SYNC();
+    // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe
+    for (int e = tid; e < wd.n_kf * 110; e += nt) {
+        const int kl = e / 110, q = e % 110;
+        const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : -1;
+        double acc = 0.0;
+        for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) {
+            if (bv.gp_kf[g] != wd.kf0 + kl) continue;
+            const double fa = bv.gp_F[a * bv.SG + g];
+            acc += fa * (bb >= 0 ? bv.gp_F[bb * bv.SG + g] : bv.gp_r[g]);
+        }
+        if (bb >= 0)
+            H[(kl * kCamSlots + a) * nc + kl * kCamSlots + bb] += acc;
+        else
+            gc[kl * kCamSlots + a] += acc;
+    }
+    KBA_SYNC();
+    // (3) regulariser rows (few): single lane per row writes its sparse outer product serially over rows
+    const int nrows = reg_row_count(wd);
+    double reg_free = 0.0, reg_fixed = 0.0;
+    if (tid == 0) {
+        for (int i = 0; i < nrows; ++i) {
+            RegRow row;
+            int all_const;
+            reg_row_eval(wd, bv.cmask, bv.pose, bv.pdir, bv.pdist, i, true, row, all_const);
+            if (all_const) {
+                reg_fixed += 0.5 * row.r * row.r;
+                continue;
+            }
+            reg_free += 0.5 * row.r * row.r;
+            for (int p = 0; p < row.n; ++p) {
+                gc[row.col[p]] += row.val[p] * row.r;
+                for (int q = 0; q < row.n; ++q) H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+            }
+        }
+    }
+    KBA_SYNC();
+    // (4) mask constant / absent slots
+    const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
+    for (int i = tid; i < nc * nc; i += nt) {
+        if (!cm[i / nc] || !cm[i % nc]) H[i] = 0.0;
+    }
+    for (int i = tid; i < nc; i += nt)
+        if (!cm[i]) gc[i] = 0.0;
+    KBA_SYNC();
+    double* Hg = bv.Hcc + wd.hcc_off;
+    for (int i = tid; i < nc * nc; i += nt) Hg[i] = H[i];
+    if (bv.st[w].compute_scale) {
+        for (int i = tid; i < nc; i += nt)
+            bv.scale_c[wd.cam0 + i] = (cm[i] && c.jacobi_scaling) ? 1.0 / (1.0 + sqrt(H[i * nc + i])) : 1.0;
+    }
+    // (5) reductions (single lane, fixed order)
+    if (tid == 0) {
+        WinRed& r = bv.red[w];
+        double cost = 0.0;
+        int fail = 0;
+        for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
+            cost += bv.blk_part[(int64_t)b * kLinPartial];
+            fail |= bv.blk_fail[b];
+        }
+        for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) cost += bv.gp_cost[g];
+        cost += reg_free;
+        double gmax = 0.0, xn2 = 0.0;
+        for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
+            gmax = fmax(gmax, bv.lblk_part[(int64_t)b * 8 + 0]);
+            xn2 += bv.lblk_part[(int64_t)b * 8 + 1];
+        }
+        for (int k = 0; k < wd.n_kf; ++k) {
+            const int gk = wd.kf0 + k;
+            if (cm[k * kCamSlots + 0]) {
+                const double* x = bv.pose + 7 * (int64_t)gk;
+                gmax = fmax(gmax, block_grad_inf(0, x, gc + k * kCamSlots));
+                for (int i = 0; i < 7; ++i) xn2 += x[i] * x[i];
+            }
+            if (cm[k * kCamSlots + 6]) {
+                const double* x = bv.pdir + 3 * (int64_t)gk;
+                gmax = fmax(gmax, block_grad_inf(1, x, gc + k * kCamSlots + 6));
+                for (int i = 0; i < 3; ++i) xn2 += x[i] * x[i];
+            }
+            if (cm[k * kCamSlots + 9]) {
+                gmax = fmax(gmax, block_grad_inf(2, bv.pdist + gk, gc + k * kCamSlots + 9));
+                xn2 += bv.pdist[gk] * bv.pdist[gk];
+            }
+        }
+        r.lin_cost = cost;
+        r.lin_fail = fail;
+        r.gmax = gmax;
+        r.xnorm2 = xn2;
+        bv.reg_cost[2 * w] = reg_free;
+        bv.reg_cost[2 * w + 1] = reg_fixed;
+    }
+}
+
+// Workgroup-per-window: S = S_c H S_c + D^2 - sum Schur slabs, rhs = S_c g_c - sum slabs; dense Cholesky; camera
+// step, camera candidate, camera parts of the step reductions.  S (nc*nc) and v (3*nc) live in scratch.
+KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* S, double* v,
+                      int* flag) {
+    const WinDesc& wd = bv.win[w];
+    const int nc = wd.nc, ncp = wd.nc_pad;
+    const double radius = bv.st[w].radius;
+    const double* Hg = bv.Hcc + wd.hcc_off;
+    const double* sc = bv.scale_c + wd.cam0;
+    const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
+    double* rhs = v;
+    double* yc = bv.yc + wd.cam0;
+    double* dc = bv.delta_c + wd.cam0;
+    const int slab = ncp * ncp + ncp;
+    if (tid == 0) *flag = 0;
+    for (int i = tid; i < nc * nc; i += nt) {
+        const int a = i / nc, b = i % nc;
+        double s = sc[a] * sc[b] * Hg[i];
+        if (a == b) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+        for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + a * ncp + b];
+        if (!cm[a] || !cm[b]) s = (a == b) ? 1.0 : 0.0;
+        S[i] = s;
+    }
+    for (int a = tid; a < nc; a += nt) {
+        double s = sc[a] * bv.gc[wd.cam0 + a];
+        for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + ncp * ncp + a];
+        rhs[a] = cm[a] ? s : 0.0;
+    }
+    KBA_SYNC();
+    // right-looking Cholesky on the upper triangle: S = U^T U (Eigen LLT<Upper> semantics: fail when pivot <= 0)
+    for (int k = 0; k < nc; ++k) {
+        if (tid == 0) {
+            const double d = S[k * nc + k];
+            if (!(d > 0.0))
+                *flag = 1;
+            else
+                S[k * nc + k] = sqrt(d);
+        }
+        KBA_SYNC();
+        if (*flag) break;
+        const double dk = S[k * nc + k];
+        for (int j = k + 1 + tid; j < nc; j += nt) S[k * nc + j] /= dk;
+        KBA_SYNC();
+        const int m = nc - k - 1;
+        for (int e = tid; e < m * m; e += nt) {
+            const int i = k + 1 + e / m, j = k + 1 + e % m;
+            if (j >= i) S[i * nc + j] -= S[k * nc + i] * S[k * nc + j];
+        }
+        KBA_SYNC();
+    }
+    if (*flag) {
+        if (tid == 0) {
+            WinRed& r = bv.red[w];
+            r.chol_fail = 1;
+            r.mcc = 0.0;
+            r.step2 = 0.0;
+            r.cand2 = 0.0;
+        }
+        for (int a = tid; a < nc; a += nt) dc[a] = 0.0;
+        return;
+    }
+    if (tid == 0) {
+        // U^T y = rhs ; U x = y
+        for (int i = 0; i < nc; ++i) {
+            double s = rhs[i];
+            for (int p = 0; p < i; ++p) s -= S[p * nc + i] * rhs[p];
+            rhs[i] = s / S[i * nc + i];
+        }
+        for (int i = nc - 1; i >= 0; --i) {
+            double s = rhs[i];
+            for (int p = i + 1; p < nc; ++p) s -= S[i * nc + p] * rhs[p];
+            rhs[i] = s / S[i * nc + i];
+        }
+    }
+    KBA_SYNC();
+    for (int a = tid; a < nc; a += nt) {
+        yc[a] = rhs[a];
+        dc[a] = cm[a] ? -sc[a] * rhs[a] : 0.0;
+    }
+    KBA_SYNC();
+    if (tid == 0) {
+        WinRed& r = bv.red[w];
+        // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled)
+        double gd = 0.0, dHd = 0.0;
+        for (int a = 0; a < nc; ++a) {
+            gd += bv.gc[wd.cam0 + a] * dc[a];
+            double hd = 0.0;
+            for (int b = 0; b < nc; ++b) hd += Hg[a * nc + b] * dc[b];
+            dHd += dc[a] * hd;
+        }
+        double step2 = 0.0, cand2 = 0.0;
+        for (int k = 0; k < wd.n_kf; ++k) {
+            const int gk = wd.kf0 + k;
+            const double* d = dc + k * kCamSlots;
+            const double* x = bv.pose + 7 * (int64_t)gk;
+            double* xc = bv.pose_c + 7 * (int64_t)gk;
+            if (cm[k * kCamSlots + 0]) {
+                pose_plus(x, d, xc);
+                for (int i = 0; i < 7; ++i) {
+                    step2 += (x[i] - xc[i]) * (x[i] - xc[i]);
+                    cand2 += xc[i] * xc[i];
+                }
+            } else {
+                for (int i = 0; i < 7; ++i) xc[i] = x[i];
+            }
+            const double* n = bv.pdir + 3 * (int64_t)gk;
+            double* ncand = bv.pdir_c + 3 * (int64_t)gk;
+            if (cm[k * kCamSlots + 6]) {
+                unitvec_plus(n, d + 6, ncand);
+                for (int i = 0; i < 3; ++i) {
+                    step2 += (n[i] - ncand[i]) * (n[i] - ncand[i]);
+                    cand2 += ncand[i] * ncand[i];
+                }
+            } else {
+                for (int i = 0; i < 3; ++i) ncand[i] = n[i];
+            }
+            if (cm[k * kCamSlots + 9]) {
+                bv.pdist_c[gk] = bv.pdist[gk] + d[9];
+                step2 += d[9] * d[9];
+                cand2 += bv.pdist_c[gk] * bv.pdist_c[gk];
+            } else {
+                bv.pdist_c[gk] = bv.pdist[gk];
+            }
+        }
+        r.chol_fail = 0;
+        r.mcc = -gd - 0.5 * dHd;
+        r.step2 = step2;
+        r.cand2 = cand2;
+    }
+}
+
+// After backsub + candidate cost kernels: fold the landmark / observation partials into WinRed (single lane).
+KBA_HD void reduce_step(const BatchView& bv, int w, const double* blk_cost_c, const int* blk_fail_c,
+                        const double* gp_cost_c) {
+    const WinDesc& wd = bv.win[w];
+    WinRed& r = bv.red[w];
+    double mcc = 0.0, s2 = 0.0, c2 = 0.0;
+    int lfail = 0;
+    for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
+        mcc += bv.lblk_part[(int64_t)b * 8 + 2];
+        s2 += bv.lblk_part[(int64_t)b * 8 + 3];
+        c2 += bv.lblk_part[(int64_t)b * 8 + 4];
+        lfail |= (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0);
+    }
+    r.mcc += mcc;
+    r.step2 += s2;
+    r.cand2 += c2;
+    r.chol_fail |= lfail;
+    double cost = 0.0;
+    int fail = 0;
+    for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
+        cost += blk_cost_c[b];
+        fail |= blk_fail_c[b];
+    }
+    for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) cost += gp_cost_c[g];
+    const int nrows = reg_row_count(wd);
+    for (int i = 0; i < nrows; ++i) {
+        RegRow row;
+        int all_const;
+        reg_row_eval(wd, bv.cmask, bv.pose_c, bv.pdir_c, bv.pdist_c, i, false, row, all_const);
+        if (!all_const) cost += 0.5 * row.r * row.r;
+    }
+    r.cand_cost = cost;
+    r.cand_fail = fail;
+}
+
+// ======================================================================================= trimming
+// Per landmark: max over its observations of the un-robustified block norms (getMaximumResidual,
+// robust_solving.cpp:82-91); < 0 when the landmark has no block in that list.
+KBA_HD void trim_max_lane(const BatchView& bv, int gl, const double* plane_rep, const double* plane_dep) {
+    double mr = -1.0, md = -1.0;
+    if (bv.lm_state[gl]) {
+        const WinDesc& wd = bv.win[bv.lm_win[gl]];
+        for (int j = 0; j < wd.n_view; ++j) {
+            const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+            if (s < 0) continue;
+            mr = fmax(mr, plane_rep[s]);
+            md = fmax(md, plane_dep[s]);
+        }
+    }
+    bv.trim_rep[gl] = mr;
+    bv.trim_dep[gl] = md;
+}
+
+// Rank-based quantile selection (TrimmerQuantile::getOutliers, trimmer_quantile.hpp:40-63): an element is an
+// outlier iff its rank in (value, id) order is >= int(n_groups * quantile).  Returns 1 if landmark li (local
+// index) of window wd is an outlier of the list `vals`.
+KBA_HD int trim_is_outlier(const double* vals, int n_lm, int li, double quantile, int min_groups) {
+    const double v = vals[li];
+    if (v < 0.0) return 0;
+    int n_groups = 0, rank = 0;
+    for (int j = 0; j < n_lm; ++j) {
+        const double u = vals[j];
+        if (u < 0.0) continue;
+        ++n_groups;
+        if (u < v || (u == v && j < li)) ++rank;
+    }
+    if (n_groups < min_groups) return 0;
+    const int num = (int)((double)n_groups * quantile);
+    return rank >= num;
+}
+
+}  // namespace kba

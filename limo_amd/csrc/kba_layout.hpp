@@ -1,0 +1,151 @@
+// kba_layout.hpp — HBM data layout of a batch of optimisation windows and the per-window LM state.
+//
+// Design: many independent windows are packed into one set of struct-of-array buffers so that
+// every kernel is a flat, coalesced scan over "all observations of the batch" / "all landmarks of the batch".
+//   * observations are stored VIEW-major (view = (keyframe, camera) pair): a 256-lane workgroup only ever
+//     holds observations of one view, so pose and camera are wave-uniform (scalar loads) and the camera-side
+//     normal-equation blocks reduce inside the workgroup;
+//   * every landmark owns an ELL row  slot[j][lm] -> observation index of its measurement in view j (or -1),
+//     so the landmark-parallel kernels read the same planes coalesced (neighbouring landmarks sit next to
+//     each other inside every view segment);
+//   * residuals/Jacobians are materialised as planes  plane[c][obs]  (8-byte coalesced stores/loads).
+// The reduced camera system of a window has 10 slots per keyframe: [rot 3 | trans 3 | plane normal 3 | plane dist 1].
+#pragma once
+#include <stdint.h>
+
+#include "../../include/limo_hip.h"
+
+namespace kba {
+
+constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimization_window of the KITTI launch = 12)
+constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
+constexpr int kMaxNc = kMaxKf * kCamSlots;
+constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
+constexpr int kSchurLm = 32;      // landmarks per Schur LDS tile
+constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per pair (3+1+1) + global normal 3/kf
+
+// number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
+constexpr int kLinPartial = 28;
+
+struct WinDesc {
+    int32_t kf0, n_kf;
+    int32_t lm0, n_lm;
+    int32_t view0, n_view;
+    int32_t obs0, n_obs;
+    int32_t blk0, n_blk;      // linearize / cost workgroups (one view each)
+    int32_t lblk0, n_lblk;    // landmark workgroups
+    int32_t gp0, n_gp;
+    int32_t sblk0, n_sblk;    // Schur workgroups
+    int32_t nc, nc_pad;       // 10*n_kf, rounded up to 16
+    int32_t cam0;             // first global camera-slot index = kf0*10
+    int32_t reg0;             // first row in the regulariser row buffers
+    int32_t has_scale_reg, has_gp_reg;
+    int32_t n_depth, n_repr;  // residual blocks built
+    int32_t do_trim;          // n_lm > min_landmarks_for_trimming
+    int32_t pose_only;        // adjustPoseOnly problem (landmarks constant)
+    double scale_w, scale_s0; // PoseRegularization weight and target
+    double speed_w, speed_dt, speed_vel[3], speed_Rb[9], speed_tb[3];  // SpeedRegularizationVector2 (pose-only)
+    int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer
+    int64_t spart_off;        // offset of this window's Schur partial slabs
+};
+
+// Per-window Levenberg-Marquardt state (device resident; see kba_lm.hpp).
+struct WinState {
+    int32_t active, need_lin, first, accept;
+    int32_t iter, max_iter, term, invalid_run;
+    int32_t in_phase;          // selected for the current ceres-style solve
+    int32_t compute_scale;     // next linearisation defines the Jacobi scaling
+    int32_t n_success, n_unsuccess;
+    int32_t acc_solves, acc_iters, acc_success, last_iters;
+    int32_t n_trimmed, pad0;
+    double radius, decrease_factor;
+    double x_cost, x_norm, fixed_cost;
+    double solve_initial_cost, solve_final_cost;
+    double first_initial_cost;
+    double rho_pending, xnorm_pending;
+    double gmax;
+};
+
+// Reduction inputs the LM decisions read (one entry per window).
+struct WinRed {
+    double lin_cost;    // cost at the linearisation point (free blocks)
+    double gmax;        // |x - Plus(x, -g)|_inf
+    double xnorm2;      // |x|^2 over the reduced program
+    double mcc;         // model cost change of the proposed step
+    double step2;       // |x - x_candidate|^2
+    double cand2;       // |x_candidate|^2
+    double cand_cost;   // cost at the candidate (free blocks)
+    int32_t lin_fail, chol_fail, cand_fail, pad;
+};
+
+struct SolveConsts {  // subset of limo_ba_options the kernels need
+    double a_rep, a_dep;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
+    int32_t max_invalid, jacobi_scaling;
+    double depth_quantile, reprojection_quantile;
+    int32_t min_groups, pad;
+};
+
+// Raw pointers to every buffer of a batch (device pointers in the library, host pointers in the emulator).
+struct BatchView {
+    int32_t n_win, TK, TL, TO, TV, TG, n_blk, n_lblk, n_sblk, Vmax;
+    int64_t SO, SL, SG;  // plane strides (padded TO, TL, TG)
+    const WinDesc* win;
+    WinState* st;
+    WinRed* red;
+    // --- parameters: current, candidate, initial (for reset)
+    double *pose, *pdir, *pdist, *lm;
+    double *pose_c, *pdir_c, *pdist_c, *lm_c;
+    // --- constant per keyframe / landmark / view / observation
+    const int32_t* kf_win;      // [TK]
+    uint8_t* cmask;             // [TK*10] 1 = free tangent dim of the reduced program
+    uint8_t* cpresent;          // [TK*10] 1 = parameter block is in the problem (free or constant)
+    const int32_t* lm_win;      // [TL]
+    const double* lm_weight;    // [TL]
+    uint8_t* lm_state;          // [TL] 1 = in problem, 0 = removed by trimming / not constrained
+    const int32_t* lm_gp;       // [TL] ground-plane residual index or -1
+    const int32_t* lm_slot;     // [Vmax*SL] observation index per (view-in-window, landmark) or -1
+    const int32_t* view_kf;     // [TV] global keyframe index
+    const int32_t* view_win;    // [TV]
+    const double* view_cam;     // [TV*16] f,cx,cy,pad, Rc[9], tc[3]
+    const int32_t* blk_view;    // [n_blk]
+    const int32_t* blk_obs0;    // [n_blk]
+    const int32_t* blk_n;       // [n_blk]
+    const int32_t* obs_lm;      // [TO] global landmark
+    const float *obs_u, *obs_v, *obs_d;  // [TO]
+    const int32_t* lblk_win;    // [n_lblk]
+    const int32_t* lblk_lm0;
+    const int32_t* lblk_n;
+    const int32_t* sblk_win;    // [n_sblk]
+    const int32_t* sblk_lm0;
+    const int32_t* sblk_n;
+    // --- ground-plane residuals
+    const int32_t* gp_lm;       // [TG] global landmark
+    const int32_t* gp_kf;       // [TG] global keyframe
+    const double* gp_w;         // [TG] loss weight
+    double *gp_r, *gp_F, *gp_E; // planes [1|10|3][SG]
+    double* gp_cost;            // [TG] cost at the linearisation point
+    double* gp_cost_c;          // [TG] cost at the candidate
+    // --- materialised linearisation (planes over observations)
+    double *obs_r, *obs_Jp, *obs_Jl;  // [3|18|9][SO]
+    double* blk_part;           // [n_blk*kLinPartial]
+    int32_t* blk_fail;          // [n_blk]
+    double* blk_cost_c;         // [n_blk] candidate cost partials
+    int32_t* blk_fail_c;        // [n_blk]
+    // --- landmark side
+    double *lm_V, *lm_g;        // planes [6|3][SL]  (unscaled E^T E, E^T r incl. ground-plane rows)
+    double *lm_scale;           // [3][SL] Jacobi scaling
+    double *lm_Li, *lm_t;       // planes [6|3][SL]  inverse Cholesky factor of (V' + D^2), t = Li g'
+    double* lblk_part;          // [n_lblk*8]: gmax, xnorm2, mcc, step2, cand2, fail, -, -
+    // --- camera side
+    double *Hcc, *gc;           // per window nc*nc (hcc_off) ; [TK*10]
+    double *scale_c, *yc, *delta_c;  // [TK*10]
+    double *S_part;             // Schur partial slabs
+    double* reg_cost;           // [n_win*2]: free / fixed regulariser cost at the linearisation point
+    // --- trimming
+    double *trim_rep, *trim_dep;   // [TL] max un-robustified residual norm per landmark, <0 = no block
+    int32_t* n_active;          // [1] counter
+};
+
+}  // namespace kba

@@ -1,0 +1,357 @@
+// kba_pack.cpp — see kba_pack.hpp.
+#include "kba_pack.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "kba_items.hpp"
+
+namespace kba {
+
+namespace {
+inline int64_t pad64(int64_t n) {
+    return (n + 63) / 64 * 64;
+}
+}  // namespace
+
+SolveConsts make_consts(const limo_ba_options& o) {
+    SolveConsts c;
+    std::memset(&c, 0, sizeof(c));
+    c.a_rep = o.reprojection_thres;
+    c.a_dep = o.depth_thres;
+    c.function_tolerance = o.function_tolerance;
+    c.gradient_tolerance = o.gradient_tolerance;
+    c.parameter_tolerance = o.parameter_tolerance;
+    c.initial_radius = o.initial_trust_region_radius;
+    c.max_radius = o.max_trust_region_radius;
+    c.min_radius = o.min_trust_region_radius;
+    c.min_lm_diagonal = o.min_lm_diagonal;
+    c.max_lm_diagonal = o.max_lm_diagonal;
+    c.min_relative_decrease = o.min_relative_decrease;
+    c.max_invalid = o.max_num_consecutive_invalid_steps;
+    c.jacobi_scaling = o.jacobi_scaling;
+    c.depth_quantile = o.depth_quantile;
+    c.reprojection_quantile = o.reprojection_quantile;
+    c.min_groups = o.minimum_number_residual_groups;
+    return c;
+}
+
+int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options& opts, const PackOptions& po,
+                 PackedBatch& P, std::string& err) {
+    if (n <= 0 || !windows) {
+        err = "no windows";
+        return LIMO_ERR_INVALID;
+    }
+    P = PackedBatch();
+    P.n_win = n;
+    P.win.resize(n);
+    // ---- pass 1: sizes, views
+    struct View {
+        int kf, cam;
+    };
+    std::vector<std::vector<View>> views(n);
+    std::vector<std::vector<int>> obs_view(n);
+    for (int w = 0; w < n; ++w) {
+        const limo_ba_window& W = windows[w];
+        if (W.n_kf < 0 || W.n_lm < 0 || W.n_obs < 0 || W.n_cam < 0) {
+            err = "negative size";
+            return LIMO_ERR_INVALID;
+        }
+        if (!po.pose_only && !po.evaluate_only && W.n_kf < 3) {
+            err = "Not enough keyframes available in bundle_adjuster_keyframes. Should be 3";
+            return LIMO_ERR_NOT_ENOUGH_KF;
+        }
+        if (po.pose_only && W.n_kf != 1) {
+            err = "pose-only window must hold exactly one keyframe";
+            return LIMO_ERR_INVALID;
+        }
+        if (W.n_kf > kMaxKf) {
+            err = "window has more keyframes than kMaxKf (12)";
+            return LIMO_ERR_INVALID;
+        }
+        if ((W.n_kf && (!W.kf_pose || !W.kf_plane_dir || !W.kf_plane_dist || !W.kf_fixation)) ||
+            (W.n_lm && (!W.lm_pos || !W.lm_weight || !W.lm_is_ground)) || (W.n_cam && !W.cam) ||
+            (W.n_obs && (!W.obs_kf || !W.obs_lm || !W.obs_cam || !W.obs_u || !W.obs_v || !W.obs_d))) {
+            err = "null pointer in window";
+            return LIMO_ERR_INVALID;
+        }
+        std::vector<int> vid((size_t)W.n_kf * std::max(1, W.n_cam), -1);
+        for (int i = 0; i < W.n_obs; ++i) {
+            const int k = W.obs_kf[i], l = W.obs_lm[i], c = W.obs_cam[i];
+            if (k < 0 || k >= W.n_kf || l < 0 || l >= W.n_lm || c < 0 || c >= W.n_cam) {
+                err = "observation index out of range";
+                return LIMO_ERR_INVALID;
+            }
+            vid[(size_t)k * W.n_cam + c] = 0;
+        }
+        int nv = 0;
+        for (int k = 0; k < W.n_kf; ++k)
+            for (int c = 0; c < W.n_cam; ++c)
+                if (vid[(size_t)k * W.n_cam + c] == 0) {
+                    vid[(size_t)k * W.n_cam + c] = nv++;
+                    views[w].push_back({k, c});
+                }
+        obs_view[w].resize(W.n_obs);
+        for (int i = 0; i < W.n_obs; ++i) obs_view[w][i] = vid[(size_t)W.obs_kf[i] * W.n_cam + W.obs_cam[i]];
+        P.Vmax = std::max(P.Vmax, nv);
+        WinDesc& d = P.win[w];
+        std::memset(&d, 0, sizeof(d));
+        d.kf0 = P.TK;
+        d.n_kf = W.n_kf;
+        d.lm0 = P.TL;
+        d.n_lm = W.n_lm;
+        d.view0 = P.TV;
+        d.n_view = nv;
+        d.obs0 = P.TO;
+        d.n_obs = W.n_obs;
+        d.nc = W.n_kf * kCamSlots;
+        d.nc_pad = (d.nc + 15) / 16 * 16;
+        d.cam0 = d.kf0 * kCamSlots;
+        d.pose_only = po.pose_only ? 1 : 0;
+        P.TK += W.n_kf;
+        P.TL += W.n_lm;
+        P.TV += nv;
+        P.TO += W.n_obs;
+    }
+    P.SO = pad64(std::max(1, P.TO));
+    P.SL = pad64(std::max(1, P.TL));
+    P.pose.resize((size_t)P.TK * 7);
+    P.pdir.resize((size_t)P.TK * 3);
+    P.pdist.resize(P.TK);
+    P.kf_win.resize(P.TK);
+    P.cmask.assign((size_t)P.TK * kCamSlots, 0);
+    P.cpresent.assign((size_t)P.TK * kCamSlots, 0);
+    P.lm.resize((size_t)P.TL * 3);
+    P.lm_win.resize(P.TL);
+    P.lm_gp.assign(P.TL, -1);
+    P.lm_weight.resize(P.TL);
+    P.lm_state.assign(P.TL, 0);
+    P.lm_slot.assign((size_t)std::max(1, P.Vmax) * P.SL, -1);
+    P.view_kf.resize(P.TV);
+    P.view_win.resize(P.TV);
+    P.view_cam.assign((size_t)P.TV * 16, 0.0);
+    P.obs_lm.resize(P.TO);
+    P.obs_u.resize(P.TO);
+    P.obs_v.resize(P.TO);
+    P.obs_d.resize(P.TO);
+    P.obs_src.resize(P.TO);
+
+    // ---- pass 2: fill
+    for (int w = 0; w < n; ++w) {
+        const limo_ba_window& W = windows[w];
+        WinDesc& d = P.win[w];
+        std::memcpy(P.pose.data() + (size_t)d.kf0 * 7, W.kf_pose, sizeof(double) * 7 * W.n_kf);
+        std::memcpy(P.pdir.data() + (size_t)d.kf0 * 3, W.kf_plane_dir, sizeof(double) * 3 * W.n_kf);
+        std::memcpy(P.pdist.data() + d.kf0, W.kf_plane_dist, sizeof(double) * W.n_kf);
+        for (int k = 0; k < W.n_kf; ++k) P.kf_win[d.kf0 + k] = w;
+        if (W.n_lm) {
+            std::memcpy(P.lm.data() + (size_t)d.lm0 * 3, W.lm_pos, sizeof(double) * 3 * W.n_lm);
+            std::memcpy(P.lm_weight.data() + d.lm0, W.lm_weight, sizeof(double) * W.n_lm);
+        }
+        for (int l = 0; l < W.n_lm; ++l) P.lm_win[d.lm0 + l] = w;
+        for (int v = 0; v < d.n_view; ++v) {
+            const int gv = d.view0 + v;
+            P.view_kf[gv] = d.kf0 + views[w][v].kf;
+            P.view_win[gv] = w;
+            const double* cam = W.cam + 10 * views[w][v].cam;
+            double* vc = P.view_cam.data() + (size_t)gv * 16;
+            vc[0] = cam[0];
+            vc[1] = cam[1];
+            vc[2] = cam[2];
+            quat_R(cam + 3, vc + 4);
+            vc[13] = cam[7];
+            vc[14] = cam[8];
+            vc[15] = cam[9];
+        }
+        // observations sorted by (view, landmark)
+        std::vector<int> order(W.n_obs);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
+            return W.obs_lm[a] < W.obs_lm[b];
+        });
+        d.blk0 = (int)P.blk_view.size();
+        std::vector<int> lm_nobs(W.n_lm, 0);
+        int depth_blocks = 0;
+        int pos = 0;
+        for (int v = 0; v < d.n_view; ++v) {
+            const int start = pos;
+            while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
+            for (int b0 = start; b0 < pos; b0 += kBlock) {
+                P.blk_view.push_back(d.view0 + v);
+                P.blk_obs0.push_back(d.obs0 + b0);
+                P.blk_n.push_back(std::min(kBlock, pos - b0));
+            }
+            for (int i = start; i < pos; ++i) {
+                const int src = order[i];
+                const int o = d.obs0 + i;
+                const int l = W.obs_lm[src];
+                P.obs_lm[o] = d.lm0 + l;
+                P.obs_u[o] = W.obs_u[src];
+                P.obs_v[o] = W.obs_v[src];
+                P.obs_d[o] = W.obs_d[src];
+                P.obs_src[o] = src;
+                int32_t& slot = P.lm_slot[(size_t)v * P.SL + d.lm0 + l];
+                if (slot != -1) {
+                    err = "duplicate (keyframe, landmark, camera) observation";
+                    return LIMO_ERR_INVALID;
+                }
+                slot = o;
+                lm_nobs[l]++;
+                if (W.obs_d[src] > 0.0f) depth_blocks++;
+            }
+        }
+        d.n_blk = (int)P.blk_view.size() - d.blk0;
+        d.n_depth = depth_blocks;
+        d.n_repr = W.n_obs;
+        for (int l = 0; l < W.n_lm; ++l) P.lm_state[d.lm0 + l] = lm_nobs[l] > 0 ? (po.pose_only ? 2 : 1) : 0;
+
+        // ---- ground-plane residuals, addGroundPlaneResiduals(10.), bundle_adjuster_keyframes.cpp:517-562
+        d.gp0 = (int)P.gp_lm.size();
+        if (!po.pose_only && !po.evaluate_only) {
+            const double weight = 10.;
+            for (int l = 0; l < W.n_lm; ++l) {
+                if (!W.lm_is_ground[l]) continue;
+                double min_dist = std::numeric_limits<double>::max();
+                int kf_id = -1;
+                for (int k = 0; k < W.n_kf; ++k) {
+                    if (W.kf_plane_dist[k] < -10.) continue;
+                    double R[9], y[3];
+                    quat_R(W.kf_pose + 7 * k, R);
+                    mat3_vec(R, W.lm_pos + 3 * l, y);
+                    y[0] += W.kf_pose[7 * k + 4];
+                    y[1] += W.kf_pose[7 * k + 5];
+                    y[2] += W.kf_pose[7 * k + 6];
+                    const double dist = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+                    if (dist < min_dist) {
+                        min_dist = dist;
+                        kf_id = k;
+                    }
+                }
+                if (kf_id < 0) continue;
+                const double max_valid_dist = 25.;
+                if (min_dist < max_valid_dist) {
+                    P.lm_gp[d.lm0 + l] = (int)P.gp_lm.size();
+                    P.gp_lm.push_back(d.lm0 + l);
+                    P.gp_kf.push_back(d.kf0 + kf_id);
+                    P.gp_w.push_back(weight * (1. - min_dist / max_valid_dist));
+                    if (P.lm_state[d.lm0 + l] == 0) P.lm_state[d.lm0 + l] = 1;  // constrained by its gp block only
+                }
+            }
+        }
+        d.n_gp = (int)P.gp_lm.size() - d.gp0;
+
+        // ---- which parameter blocks exist / are free (B9)
+        uint8_t* present = P.cpresent.data() + (size_t)d.cam0;
+        uint8_t* freem = P.cmask.data() + (size_t)d.cam0;
+        auto set_block = [&](uint8_t* m, int k, int s0, int cnt) {
+            for (int i = 0; i < cnt; ++i) m[k * kCamSlots + s0 + i] = 1;
+        };
+        if (po.evaluate_only) {
+            for (int k = 0; k < W.n_kf; ++k) {
+                set_block(present, k, 0, 6);
+                set_block(freem, k, 0, 6);
+            }
+        } else if (po.pose_only) {
+            set_block(present, 0, 0, 6);
+            set_block(freem, 0, 0, 6);  // the new keyframe is not in active_keyframe_ids_, so never constant
+            if (po.prior && po.prior->speed_weight > 0.0) {
+                d.speed_w = po.prior->speed_weight;
+                d.speed_dt = po.prior->dt_cur;
+                for (int i = 0; i < 3; ++i) d.speed_vel[i] = po.prior->vel_prev[i];
+                quat_R(po.prior->pose_before, d.speed_Rb);
+                for (int i = 0; i < 3; ++i) d.speed_tb[i] = po.prior->pose_before[4 + i];
+            }
+        } else {
+            // scale regularisation, :704-716 / :890-904
+            const int n_depth = d.n_depth, n_gp = d.n_gp;
+            double scale_w = -1.0;
+            if (n_depth > 10 || n_gp > 10) {
+                if (n_gp < 30) scale_w = 1000. / (static_cast<double>(n_depth + static_cast<double>(n_gp)));
+            } else {
+                scale_w = 1000.;
+            }
+            if (scale_w > 0.0 && W.n_kf > 1) {
+                d.has_scale_reg = 1;
+                d.scale_w = scale_w;
+                double dd[3];
+                rel_translation(W.kf_pose + 7, W.kf_pose, dd, nullptr, nullptr, false);
+                d.scale_s0 = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+            }
+            d.has_gp_reg = (n_gp > 0 && W.n_kf > 1) ? 1 : 0;  // :717-719, :771
+            std::vector<int> kf_obs(W.n_kf, 0), kf_gp(W.n_kf, 0);
+            for (int i = 0; i < W.n_obs; ++i) kf_obs[W.obs_kf[i]]++;
+            for (int g = d.gp0; g < d.gp0 + d.n_gp; ++g) kf_gp[P.gp_kf[g] - d.kf0]++;
+            for (int k = 0; k < W.n_kf; ++k) {
+                const bool pose_in = kf_obs[k] > 0 || kf_gp[k] > 0 || d.has_gp_reg || (d.has_scale_reg && k < 2);
+                const bool plane_in = kf_gp[k] > 0 || d.has_gp_reg;
+                if (pose_in) set_block(present, k, 0, 6);
+                if (plane_in) set_block(present, k, 6, 4);
+                const bool fixed = W.kf_fixation[k] == LIMO_FIX_POSE;  // deactivatePoseParameters, :198-219
+                if (pose_in && !fixed) set_block(freem, k, 0, 6);
+                if (plane_in && !fixed) set_block(freem, k, 6, 3);
+                if (plane_in && !fixed && !(n_depth < 10)) set_block(freem, k, 9, 1);  // :722-728
+            }
+        }
+        d.do_trim = (W.n_lm > opts.min_landmarks_for_trimming) ? 1 : 0;  // :741 / :865
+
+        // ---- workgroup tables
+        d.lblk0 = (int)P.lblk_win.size();
+        for (int l0 = 0; l0 < W.n_lm; l0 += kBlock) {
+            P.lblk_win.push_back(w);
+            P.lblk_lm0.push_back(d.lm0 + l0);
+            P.lblk_n.push_back(std::min(kBlock, W.n_lm - l0));
+        }
+        d.n_lblk = (int)P.lblk_win.size() - d.lblk0;
+        d.sblk0 = (int)P.sblk_win.size();
+        if (!po.pose_only && !po.evaluate_only) {
+            const int per = 8 * kSchurLm;
+            for (int l0 = 0; l0 < W.n_lm; l0 += per) {
+                P.sblk_win.push_back(w);
+                P.sblk_lm0.push_back(d.lm0 + l0);
+                P.sblk_n.push_back(std::min(per, W.n_lm - l0));
+            }
+        }
+        d.n_sblk = (int)P.sblk_win.size() - d.sblk0;
+        d.hcc_off = P.hcc_total;
+        P.hcc_total += (int64_t)d.nc * d.nc;
+        d.spart_off = P.spart_total;
+        P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nc_pad * d.nc_pad + d.nc_pad);
+    }
+    P.TG = (int)P.gp_lm.size();
+    P.SG = pad64(std::max(1, P.TG));
+    P.n_blk = (int)P.blk_view.size();
+    P.n_lblk = (int)P.lblk_win.size();
+    P.n_sblk = (int)P.sblk_win.size();
+    return LIMO_OK;
+}
+
+void run_schedule(Executor& ex, const limo_ba_options& o) {
+    using Clock = std::chrono::steady_clock;
+    auto run_solve = [&](int max_iter, int select) {
+        ex.solve_init(max_iter, select);
+        const auto t0 = Clock::now();
+        for (;;) {
+            ex.linearize();
+            if (ex.active_count() == 0) break;
+            if (o.max_solver_time_sec > 0.0 &&
+                std::chrono::duration<double>(Clock::now() - t0).count() >= o.max_solver_time_sec) {
+                ex.expire(0);
+                break;
+            }
+            ex.step();
+        }
+    };
+    for (int r = 0; r < o.num_trim_rounds; ++r) {
+        run_solve(o.trim_solver_iterations, 1);
+        run_solve(3 * o.trim_solver_iterations, 2);
+        ex.trim();
+    }
+    run_solve(o.max_num_iterations, 0);
+}
+
+}  // namespace kba

@@ -1,0 +1,66 @@
+// kba_pack.hpp — host-side flattening of limo_ba_window[] into the batch layout of kba_layout.hpp, and the
+// phase orchestration (solveTrimmed schedule) that drives an Executor (HIP kernels, or the test emulator).
+//
+// Replaces the host logic of BundleAdjusterKeyframes::solve()/adjustPoseOnly() that decides WHICH residuals and
+// parameters exist (reference: keyframe_bundle_adjustment/src/bundle_adjuster_keyframes.cpp:498-562 ground-plane
+// wiring, :704-736 scale / ground-plane regularisation and constness rules, :740-758 trimming schedule) and the
+// outer loop of robust_optimization::solveTrimmed (robust_optimization/src/robust_solving.cpp:140-248).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kba_layout.hpp"
+
+namespace kba {
+
+struct PackedBatch {
+    int32_t n_win = 0, TK = 0, TL = 0, TO = 0, TV = 0, TG = 0, n_blk = 0, n_lblk = 0, n_sblk = 0, Vmax = 0;
+    int64_t SO = 0, SL = 0, SG = 0;
+    int64_t hcc_total = 0, spart_total = 0;
+    std::vector<WinDesc> win;
+    std::vector<double> pose, pdir, pdist, lm;  // initial parameters
+    std::vector<int32_t> kf_win;
+    std::vector<uint8_t> cmask, cpresent;
+    std::vector<int32_t> lm_win, lm_gp, lm_slot;
+    std::vector<double> lm_weight;
+    std::vector<uint8_t> lm_state;
+    std::vector<int32_t> view_kf, view_win;
+    std::vector<double> view_cam;
+    std::vector<int32_t> blk_view, blk_obs0, blk_n;
+    std::vector<int32_t> obs_lm;
+    std::vector<float> obs_u, obs_v, obs_d;
+    std::vector<int32_t> obs_src;  // packed observation -> index in the caller's window
+    std::vector<int32_t> lblk_win, lblk_lm0, lblk_n, sblk_win, sblk_lm0, sblk_n;
+    std::vector<int32_t> gp_lm, gp_kf;
+    std::vector<double> gp_w;
+};
+
+struct PackOptions {
+    bool pose_only = false;
+    bool evaluate_only = false;  // no problem-build logic (no ground plane / regularisers), every parameter free
+    const limo_speed_prior* prior = nullptr;
+};
+
+// Returns LIMO_OK or a negative limo_status; err receives a message.
+int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options& opts, const PackOptions& po,
+                 PackedBatch& out, std::string& err);
+
+SolveConsts make_consts(const limo_ba_options& o);
+
+// One ceres-style solve phase / trimming step, implemented by the HIP library and by the test emulator.
+struct Executor {
+    virtual ~Executor() {}
+    // select = 0: every window; 1: windows with do_trim; 2: of those, the ones whose last solve did not
+    // reduce the cost (robust_solving.cpp:172-181)
+    virtual void solve_init(int max_iter, int select) = 0;
+    virtual void linearize() = 0;     // linearise windows that need it + IterationZero / successful-step tail
+    virtual int active_count() = 0;   // number of windows still iterating (synchronises)
+    virtual void step() = 0;          // trust-region step, candidate evaluation, accept / reject
+    virtual void trim() = 0;          // quantile trimming of windows with do_trim
+    virtual void expire(int) {}       // wall-clock cap reached: stop every active window (NO_CONVERGENCE)
+};
+
+// solveTrimmed schedule over a whole batch (all windows advance in lock-step, finished windows idle).
+void run_schedule(Executor& ex, const limo_ba_options& o);
+
+}  // namespace kba

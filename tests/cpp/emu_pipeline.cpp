@@ -1,0 +1,322 @@
+// TEST INFRASTRUCTURE — serial CPU emulation of the batched HIP pipeline.
+//
+// Runs the SAME per-lane / per-workgroup statements as the gfx950 kernels (limo_amd/csrc/kba_items.hpp,
+// kba_lm.hpp) and the SAME host packing and phase orchestration (kba_pack.cpp), with plain loops in place of
+// lanes and workgroup reductions.  It exists so that the host logic and the kernel arithmetic can be unit-tested
+// against the oracle in the CPU-only test tier (`pytest -m "not gpu"`).  It is NOT part of the product: it is
+// built only into tests/cpp/_build/libkba_emu.so and nothing under limo_amd/ links or loads it.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../limo_amd/csrc/kba_buffers.hpp"
+#include "../../limo_amd/csrc/kba_items.hpp"
+
+using namespace kba;
+
+namespace {
+
+struct EmuBatch : Executor {
+    PackedBatch P;
+    BatchView bv;
+    SolveConsts c;
+    std::vector<void*> allocs;
+    std::vector<double> plane_rep, plane_dep;
+
+    ~EmuBatch() override {
+        for (void* p : allocs) std::free(p);
+    }
+    void alloc() {
+        std::memset(&bv, 0, sizeof(bv));
+        for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) {
+            void* p = std::calloc(1, bytes ? bytes : 1);
+            if (init) std::memcpy(p, init, bytes);
+            *slot = p;
+            allocs.push_back(p);
+        });
+        for (int w = 0; w < bv.n_win; ++w) {
+            bv.st[w].term = -1;
+        }
+        plane_rep.assign(bv.SO, -1.0);
+        plane_dep.assign(bv.SO, -1.0);
+    }
+
+    void solve_init(int max_iter, int select) override {
+        for (int w = 0; w < bv.n_win; ++w) {
+            WinState& s = bv.st[w];
+            bool sel = true;
+            if (select >= 1) sel = bv.win[w].do_trim != 0;
+            if (select == 2) sel = sel && (s.solve_initial_cost - s.solve_final_cost <= 0.0);
+            lm_solve_init(s, sel, max_iter, c);
+        }
+    }
+
+    void linearize() override {
+        // K1: observations
+        for (int b = 0; b < bv.n_blk; ++b) {
+            const int w = bv.view_win[bv.blk_view[b]];
+            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
+            double part[kLinPartial];
+            for (int i = 0; i < kLinPartial; ++i) part[i] = 0.0;
+            int fail = 0;
+            for (int t = 0; t < kBlock; ++t) {
+                LinLane l;
+                linearize_lane(bv, c, b, t, l);
+                part[0] += l.cost;
+                for (int i = 0; i < 21; ++i) part[1 + i] += l.U[i];
+                for (int i = 0; i < 6; ++i) part[22 + i] += l.g[i];
+                fail |= l.fail;
+            }
+            for (int i = 0; i < kLinPartial; ++i) bv.blk_part[(int64_t)b * kLinPartial + i] = part[i];
+            bv.blk_fail[b] = fail;
+        }
+        // ground-plane rows
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
+            const WinDesc& wd = bv.win[w];
+            for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(bv, g, false, bv.gp_cost);
+        }
+        // landmarks
+        for (int b = 0; b < bv.n_lblk; ++b) {
+            const int w = bv.lblk_win[b];
+            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
+            double gmax = 0.0, xn2 = 0.0;
+            for (int t = 0; t < bv.lblk_n[b]; ++t) {
+                double part[8];
+                lm_accum_lane(bv, c, bv.lblk_lm0[b] + t, part);
+                gmax = std::fmax(gmax, part[0]);
+                xn2 += part[1];
+            }
+            bv.lblk_part[(int64_t)b * 8 + 0] = gmax;
+            bv.lblk_part[(int64_t)b * 8 + 1] = xn2;
+        }
+        // camera assemble + LM decision
+        std::vector<double> H((size_t)kMaxNc * kMaxNc);
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
+            cam_assemble(bv, c, w, 0, 1, H.data());
+            lm_decide_lin(bv.st[w], bv.red[w], bv.reg_cost[2 * w + 1], c);
+        }
+    }
+
+    int active_count() override {
+        int n = 0;
+        for (int w = 0; w < bv.n_win; ++w) n += bv.st[w].active;
+        return n;
+    }
+
+    void expire(int) override {
+        for (int w = 0; w < bv.n_win; ++w)
+            if (bv.st[w].active) lm_terminate(bv.st[w], LIMO_NO_CONVERGENCE);
+    }
+
+    void step() override {
+        // landmark damping
+        for (int b = 0; b < bv.n_lblk; ++b) {
+            const int w = bv.lblk_win[b];
+            if (!bv.st[w].active) continue;
+            int fail = 0;
+            for (int t = 0; t < bv.lblk_n[b]; ++t) fail |= lm_damp_lane(bv, c, bv.lblk_lm0[b] + t);
+            bv.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
+        }
+        // Schur slabs
+        std::vector<double> Z, tt;
+        for (int sb = 0; sb < bv.n_sblk; ++sb) {
+            const int w = bv.sblk_win[sb];
+            if (!bv.st[w].active) continue;
+            const WinDesc& wd = bv.win[w];
+            const int ncp = wd.nc_pad;
+            const int slab = ncp * ncp + ncp;
+            double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
+            for (int i = 0; i < slab; ++i) out[i] = 0.0;
+            for (int l0 = 0; l0 < bv.sblk_n[sb]; l0 += kSchurLm) {
+                const int nl = std::min(kSchurLm, bv.sblk_n[sb] - l0);
+                Z.assign((size_t)3 * kSchurLm * ncp, 0.0);
+                tt.assign((size_t)3 * kSchurLm, 0.0);
+                for (int li = 0; li < nl; ++li) {
+                    const int gl = bv.sblk_lm0[sb] + l0 + li;
+                    if (bv.lm_state[gl] != 1) continue;
+                    for (int j = 0; j < wd.n_view; ++j) schur_fill_view(bv, wd, gl, li, j, Z.data(), ncp);
+                    schur_fill_gp(bv, wd, gl, li, Z.data(), ncp);
+                    for (int cc = 0; cc < 3; ++cc) tt[3 * li + cc] = bv.lm_t[cc * bv.SL + gl];
+                }
+                for (int k = 0; k < 3 * nl; ++k) {
+                    const double* zr = Z.data() + (size_t)k * ncp;
+                    for (int a = 0; a < wd.nc; ++a) {
+                        if (zr[a] == 0.0) continue;
+                        for (int bcol = 0; bcol < wd.nc; ++bcol) out[a * ncp + bcol] += zr[a] * zr[bcol];
+                        out[ncp * ncp + a] += zr[a] * tt[k];
+                    }
+                }
+            }
+        }
+        // camera solve
+        std::vector<double> S((size_t)kMaxNc * kMaxNc), v(3 * kMaxNc);
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].active) continue;
+            int flag = 0;
+            cam_solve(bv, c, w, 0, 1, S.data(), v.data(), &flag);
+        }
+        // back-substitution
+        for (int b = 0; b < bv.n_lblk; ++b) {
+            const int w = bv.lblk_win[b];
+            if (!bv.st[w].active) continue;
+            double mcc = 0.0, s2 = 0.0, c2 = 0.0;
+            for (int t = 0; t < bv.lblk_n[b]; ++t) {
+                double part[8];
+                backsub_lane(bv, bv.lblk_lm0[b] + t, part);
+                mcc += part[2];
+                s2 += part[3];
+                c2 += part[4];
+            }
+            bv.lblk_part[(int64_t)b * 8 + 2] = mcc;
+            bv.lblk_part[(int64_t)b * 8 + 3] = s2;
+            bv.lblk_part[(int64_t)b * 8 + 4] = c2;
+        }
+        // candidate cost
+        for (int b = 0; b < bv.n_blk; ++b) {
+            const int w = bv.view_win[bv.blk_view[b]];
+            if (!bv.st[w].active) continue;
+            double cost = 0.0;
+            int fail = 0;
+            for (int t = 0; t < kBlock; ++t) {
+                double cst;
+                int f;
+                cost_lane(bv, c, b, t, cst, f);
+                cost += cst;
+                fail |= f;
+            }
+            bv.blk_cost_c[b] = cost;
+            bv.blk_fail_c[b] = fail;
+        }
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].active) continue;
+            const WinDesc& wd = bv.win[w];
+            for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(bv, g, true, bv.gp_cost_c);
+            reduce_step(bv, w, bv.blk_cost_c, bv.blk_fail_c, bv.gp_cost_c);
+            lm_decide_step(bv.st[w], bv.red[w], c);
+        }
+        // accept: candidate -> current
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].accept) continue;
+            const WinDesc& wd = bv.win[w];
+            std::memcpy(bv.pose + 7 * (size_t)wd.kf0, bv.pose_c + 7 * (size_t)wd.kf0, sizeof(double) * 7 * wd.n_kf);
+            std::memcpy(bv.pdir + 3 * (size_t)wd.kf0, bv.pdir_c + 3 * (size_t)wd.kf0, sizeof(double) * 3 * wd.n_kf);
+            std::memcpy(bv.pdist + wd.kf0, bv.pdist_c + wd.kf0, sizeof(double) * wd.n_kf);
+            std::memcpy(bv.lm + 3 * (size_t)wd.lm0, bv.lm_c + 3 * (size_t)wd.lm0, sizeof(double) * 3 * wd.n_lm);
+        }
+    }
+
+    void trim() override {
+        for (int b = 0; b < bv.n_blk; ++b) {
+            const int w = bv.view_win[bv.blk_view[b]];
+            if (!bv.win[w].do_trim) continue;
+            for (int t = 0; t < kBlock; ++t) trim_residual_lane(bv, b, t, plane_rep.data(), plane_dep.data());
+        }
+        for (int w = 0; w < bv.n_win; ++w) {
+            const WinDesc& wd = bv.win[w];
+            if (!wd.do_trim) continue;
+            for (int l = 0; l < wd.n_lm; ++l) trim_max_lane(bv, wd.lm0 + l, plane_rep.data(), plane_dep.data());
+            std::vector<uint8_t> out(wd.n_lm, 0);
+            for (int l = 0; l < wd.n_lm; ++l) {
+                out[l] = trim_is_outlier(bv.trim_dep + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
+                         trim_is_outlier(bv.trim_rep + wd.lm0, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
+            }
+            for (int l = 0; l < wd.n_lm; ++l)
+                if (out[l] && bv.lm_state[wd.lm0 + l]) {
+                    bv.lm_state[wd.lm0 + l] = 0;
+                    bv.st[w].n_trimmed++;
+                }
+        }
+    }
+};
+
+void fill_report(const EmuBatch& B, int w, limo_ba_report* r) {
+    const WinState& s = B.bv.st[w];
+    const WinDesc& d = B.bv.win[w];
+    std::memset(r, 0, sizeof(*r));
+    r->termination = s.term;
+    r->num_solves = s.acc_solves;
+    r->iterations_total = s.acc_iters;
+    r->iterations_final = s.last_iters;
+    r->successful_steps = s.acc_success;
+    r->n_depth_blocks = d.n_depth;
+    r->n_repr_blocks = d.n_repr;
+    r->n_gp_blocks = d.n_gp;
+    r->n_trimmed_landmarks = s.n_trimmed;
+    r->initial_cost = s.first_initial_cost;
+    r->final_cost = s.solve_final_cost;
+}
+
+void write_back(const EmuBatch& B, limo_ba_window* windows) {
+    for (int w = 0; w < B.bv.n_win; ++w) {
+        const WinDesc& d = B.bv.win[w];
+        std::memcpy(windows[w].kf_pose, B.bv.pose + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
+        std::memcpy(windows[w].kf_plane_dir, B.bv.pdir + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
+        std::memcpy(windows[w].kf_plane_dist, B.bv.pdist + d.kf0, sizeof(double) * d.n_kf);
+        if (d.n_lm) std::memcpy(windows[w].lm_pos, B.bv.lm + 3 * (size_t)d.lm0, sizeof(double) * 3 * d.n_lm);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_ba_solve_batch(int32_t n, limo_ba_window* windows, const limo_ba_options* o, limo_ba_report* reports,
+                       int pose_only, const limo_speed_prior* prior) {
+    EmuBatch B;
+    std::string err;
+    PackOptions po;
+    po.pose_only = pose_only != 0;
+    po.prior = prior;
+    int rc = pack_windows(n, windows, *o, po, B.P, err);
+    if (rc != LIMO_OK) return rc;
+    B.c = make_consts(*o);
+    B.alloc();
+    run_schedule(B, *o);
+    write_back(B, windows);
+    if (reports)
+        for (int w = 0; w < n; ++w) fill_report(B, w, reports + w);
+    return LIMO_OK;
+}
+
+int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int apply_loss, double* cost,
+                    double* residuals, double* jac_pose, double* jac_lm, uint8_t* valid) {
+    (void)apply_loss;
+    EmuBatch B;
+    std::string err;
+    PackOptions po;
+    po.evaluate_only = true;
+    int rc = pack_windows(1, window, *o, po, B.P, err);
+    if (rc != LIMO_OK) return rc;
+    B.c = make_consts(*o);
+    B.alloc();
+    double total = 0.0;
+    for (int b = 0; b < B.bv.n_blk; ++b) {
+        const int view = B.bv.blk_view[b];
+        const double* cam = B.bv.view_cam + 16 * (int64_t)view;
+        for (int t = 0; t < B.bv.blk_n[b]; ++t) {
+            const int64_t o_ = B.bv.blk_obs0[b] + t;
+            const int gl = B.bv.obs_lm[o_];
+            ObsOut oo;
+            bool ok = obs_residual_jacobian(B.bv.pose + 7 * (int64_t)B.bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1],
+                                            cam[2], B.bv.lm + 3 * (int64_t)gl, B.bv.obs_u[o_], B.bv.obs_v[o_],
+                                            B.bv.obs_d[o_], B.bv.lm_weight[gl], B.c.a_rep, B.c.a_dep, apply_loss != 0, &oo);
+            const int src = B.P.obs_src[o_];
+            if (!ok) {
+                std::memset(&oo, 0, sizeof(oo));
+            }
+            total += oo.cost;
+            if (valid) valid[src] = ok ? 1 : 0;
+            if (residuals) std::memcpy(residuals + 3 * (size_t)src, oo.r, sizeof(oo.r));
+            if (jac_pose) std::memcpy(jac_pose + 18 * (size_t)src, oo.Jp, sizeof(oo.Jp));
+            if (jac_lm) std::memcpy(jac_lm + 9 * (size_t)src, oo.Jl, sizeof(oo.Jl));
+        }
+    }
+    if (cost) *cost = total;
+    return LIMO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""ctypes binding of the test-only CPU emulation of the HIP pipeline (tests/cpp/emu_pipeline.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from limo_amd import _ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = [os.path.join(_HERE, "cpp", "emu_pipeline.cpp"), os.path.join(_HERE, "..", "limo_amd", "csrc", "kba_pack.cpp")]
+LIB_PATH = os.path.join(_HERE, "cpp", "_build", "libkba_emu.so")
+_lib = None
+
+
+def build(force=False):
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    deps = _SRC + [os.path.join(_HERE, "..", "limo_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "limo_amd", "csrc")) if f.endswith(".hpp")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + _SRC)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(LIB_PATH)
+        dp, u8p = _ffi.c_double_p, _ffi.c_uint8_p
+        lib.emu_ba_solve_batch.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.POINTER(_ffi.SpeedPrior)]
+        lib.emu_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+        _lib = lib
+    return _lib
+
+
+def solve_batch(windows, opts, pose_only=False, prior=None):
+    from limo_amd.window import struct_array
+
+    lib = load()
+    arr = struct_array(windows)
+    reps = (_ffi.BaReport * len(windows))()
+    rc = lib.emu_ba_solve_batch(len(windows), arr, C.byref(opts), reps, int(pose_only), None if prior is None else C.byref(prior))
+    if rc != 0:
+        raise RuntimeError("emu_ba_solve_batch rc=%d" % rc)
+    return [r.as_dict() for r in reps]
+
+
+def evaluate(window, opts, apply_loss=True):
+    lib = load()
+    s = window.as_struct()
+    M = window.n_obs
+    cost = np.zeros(1)
+    res = np.zeros((M, 3))
+    jp = np.zeros((M, 3, 6))
+    jl = np.zeros((M, 3, 3))
+    valid = np.zeros(M, np.uint8)
+    dp = lambda a: a.ctypes.data_as(_ffi.c_double_p)
+    rc = lib.emu_ba_evaluate(C.byref(s), C.byref(opts), int(apply_loss), dp(cost), dp(res), dp(jp), dp(jl), valid.ctypes.data_as(_ffi.c_uint8_p))
+    if rc != 0:
+        raise RuntimeError("emu_ba_evaluate rc=%d" % rc)
+    return float(cost[0]), res, jp, jl, valid
