@@ -1,0 +1,124 @@
+"""Thin Python driver over the C-ABI (ctypes): context, batched solve, evaluate, pose-only.
+
+Used by tests and bench.py.  It never computes anything itself: every call goes through
+`limo_amd/lib/liblimo_hip.so` (include/limo_hip.h) and fails loudly if that library or a GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .window import struct_array
+
+
+class LimoError(RuntimeError):
+    pass
+
+
+class NotEnoughKeyframes(LimoError):
+    """BundleAdjusterKeyframes::NotEnoughKeyframesException (bundle_adjuster_keyframes.hpp:59-68)."""
+
+
+def _check(rc, ctx=None, what=""):
+    if rc == _ffi.LIMO_OK:
+        return
+    msg = ""
+    if ctx is not None:
+        msg = _ffi.load().limo_last_error(ctx).decode(errors="replace")
+    if rc == _ffi.LIMO_ERR_NOT_ENOUGH_KF:
+        raise NotEnoughKeyframes(msg or what)
+    raise LimoError("%s failed: rc=%d %s" % (what, rc, msg))
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.lib = _ffi.load()
+        self.ptr = C.c_void_p()
+        rc = self.lib.limo_ctx_create(device, C.byref(self.ptr))
+        if rc != 0:
+            raise LimoError("limo_ctx_create(device=%d) failed rc=%d (no gfx950 device? the product path has no CPU fallback)" % (device, rc))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        _check(self.lib.limo_ctx_set_stream(self.ptr, C.c_void_p(stream)), self.ptr, "limo_ctx_set_stream")
+
+    def close(self):
+        if self.ptr:
+            self.lib.limo_ctx_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- single window
+    def solve(self, window, opts):
+        s = window.as_struct()
+        rep = _ffi.BaReport()
+        _check(self.lib.limo_ba_solve(self.ptr, C.byref(s), C.byref(opts), C.byref(rep)), self.ptr, "limo_ba_solve")
+        return rep.as_dict()
+
+    def adjust_pose_only(self, window, prior, opts):
+        s = window.as_struct()
+        rep = _ffi.BaReport()
+        rc = self.lib.limo_ba_adjust_pose_only(self.ptr, C.byref(s), None if prior is None else C.byref(prior), C.byref(opts), C.byref(rep))
+        _check(rc, self.ptr, "limo_ba_adjust_pose_only")
+        return rep.as_dict()
+
+    def evaluate(self, window, opts, apply_loss=True):
+        s = window.as_struct()
+        M = window.n_obs
+        cost = np.zeros(1)
+        res = np.zeros((M, 3))
+        jp = np.zeros((M, 3, 6))
+        jl = np.zeros((M, 3, 3))
+        valid = np.zeros(M, np.uint8)
+        dp = lambda a: a.ctypes.data_as(_ffi.c_double_p)
+        rc = self.lib.limo_ba_evaluate(self.ptr, C.byref(s), C.byref(opts), int(apply_loss), dp(cost), dp(res), dp(jp), dp(jl), valid.ctypes.data_as(_ffi.c_uint8_p))
+        _check(rc, self.ptr, "limo_ba_evaluate")
+        return float(cost[0]), res, jp, jl, valid
+
+
+class Batch:
+    """Many independent windows resident in HBM (limo_ba_batch_*)."""
+
+    def __init__(self, ctx, windows):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.windows = list(windows)
+        self._arr = struct_array(self.windows)
+        self.ptr = C.c_void_p()
+        _check(self.lib.limo_ba_batch_create(ctx.ptr, len(self.windows), self._arr, C.byref(self.ptr)), ctx.ptr, "limo_ba_batch_create")
+
+    def solve(self, opts):
+        _check(self.lib.limo_ba_batch_solve(self.ptr, C.byref(opts)), self.ctx.ptr, "limo_ba_batch_solve")
+
+    def reset(self):
+        _check(self.lib.limo_ba_batch_reset(self.ptr), self.ctx.ptr, "limo_ba_batch_reset")
+
+    def download(self):
+        """Writes optimised parameters into self.windows (in place) and returns the reports."""
+        reps = (_ffi.BaReport * len(self.windows))()
+        _check(self.lib.limo_ba_batch_download(self.ptr, self._arr, reps), self.ctx.ptr, "limo_ba_batch_download")
+        return [r.as_dict() for r in reps]
+
+    def kernel_stats(self, reset=False):
+        ms = C.c_double()
+        n = C.c_int64()
+        tot = C.c_double()
+        _check(self.lib.limo_ba_batch_kernel_stats(self.ptr, int(reset), C.byref(ms), C.byref(n), C.byref(tot)), self.ctx.ptr, "limo_ba_batch_kernel_stats")
+        return {"linearize_ms": ms.value, "linearize_launches": n.value, "total_ms": tot.value}
+
+    def close(self):
+        if self.ptr:
+            self.lib.limo_ba_batch_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

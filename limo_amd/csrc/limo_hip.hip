@@ -1,0 +1,545 @@
+// limo_hip.hip — the C-ABI of include/limo_hip.h on top of the gfx950 kernels (kba_kernels.hip).
+// Host side: packing (kba_pack.cpp), device allocation, launch sequencing, result download.
+// There is NO CPU fallback here: without a HIP device limo_ctx_create fails with LIMO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kba_kernels.hip"
+
+#include "kba_buffers.hpp"
+
+using namespace kba;
+
+struct limo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own = nullptr;
+    std::string err;
+};
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                     \
+            return LIMO_ERR_RUNTIME;                                                             \
+        }                                                                                        \
+    } while (0)
+
+namespace {
+
+inline int cdiv(int64_t a, int64_t b) {
+    return (int)((a + b - 1) / b);
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct limo_ba_batch : Executor {
+    limo_ctx* ctx = nullptr;
+    PackedBatch P;
+    BatchView bv;
+    SolveConsts c;
+    limo_ba_options opts;
+    std::vector<void*> allocs;
+    double *d_plane_rep = nullptr, *d_plane_dep = nullptr;
+    double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
+    uint8_t* d_lm_state0 = nullptr;
+    int32_t* h_active = nullptr;  // pinned
+    int max_nc = 0, max_ld_bytes = 0;
+    int rc = LIMO_OK;
+    // kernel timing (linearize) via HIP events on the batch's stream
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    double lin_ms_acc = 0.0;
+    int64_t lin_launches = 0;
+    hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
+    double total_ms_acc = 0.0;
+    double last_solve_sec = 0.0;
+
+    ~limo_ba_batch() override {
+        for (void* p : allocs) (void)hipFree(p);
+        if (h_active) (void)hipHostFree(h_active);
+        for (auto& e : ev_pool) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        if (ev_total_a) (void)hipEventDestroy(ev_total_a);
+        if (ev_total_b) (void)hipEventDestroy(ev_total_b);
+    }
+
+    int dmalloc(void** p, size_t bytes) {
+        HIP_TRY(ctx, hipMalloc(p, bytes ? bytes : 8));
+        allocs.push_back(*p);
+        return LIMO_OK;
+    }
+
+    int upload() {
+        std::memset(&bv, 0, sizeof(bv));
+        int status = LIMO_OK;
+        for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) {
+            if (status != LIMO_OK) return;
+            void* p = nullptr;
+            if (dmalloc(&p, bytes) != LIMO_OK) {
+                status = LIMO_ERR_RUNTIME;
+                return;
+            }
+            hipError_t e = init ? hipMemcpyAsync(p, init, bytes, hipMemcpyHostToDevice, ctx->stream)
+                                : hipMemsetAsync(p, 0, bytes ? bytes : 8, ctx->stream);
+            if (e != hipSuccess) {
+                ctx->err = std::string("upload: ") + hipGetErrorString(e);
+                status = LIMO_ERR_RUNTIME;
+            }
+            *slot = p;
+        });
+        if (status != LIMO_OK) return status;
+        if (dmalloc((void**)&d_plane_rep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_plane_dep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_pose0, sizeof(double) * 7 * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_pdir0, sizeof(double) * 3 * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_pdist0, sizeof(double) * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_lm0, sizeof(double) * 3 * std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_lm_state0, std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
+        HIP_TRY(ctx, hipMemcpyAsync(d_pose0, P.pose.data(), sizeof(double) * P.pose.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pdir0, P.pdir.data(), sizeof(double) * P.pdir.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pdist0, P.pdist.data(), sizeof(double) * P.pdist.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_lm0, P.lm.data(), sizeof(double) * P.lm.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_lm_state0, P.lm_state.data(), P.lm_state.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipHostMalloc((void**)&h_active, 64));
+        for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
+        int max_ncp = (max_nc + 15) / 16 * 16;
+        max_ld_bytes = (3 * kSchurLm * schur_ld(std::max(16, max_ncp)) + 3 * kSchurLm) * (int)sizeof(double);
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
+        const int cam_bytes = (max_nc * max_nc + 3 * max_nc) * (int)sizeof(double);
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, cam_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, cam_bytes));
+        HIP_TRY(ctx, hipEventCreate(&ev_total_a));
+        HIP_TRY(ctx, hipEventCreate(&ev_total_b));
+        return reset_state();
+    }
+
+    int reset_state() {
+        std::vector<WinState> st(P.n_win);
+        std::memset(st.data(), 0, sizeof(WinState) * st.size());
+        for (auto& s : st) s.term = -1;
+        HIP_TRY(ctx, hipMemcpyAsync(bv.st, st.data(), sizeof(WinState) * st.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.pose, d_pose0, sizeof(double) * 7 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.pdir, d_pdir0, sizeof(double) * 3 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.pdist, d_pdist0, sizeof(double) * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.lm, d_lm0, sizeof(double) * 3 * P.TL, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.lm_state, d_lm_state0, P.TL, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // st vector goes out of scope
+        return LIMO_OK;
+    }
+
+    void note(hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == LIMO_OK) {
+            rc = LIMO_ERR_RUNTIME;
+            ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        }
+    }
+#define LAUNCH_CHECK(what) note(hipGetLastError(), what)
+
+    // ---- Executor
+    void solve_init(int max_iter, int select) override {
+        hipLaunchKernelGGL(k_solve_init, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv, c, max_iter, select);
+        LAUNCH_CHECK("k_solve_init");
+    }
+
+    void linearize() override {
+        hipStream_t s = ctx->stream;
+        if (P.n_blk) {
+            EventPair* ep = nullptr;
+            if (ev_used < 8192) {
+                if (ev_used == ev_pool.size()) {
+                    EventPair e;
+                    note(hipEventCreate(&e.a), "hipEventCreate");
+                    note(hipEventCreate(&e.b), "hipEventCreate");
+                    ev_pool.push_back(e);
+                }
+                ep = &ev_pool[ev_used++];
+                note(hipEventRecord(ep->a, s), "hipEventRecord");
+            }
+            hipLaunchKernelGGL(k_linearize, dim3(P.n_blk), dim3(kBlock), 0, s, bv, c);
+            LAUNCH_CHECK("k_linearize");
+            if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+        }
+        if (P.TG) {
+            hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 0);
+            LAUNCH_CHECK("k_gp");
+        }
+        if (P.n_lblk) {
+            hipLaunchKernelGGL(k_lm_accum, dim3(P.n_lblk), dim3(kBlock), 0, s, bv, c);
+            LAUNCH_CHECK("k_lm_accum");
+        }
+        note(hipMemsetAsync(bv.n_active, 0, sizeof(int32_t), s), "memset n_active");
+        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), sizeof(double) * max_nc * max_nc, s, bv, c);
+        LAUNCH_CHECK("k_cam_assemble");
+    }
+
+    int active_count() override {
+        if (rc != LIMO_OK) return 0;
+        note(hipMemcpyAsync(h_active, bv.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), "memcpy n_active");
+        note(hipStreamSynchronize(ctx->stream), "sync");
+        return rc == LIMO_OK ? *h_active : 0;
+    }
+
+    void expire(int) override {
+        hipLaunchKernelGGL(k_expire, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv);
+        LAUNCH_CHECK("k_expire");
+    }
+
+    void step() override {
+        hipStream_t s = ctx->stream;
+        if (P.n_lblk) {
+            hipLaunchKernelGGL(k_lm_damp, dim3(P.n_lblk), dim3(kBlock), 0, s, bv, c);
+            LAUNCH_CHECK("k_lm_damp");
+        }
+        if (P.n_sblk) {
+            hipLaunchKernelGGL(k_schur, dim3(P.n_sblk), dim3(kBlock), max_ld_bytes, s, bv);
+            LAUNCH_CHECK("k_schur");
+        }
+        hipLaunchKernelGGL(k_cam_solve, dim3(P.n_win), dim3(kBlock), sizeof(double) * (max_nc * max_nc + 3 * max_nc), s, bv, c);
+        LAUNCH_CHECK("k_cam_solve");
+        if (P.n_lblk) {
+            hipLaunchKernelGGL(k_backsub, dim3(P.n_lblk), dim3(kBlock), 0, s, bv);
+            LAUNCH_CHECK("k_backsub");
+        }
+        if (P.n_blk) {
+            hipLaunchKernelGGL(k_cost, dim3(P.n_blk), dim3(kBlock), 0, s, bv, c);
+            LAUNCH_CHECK("k_cost");
+        }
+        if (P.TG) {
+            hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 1);
+            LAUNCH_CHECK("k_gp(cand)");
+        }
+        hipLaunchKernelGGL(k_step_decide, dim3(cdiv(P.n_win, 64)), dim3(64), 0, s, bv, c);
+        LAUNCH_CHECK("k_step_decide");
+        hipLaunchKernelGGL(k_accept, dim3(cdiv((int64_t)P.TK + P.TL, 256)), dim3(256), 0, s, bv);
+        LAUNCH_CHECK("k_accept");
+    }
+
+    void trim() override {
+        hipStream_t s = ctx->stream;
+        bool any = false;
+        for (const WinDesc& d : P.win) any = any || d.do_trim;
+        if (!any) return;
+        if (P.n_blk) {
+            hipLaunchKernelGGL(k_trim_residual, dim3(P.n_blk), dim3(kBlock), 0, s, bv, d_plane_rep, d_plane_dep);
+            LAUNCH_CHECK("k_trim_residual");
+        }
+        if (P.TL) {
+            hipLaunchKernelGGL(k_trim_max, dim3(cdiv(P.TL, 256)), dim3(256), 0, s, bv, (const double*)d_plane_rep,
+                               (const double*)d_plane_dep);
+            LAUNCH_CHECK("k_trim_max");
+        }
+        hipLaunchKernelGGL(k_trim_select, dim3(P.n_win), dim3(kBlock), 0, s, bv, c);
+        LAUNCH_CHECK("k_trim_select");
+    }
+
+    int collect_linearize_events() {
+        if (ev_used) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t i = 0; i < ev_used; ++i) {
+                float ms = 0.f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_pool[i].a, ev_pool[i].b));
+                lin_ms_acc += ms;
+                lin_launches += 1;
+            }
+            ev_used = 0;
+        }
+        return LIMO_OK;
+    }
+};
+
+// =============================================================================================== C-ABI
+extern "C" {
+
+int limo_abi_version(void) {
+    return LIMO_ABI_VERSION;
+}
+
+int limo_ctx_create(int device, limo_ctx** out) {
+    if (!out) return LIMO_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return LIMO_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    limo_ctx* c = new limo_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return LIMO_ERR_RUNTIME;
+    }
+    c->stream = c->own;
+    *out = c;
+    return LIMO_OK;
+}
+
+void limo_ctx_destroy(limo_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->own) (void)hipStreamDestroy(ctx->own);
+    delete ctx;
+}
+
+int limo_ctx_set_stream(limo_ctx* ctx, void* hip_stream) {
+    if (!ctx) return LIMO_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own;
+    return LIMO_OK;
+}
+
+const char* limo_last_error(const limo_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : "null context";
+}
+
+void limo_ba_default_options(limo_ba_options* o) {
+    if (!o) return;
+    o->depth_thres = 0.16;
+    o->reprojection_thres = 1.6;
+    o->depth_quantile = 0.95;
+    o->reprojection_quantile = 0.95;
+    o->num_trim_rounds = 1;
+    o->trim_solver_iterations = 2;
+    o->min_landmarks_for_trimming = 100;
+    o->minimum_number_residual_groups = 30;
+    o->max_num_iterations = 100;
+    o->max_solver_time_sec = -1.0;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->min_relative_decrease = 1e-3;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+}
+
+static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* windows, const limo_ba_options* opts,
+                             const PackOptions& po, limo_ba_batch** out) {
+    if (!ctx || !out) return LIMO_ERR_INVALID;
+    *out = nullptr;
+    limo_ba_options o;
+    if (opts)
+        o = *opts;
+    else
+        limo_ba_default_options(&o);
+    limo_ba_batch* b = new limo_ba_batch();
+    b->ctx = ctx;
+    b->opts = o;
+    b->c = make_consts(o);
+    int rc = pack_windows(n, windows, o, po, b->P, ctx->err);
+    if (rc == LIMO_OK) {
+        if (hipSetDevice(ctx->device) != hipSuccess) rc = LIMO_ERR_NO_DEVICE;
+    }
+    if (rc == LIMO_OK) rc = b->upload();
+    if (rc != LIMO_OK) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return LIMO_OK;
+}
+
+int limo_ba_batch_create(limo_ctx* ctx, int32_t n_windows, const limo_ba_window* windows, limo_ba_batch** out) {
+    // min_landmarks_for_trimming decides do_trim at pack time; take it from the default options here and
+    // refresh at solve() if the caller passes different options.
+    return batch_create_impl(ctx, n_windows, windows, nullptr, PackOptions(), out);
+}
+
+int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
+    if (!b) return LIMO_ERR_INVALID;
+    limo_ctx* ctx = b->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    if (opts) {
+        if (opts->min_landmarks_for_trimming != b->opts.min_landmarks_for_trimming) {
+            for (int w = 0; w < b->P.n_win; ++w) b->P.win[w].do_trim = b->P.win[w].n_lm > opts->min_landmarks_for_trimming;
+            HIP_TRY(ctx, hipMemcpyAsync((void*)b->bv.win, b->P.win.data(), sizeof(WinDesc) * b->P.n_win, hipMemcpyHostToDevice,
+                                        ctx->stream));
+        }
+        b->opts = *opts;
+        b->c = make_consts(*opts);
+    }
+    b->rc = LIMO_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(b->ev_total_a, ctx->stream));
+    run_schedule(*b, b->opts);
+    HIP_TRY(ctx, hipEventRecord(b->ev_total_b, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, b->ev_total_a, b->ev_total_b));
+    b->total_ms_acc += ms;
+    b->last_solve_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return b->rc;
+}
+
+int limo_ba_batch_reset(limo_ba_batch* b) {
+    if (!b) return LIMO_ERR_INVALID;
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    return b->reset_state();
+}
+
+int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_ba_report* reports) {
+    if (!b) return LIMO_ERR_INVALID;
+    limo_ctx* ctx = b->ctx;
+    const PackedBatch& P = b->P;
+    std::vector<double> pose((size_t)P.TK * 7), pdir((size_t)P.TK * 3), pdist(P.TK), lm((size_t)P.TL * 3);
+    std::vector<WinState> st(P.n_win);
+    HIP_TRY(ctx, hipMemcpyAsync(pose.data(), b->bv.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pdir.data(), b->bv.pdir, sizeof(double) * pdir.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pdist.data(), b->bv.pdist, sizeof(double) * pdist.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (P.TL) HIP_TRY(ctx, hipMemcpyAsync(lm.data(), b->bv.lm, sizeof(double) * lm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(st.data(), b->bv.st, sizeof(WinState) * st.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int w = 0; w < P.n_win; ++w) {
+        const WinDesc& d = P.win[w];
+        if (windows_out) {
+            limo_ba_window& W = windows_out[w];
+            if (W.n_kf != d.n_kf || W.n_lm != d.n_lm) {
+                ctx->err = "download: window shape differs from create()";
+                return LIMO_ERR_INVALID;
+            }
+            std::memcpy(W.kf_pose, pose.data() + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
+            std::memcpy(W.kf_plane_dir, pdir.data() + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
+            std::memcpy(W.kf_plane_dist, pdist.data() + d.kf0, sizeof(double) * d.n_kf);
+            if (d.n_lm) std::memcpy(W.lm_pos, lm.data() + 3 * (size_t)d.lm0, sizeof(double) * 3 * d.n_lm);
+        }
+        if (reports) {
+            limo_ba_report& r = reports[w];
+            const WinState& s = st[w];
+            std::memset(&r, 0, sizeof(r));
+            r.termination = s.term;
+            r.num_solves = s.acc_solves;
+            r.iterations_total = s.acc_iters;
+            r.iterations_final = s.last_iters;
+            r.successful_steps = s.acc_success;
+            r.n_depth_blocks = d.n_depth;
+            r.n_repr_blocks = d.n_repr;
+            r.n_gp_blocks = d.n_gp;
+            r.n_trimmed_landmarks = s.n_trimmed;
+            r.initial_cost = s.first_initial_cost;
+            r.final_cost = s.solve_final_cost;
+            r.time_sec = b->last_solve_sec;
+        }
+    }
+    return LIMO_OK;
+}
+
+void limo_ba_batch_destroy(limo_ba_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    delete b;
+}
+
+int limo_ba_batch_kernel_stats(limo_ba_batch* b, int reset, double* linearize_ms, int64_t* linearize_launches,
+                               double* total_ms) {
+    if (!b) return LIMO_ERR_INVALID;
+    int rc = b->collect_linearize_events();
+    if (rc != LIMO_OK) return rc;
+    if (linearize_ms) *linearize_ms = b->lin_ms_acc;
+    if (linearize_launches) *linearize_launches = b->lin_launches;
+    if (total_ms) *total_ms = b->total_ms_acc;
+    if (reset) {
+        b->lin_ms_acc = 0.0;
+        b->lin_launches = 0;
+        b->total_ms_acc = 0.0;
+    }
+    return LIMO_OK;
+}
+
+int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report) {
+    if (!ctx || !window) return LIMO_ERR_INVALID;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, PackOptions(), &b);
+    if (rc != LIMO_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = limo_ba_batch_solve(b, nullptr);
+    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
+    if (report) report->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    limo_ba_batch_destroy(b);
+    return rc;
+}
+
+int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_speed_prior* prior,
+                             const limo_ba_options* opts, limo_ba_report* report) {
+    if (!ctx || !window) return LIMO_ERR_INVALID;
+    PackOptions po;
+    po.pose_only = true;
+    po.prior = prior;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, po, &b);
+    if (rc != LIMO_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = limo_ba_batch_solve(b, nullptr);
+    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
+    if (report) report->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    limo_ba_batch_destroy(b);
+    return rc;
+}
+
+int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_options* opts, int apply_loss,
+                     double* cost, double* residuals, double* jac_pose, double* jac_lm, uint8_t* valid) {
+    if (!ctx || !window) return LIMO_ERR_INVALID;
+    PackOptions po;
+    po.evaluate_only = true;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, po, &b);
+    if (rc != LIMO_OK) return rc;
+    const PackedBatch& P = b->P;
+    const int M = P.TO;
+    double* d_cost = nullptr;
+    uint8_t* d_valid = nullptr;
+    rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, M));
+    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, std::max(1, M));
+    if (rc == LIMO_OK && P.n_blk) {
+        hipLaunchKernelGGL(k_evaluate, dim3(P.n_blk), dim3(kBlock), 0, ctx->stream, b->bv, b->c, apply_loss, d_cost, d_valid);
+        if (hipGetLastError() != hipSuccess) rc = LIMO_ERR_RUNTIME;
+    }
+    std::vector<double> hr((size_t)3 * P.SO), hjp((size_t)18 * P.SO), hjl((size_t)9 * P.SO), hc(std::max(1, M));
+    std::vector<uint8_t> hv(std::max(1, M));
+    if (rc == LIMO_OK) {
+        hipError_t e = hipMemcpyAsync(hr.data(), b->bv.obs_r, sizeof(double) * hr.size(), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hjp.data(), b->bv.obs_Jp, sizeof(double) * hjp.size(), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hjl.data(), b->bv.obs_Jl, sizeof(double) * hjl.size(), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cost, sizeof(double) * std::max(1, M), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), d_valid, std::max(1, M), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("evaluate: ") + hipGetErrorString(e);
+            rc = LIMO_ERR_RUNTIME;
+        }
+    }
+    if (rc == LIMO_OK) {
+        double total = 0.0;
+        for (int o = 0; o < M; ++o) {
+            const int src = P.obs_src[o];
+            total += hc[o];
+            if (valid) valid[src] = hv[o];
+            if (residuals)
+                for (int i = 0; i < 3; ++i) residuals[3 * (size_t)src + i] = hr[(size_t)i * P.SO + o];
+            if (jac_pose)
+                for (int i = 0; i < 18; ++i) jac_pose[18 * (size_t)src + i] = hjp[(size_t)i * P.SO + o];
+            if (jac_lm)
+                for (int i = 0; i < 9; ++i) jac_lm[9 * (size_t)src + i] = hjl[(size_t)i * P.SO + o];
+        }
+        if (cost) *cost = total;
+    }
+    limo_ba_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"
