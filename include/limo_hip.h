@@ -143,7 +143,7 @@ typedef struct limo_ba_report {
     int32_t n_repr_blocks;
     int32_t n_gp_blocks;
     int32_t n_trimmed_landmarks; /* landmarks removed by trimming                                */
-    int32_t reserved;
+    int32_t num_linearizations;  /* residual+Jacobian evaluations (iteration 0 + accepted steps), all solves */
     double initial_cost;         /* cost of the first solve at x0 (incl. fixed cost)             */
     double final_cost;           /* cost after the final solve (incl. fixed cost)                */
     double time_sec;             /* wall time inside the library for this window / batch         */

@@ -80,7 +80,7 @@ class BaReport(C.Structure):  # struct limo_ba_report
         ("n_repr_blocks", C.c_int32),
         ("n_gp_blocks", C.c_int32),
         ("n_trimmed_landmarks", C.c_int32),
-        ("reserved", C.c_int32),
+        ("num_linearizations", C.c_int32),
         ("initial_cost", C.c_double),
         ("final_cost", C.c_double),
         ("time_sec", C.c_double),

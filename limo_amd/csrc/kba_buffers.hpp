@@ -41,8 +41,13 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(pdist_c, TK * D, P.pdist.data());
     KBA_BUF(lm_c, TL * 3 * D, P.lm.data());
     KBA_BUF(kf_win, TK * I, P.kf_win.data());
+    KBA_BUF(kf_blk0, TK * I, P.kf_blk0.data());
+    KBA_BUF(kf_nblk, TK * I, P.kf_nblk.data());
+    KBA_BUF(kf_gp0, TK * I, P.kf_gp0.data());
+    KBA_BUF(kf_ngp, TK * I, P.kf_ngp.data());
     KBA_BUF(cmask, TK * kCamSlots, P.cmask.data());
     KBA_BUF(cpresent, TK * kCamSlots, P.cpresent.data());
+    KBA_BUF(cslot, TK * kCamSlots * I, P.cslot.data());
     KBA_BUF(lm_win, TL * I, P.lm_win.data());
     KBA_BUF(lm_weight, TL * D, P.lm_weight.data());
     KBA_BUF(lm_state, TL, P.lm_state.data());

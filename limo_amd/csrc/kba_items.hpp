@@ -92,15 +92,16 @@ KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_
     double nr = -1.0, nd = -1.0;
     if (bv.lm_state[gl]) {
         const double* cam = bv.view_cam + 16 * (int64_t)view;
-        double ruv[2], rd;
+        double ruv[2], rd, zc[3];
+        // the reprojection functor fails for |z| < 0.01 (its block then counts as an infinite residual); the
+        // depth functor has no failure mode (cost_functors_ceres.hpp:193-212)
         if (obs_residual(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                         bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], ruv, &rd, nullptr)) {
+                         bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], ruv, &rd, zc)) {
             nr = sqrt(ruv[0] * ruv[0] + ruv[1] * ruv[1]);
-            if (bv.obs_d[o] > 0.0f) nd = sqrt(rd * rd);
         } else {
             nr = INFINITY;
-            if (bv.obs_d[o] > 0.0f) nd = INFINITY;
         }
+        if (bv.obs_d[o] > 0.0f) nd = fabs(zc[2] - static_cast<double>(bv.obs_d[o]));
     }
     plane_rep[o] = nr;
     plane_dep[o] = nd;
@@ -217,52 +218,64 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
 }
 
 // ======================================================================================= Schur tiles
-// Z tile layout: Z[k * ld + row], k = 3*li + c' (li = landmark within tile), row = camera slot of the window.
+// The Schur complement only involves the FREE camera slots of a window; they are numbered compactly
+// (cslot: full local slot -> compact index or -1; nf free slots, nf_pad rounded up to 16).
+// Z tile layout: Z[k * ld + row], k = 3*li + c' (li = landmark within tile), row = compact camera slot.
 // Y' = W' L^-T with W' = S_c F^T E S_l;  sum_i Y'_i Y'_i^T = W' (V'+D^2)^-1 W'^T.
-// Adds landmark gl's contribution for view j into the tile (caller guarantees exclusive ownership of the
-// (landmark, keyframe) rows, see kba_kernels.hip).
-KBA_HD void schur_fill_view(const BatchView& bv, const WinDesc& wd, int gl, int li, int j, double* Z, int ld) {
+// lmk[9] = {sl[3], Li[6]} of the landmark (loaded once per lane), cs / sc = the window's compact-slot table and
+// camera scale by FULL local slot (LDS on the device).  All global loads are issued before any use so that the
+// 27 plane reads of an observation are in flight together.
+KBA_HD void schur_fill_view(const BatchView& bv, int gl, int li, int j, int kl, const double* lmk, const int* cs,
+                            const double* sc, double* Z, int ld) {
     const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
     if (s < 0) return;
-    const int gk = bv.view_kf[wd.view0 + j];
-    const int row0 = (gk - wd.kf0) * kCamSlots;
-    double sl[3], Li[6];
-    for (int i = 0; i < 3; ++i) sl[i] = bv.lm_scale[i * bv.SL + gl];
-    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
-    double E[9];
+    double E[9], F[18];
+#pragma unroll
     for (int i = 0; i < 9; ++i) E[i] = bv.obs_Jl[i * bv.SO + s];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) F[i] = bv.obs_Jp[i * bv.SO + s];
+    const int row0 = kl * kCamSlots;
+    if (cs[row0] < 0) return;  // pose block constant: all six slots masked together
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
-        if (!bv.cmask[(int64_t)gk * kCamSlots + a]) continue;
-        const double f0 = bv.obs_Jp[(0 * 6 + a) * bv.SO + s], f1 = bv.obs_Jp[(1 * 6 + a) * bv.SO + s],
-                     f2 = bv.obs_Jp[(2 * 6 + a) * bv.SO + s];
-        const double sc = bv.scale_c[(int64_t)gk * kCamSlots + a];
-        const double w0 = sc * (f0 * E[0] + f1 * E[3] + f2 * E[6]) * sl[0];
-        const double w1 = sc * (f0 * E[1] + f1 * E[4] + f2 * E[7]) * sl[1];
-        const double w2 = sc * (f0 * E[2] + f1 * E[5] + f2 * E[8]) * sl[2];
+        const int r = cs[row0 + a];
+        const double f0 = F[a], f1 = F[6 + a], f2 = F[12 + a];
+        const double sca = sc[row0 + a];
+        const double w0 = sca * (f0 * E[0] + f1 * E[3] + f2 * E[6]) * lmk[0];
+        const double w1 = sca * (f0 * E[1] + f1 * E[4] + f2 * E[7]) * lmk[1];
+        const double w2 = sca * (f0 * E[2] + f1 * E[5] + f2 * E[8]) * lmk[2];
         // Y'[a][c'] = sum_c W[a][c] Li[c'][c]
-        Z[(3 * li + 0) * ld + row0 + a] += w0 * Li[0];
-        Z[(3 * li + 1) * ld + row0 + a] += w0 * Li[1] + w1 * Li[2];
-        Z[(3 * li + 2) * ld + row0 + a] += w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+        Z[(3 * li + 0) * ld + r] += w0 * lmk[3];
+        Z[(3 * li + 1) * ld + r] += w0 * lmk[4] + w1 * lmk[5];
+        Z[(3 * li + 2) * ld + r] += w0 * lmk[6] + w1 * lmk[7] + w2 * lmk[8];
     }
 }
 
-KBA_HD void schur_fill_gp(const BatchView& bv, const WinDesc& wd, int gl, int li, double* Z, int ld) {
-    const int gg = bv.lm_gp[gl];
-    if (gg < 0) return;
-    const int gk = bv.gp_kf[gg];
-    const int row0 = (gk - wd.kf0) * kCamSlots;
-    double sl[3], Li[6], E[3];
-    for (int i = 0; i < 3; ++i) sl[i] = bv.lm_scale[i * bv.SL + gl];
-    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
+KBA_HD void schur_fill_gp(const BatchView& bv, int gg, int li, int kl, const double* lmk, const int* cs,
+                          const double* sc, double* Z, int ld) {
+    double E[3], F[10];
+#pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = bv.gp_E[i * bv.SG + gg];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) F[i] = bv.gp_F[i * bv.SG + gg];
+    const int row0 = kl * kCamSlots;
+#pragma unroll
     for (int a = 0; a < kCamSlots; ++a) {
-        if (!bv.cmask[(int64_t)gk * kCamSlots + a]) continue;
-        const double f = bv.gp_F[a * bv.SG + gg] * bv.scale_c[(int64_t)gk * kCamSlots + a];
-        const double w0 = f * E[0] * sl[0], w1 = f * E[1] * sl[1], w2 = f * E[2] * sl[2];
-        Z[(3 * li + 0) * ld + row0 + a] += w0 * Li[0];
-        Z[(3 * li + 1) * ld + row0 + a] += w0 * Li[1] + w1 * Li[2];
-        Z[(3 * li + 2) * ld + row0 + a] += w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+        const int r = cs[row0 + a];
+        if (r < 0) continue;
+        const double f = F[a] * sc[row0 + a];
+        const double w0 = f * E[0] * lmk[0], w1 = f * E[1] * lmk[1], w2 = f * E[2] * lmk[2];
+        Z[(3 * li + 0) * ld + r] += w0 * lmk[3];
+        Z[(3 * li + 1) * ld + r] += w0 * lmk[4] + w1 * lmk[5];
+        Z[(3 * li + 2) * ld + r] += w0 * lmk[6] + w1 * lmk[7] + w2 * lmk[8];
     }
+}
+
+KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lmk[i] = bv.lm_scale[i * bv.SL + gl];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
 }
 
 // ======================================================================================= back-substitution
@@ -555,25 +568,59 @@ KBA_HD double block_grad_inf(int kind, const double* x, const double* g) {
     return m;
 }
 
+// Deterministic workgroup reductions over `nt` lanes (nt a power of two; nt == 1 in the emulator).
+// red must hold nt doubles.  Every lane of the workgroup must call these.
+KBA_HD double coop_sum(double v, int tid, int nt, double* red) {
+    red[tid] = v;
+    KBA_SYNC();
+    for (int s = nt >> 1; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        KBA_SYNC();
+    }
+    const double out = red[0];
+    KBA_SYNC();
+    return out;
+}
+KBA_HD double coop_max(double v, int tid, int nt, double* red) {
+    red[tid] = v;
+    KBA_SYNC();
+    for (int s = nt >> 1; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        KBA_SYNC();
+    }
+    const double out = red[0];
+    KBA_SYNC();
+    return out;
+}
+
+// scratch doubles needed by cam_assemble / cam_solve for a system of nc slots and nt lanes
+KBA_HD int cam_assemble_scratch(int nc, int nt) {
+    return nc * nc + nt + (int)((sizeof(RegRow) * kMaxRegRows + 7) / 8);
+}
+KBA_HD int cam_solve_scratch(int nc, int nt) {
+    return nc * nc + 3 * nc + nt;
+}
+
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
-// Jacobi scaling of the camera columns, cost / gradient-norm / |x| reductions.  H (nc*nc) lives in scratch.
-// lin partial inputs: blk_part (per linearize workgroup), gp planes, lblk_part (per landmark workgroup).
-KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* H) {
+// Jacobi scaling of the camera columns, cost / gradient-norm / |x| reductions.
+// scratch: H (nc*nc) | red (nt) | regulariser rows.
+KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* scratch) {
     const WinDesc& wd = bv.win[w];
     const int nc = wd.nc;
+    double* H = scratch;
+    double* red = scratch + nc * nc;
+    RegRow* rows = reinterpret_cast<RegRow*>(red + nt);
     double* gc = bv.gc + (int64_t)wd.cam0;
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
     KBA_SYNC();
-    // (1) observation blocks: U_k (6x6) and g_k per keyframe, summed over the workgroups of its views.
-    //     One lane per (keyframe, entry) so every output has a single writer and a fixed summation order.
+    // (1) observation blocks: U_k (6x6) and g_k per keyframe = sum over the linearize workgroups of its views
+    //     (contiguous range kf_blk0/kf_nblk); one lane per (keyframe, entry): single writer, fixed order.
     for (int e = tid; e < wd.n_kf * 27; e += nt) {
         const int kl = e / 27, q = e % 27;
+        const int b0 = bv.kf_blk0[wd.kf0 + kl], nb = bv.kf_nblk[wd.kf0 + kl];
         double acc = 0.0;
-        for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
-            if (bv.view_kf[bv.blk_view[b]] != wd.kf0 + kl) continue;
-            acc += bv.blk_part[(int64_t)b * kLinPartial + 1 + q];
-        }
+        for (int b = b0; b < b0 + nb; ++b) acc += bv.blk_part[(int64_t)b * kLinPartial + 1 + q];
         if (q < 21) {
             int a = 0, rem = q;
             while (rem >= 6 - a) {
@@ -588,13 +635,13 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
     }
     KBA_SYNC();
-    // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe
+    // (2) ground-plane rows (sorted by keyframe: kf_gp0/kf_ngp): F^T F on the 10x10 block of their keyframe
     for (int e = tid; e < wd.n_kf * 110; e += nt) {
         const int kl = e / 110, q = e % 110;
         const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : -1;
+        const int g0 = bv.kf_gp0[wd.kf0 + kl], ng = bv.kf_ngp[wd.kf0 + kl];
         double acc = 0.0;
-        for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) {
-            if (bv.gp_kf[g] != wd.kf0 + kl) continue;
+        for (int g = g0; g < g0 + ng; ++g) {
             const double fa = bv.gp_F[a * bv.SG + g];
             acc += fa * (bb >= 0 ? bv.gp_F[bb * bv.SG + g] : bv.gp_r[g]);
         }
@@ -603,27 +650,26 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         else
             gc[kl * kCamSlots + a] += acc;
     }
-    KBA_SYNC();
-    // (3) regulariser rows (few): single lane per row writes its sparse outer product serially over rows
+    // (3) regulariser rows: one lane evaluates one row into scratch ...
     const int nrows = reg_row_count(wd);
-    double reg_free = 0.0, reg_fixed = 0.0;
-    if (tid == 0) {
-        for (int i = 0; i < nrows; ++i) {
-            RegRow row;
-            int all_const;
-            reg_row_eval(wd, bv.cmask, bv.pose, bv.pdir, bv.pdist, i, true, row, all_const);
-            if (all_const) {
-                reg_fixed += 0.5 * row.r * row.r;
-                continue;
-            }
-            reg_free += 0.5 * row.r * row.r;
-            for (int p = 0; p < row.n; ++p) {
-                gc[row.col[p]] += row.val[p] * row.r;
-                for (int q = 0; q < row.n; ++q) H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
-            }
-        }
+    for (int i = tid; i < nrows; i += nt) {
+        int all_const;
+        reg_row_eval(wd, bv.cmask, bv.pose, bv.pdir, bv.pdist, i, true, rows[i], all_const);
+        if (all_const) rows[i].n = -1;  // fixed-cost row
     }
     KBA_SYNC();
+    // ... then rows are added one after another (fixed order), each row's <=16x16 outer product spread over lanes
+    for (int i = 0; i < nrows; ++i) {
+        const RegRow& row = rows[i];
+        if (row.n > 0) {
+            for (int e = tid; e < row.n * row.n; e += nt) {
+                const int p = e / row.n, q = e % row.n;
+                H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+            }
+            for (int p = tid; p < row.n; p += nt) gc[row.col[p]] += row.val[p] * row.r;
+        }
+        KBA_SYNC();
+    }
     // (4) mask constant / absent slots
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
     for (int i = tid; i < nc * nc; i += nt) {
@@ -638,41 +684,50 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         for (int i = tid; i < nc; i += nt)
             bv.scale_c[wd.cam0 + i] = (cm[i] && c.jacobi_scaling) ? 1.0 / (1.0 + sqrt(H[i * nc + i])) : 1.0;
     }
-    // (5) reductions (single lane, fixed order)
+    // (5) reductions
+    double cost = 0.0, failf = 0.0, gmax = 0.0, xn2 = 0.0, reg_free = 0.0, reg_fixed = 0.0;
+    for (int b = wd.blk0 + tid; b < wd.blk0 + wd.n_blk; b += nt) {
+        cost += bv.blk_part[(int64_t)b * kLinPartial];
+        if (bv.blk_fail[b]) failf = 1.0;
+    }
+    for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost[g];
+    for (int i = tid; i < nrows; i += nt) {
+        if (rows[i].n < 0)
+            reg_fixed += 0.5 * rows[i].r * rows[i].r;
+        else
+            reg_free += 0.5 * rows[i].r * rows[i].r;
+    }
+    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt) {
+        gmax = fmax(gmax, bv.lblk_part[(int64_t)b * 8 + 0]);
+        xn2 += bv.lblk_part[(int64_t)b * 8 + 1];
+    }
+    for (int k = tid; k < wd.n_kf; k += nt) {
+        const int gk = wd.kf0 + k;
+        if (cm[k * kCamSlots + 0]) {
+            const double* x = bv.pose + 7 * (int64_t)gk;
+            gmax = fmax(gmax, block_grad_inf(0, x, gc + k * kCamSlots));
+            for (int i = 0; i < 7; ++i) xn2 += x[i] * x[i];
+        }
+        if (cm[k * kCamSlots + 6]) {
+            const double* x = bv.pdir + 3 * (int64_t)gk;
+            gmax = fmax(gmax, block_grad_inf(1, x, gc + k * kCamSlots + 6));
+            for (int i = 0; i < 3; ++i) xn2 += x[i] * x[i];
+        }
+        if (cm[k * kCamSlots + 9]) {
+            gmax = fmax(gmax, block_grad_inf(2, bv.pdist + gk, gc + k * kCamSlots + 9));
+            xn2 += bv.pdist[gk] * bv.pdist[gk];
+        }
+    }
+    reg_free = coop_sum(reg_free, tid, nt, red);
+    reg_fixed = coop_sum(reg_fixed, tid, nt, red);
+    cost = coop_sum(cost, tid, nt, red) + reg_free;
+    failf = coop_max(failf, tid, nt, red);
+    gmax = coop_max(gmax, tid, nt, red);
+    xn2 = coop_sum(xn2, tid, nt, red);
     if (tid == 0) {
         WinRed& r = bv.red[w];
-        double cost = 0.0;
-        int fail = 0;
-        for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
-            cost += bv.blk_part[(int64_t)b * kLinPartial];
-            fail |= bv.blk_fail[b];
-        }
-        for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) cost += bv.gp_cost[g];
-        cost += reg_free;
-        double gmax = 0.0, xn2 = 0.0;
-        for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
-            gmax = fmax(gmax, bv.lblk_part[(int64_t)b * 8 + 0]);
-            xn2 += bv.lblk_part[(int64_t)b * 8 + 1];
-        }
-        for (int k = 0; k < wd.n_kf; ++k) {
-            const int gk = wd.kf0 + k;
-            if (cm[k * kCamSlots + 0]) {
-                const double* x = bv.pose + 7 * (int64_t)gk;
-                gmax = fmax(gmax, block_grad_inf(0, x, gc + k * kCamSlots));
-                for (int i = 0; i < 7; ++i) xn2 += x[i] * x[i];
-            }
-            if (cm[k * kCamSlots + 6]) {
-                const double* x = bv.pdir + 3 * (int64_t)gk;
-                gmax = fmax(gmax, block_grad_inf(1, x, gc + k * kCamSlots + 6));
-                for (int i = 0; i < 3; ++i) xn2 += x[i] * x[i];
-            }
-            if (cm[k * kCamSlots + 9]) {
-                gmax = fmax(gmax, block_grad_inf(2, bv.pdist + gk, gc + k * kCamSlots + 9));
-                xn2 += bv.pdist[gk] * bv.pdist[gk];
-            }
-        }
         r.lin_cost = cost;
-        r.lin_fail = fail;
+        r.lin_fail = failf != 0.0;
         r.gmax = gmax;
         r.xnorm2 = xn2;
         bv.reg_cost[2 * w] = reg_free;
@@ -681,32 +736,42 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
 }
 
 // Workgroup-per-window: S = S_c H S_c + D^2 - sum Schur slabs, rhs = S_c g_c - sum slabs; dense Cholesky; camera
-// step, camera candidate, camera parts of the step reductions.  S (nc*nc) and v (3*nc) live in scratch.
-KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* S, double* v,
-                      int* flag) {
+// step, camera candidate, camera parts of the step reductions.  scratch: S (nc*nc) | v (3*nc) | red (nt).
+KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* scratch, int* flag) {
     const WinDesc& wd = bv.win[w];
-    const int nc = wd.nc, ncp = wd.nc_pad;
+    const int nc = wd.nc, nfp = wd.nf_pad;
+    double* S = scratch;
+    double* rhs = scratch + nc * nc;
+    double* red = rhs + 3 * nc;
+    const int32_t* cs = bv.cslot + wd.cam0;
     const double radius = bv.st[w].radius;
     const double* Hg = bv.Hcc + wd.hcc_off;
     const double* sc = bv.scale_c + wd.cam0;
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
-    double* rhs = v;
     double* yc = bv.yc + wd.cam0;
     double* dc = bv.delta_c + wd.cam0;
-    const int slab = ncp * ncp + ncp;
+    const int slab = nfp * nfp + nfp;
     if (tid == 0) *flag = 0;
     for (int i = tid; i < nc * nc; i += nt) {
         const int a = i / nc, b = i % nc;
-        double s = sc[a] * sc[b] * Hg[i];
-        if (a == b) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-        for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + a * ncp + b];
-        if (!cm[a] || !cm[b]) s = (a == b) ? 1.0 : 0.0;
+        double s;
+        if (cm[a] && cm[b]) {
+            s = sc[a] * sc[b] * Hg[i];
+            if (a == b) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+            const int ca = cs[a], cb = cs[b];
+            for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + ca * nfp + cb];
+        } else {
+            s = (a == b) ? 1.0 : 0.0;
+        }
         S[i] = s;
     }
     for (int a = tid; a < nc; a += nt) {
-        double s = sc[a] * bv.gc[wd.cam0 + a];
-        for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + ncp * ncp + a];
-        rhs[a] = cm[a] ? s : 0.0;
+        double s = 0.0;
+        if (cm[a]) {
+            s = sc[a] * bv.gc[wd.cam0 + a];
+            for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + nfp * nfp + cs[a]];
+        }
+        rhs[a] = s;
     }
     KBA_SYNC();
     // right-looking Cholesky on the upper triangle: S = U^T U (Eigen LLT<Upper> semantics: fail when pivot <= 0)
@@ -741,109 +806,119 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         for (int a = tid; a < nc; a += nt) dc[a] = 0.0;
         return;
     }
-    if (tid == 0) {
-        // U^T y = rhs ; U x = y
-        for (int i = 0; i < nc; ++i) {
-            double s = rhs[i];
-            for (int p = 0; p < i; ++p) s -= S[p * nc + i] * rhs[p];
-            rhs[i] = s / S[i * nc + i];
-        }
-        for (int i = nc - 1; i >= 0; --i) {
-            double s = rhs[i];
-            for (int p = i + 1; p < nc; ++p) s -= S[i * nc + p] * rhs[p];
-            rhs[i] = s / S[i * nc + i];
-        }
+    // triangular solves, column oriented:  U^T y = rhs  then  U x = y
+    for (int i = 0; i < nc; ++i) {
+        if (tid == 0) rhs[i] = rhs[i] / S[i * nc + i];
+        KBA_SYNC();
+        const double xi = rhs[i];
+        for (int j = i + 1 + tid; j < nc; j += nt) rhs[j] -= S[i * nc + j] * xi;
+        KBA_SYNC();
     }
-    KBA_SYNC();
+    for (int i = nc - 1; i >= 0; --i) {
+        if (tid == 0) rhs[i] = rhs[i] / S[i * nc + i];
+        KBA_SYNC();
+        const double xi = rhs[i];
+        for (int j = tid; j < i; j += nt) rhs[j] -= S[j * nc + i] * xi;
+        KBA_SYNC();
+    }
     for (int a = tid; a < nc; a += nt) {
         yc[a] = rhs[a];
-        dc[a] = cm[a] ? -sc[a] * rhs[a] : 0.0;
+        const double d = cm[a] ? -sc[a] * rhs[a] : 0.0;
+        dc[a] = d;
+        rhs[nc + a] = d;  // delta_c copy in scratch
     }
     KBA_SYNC();
+    const double* dl = rhs + nc;
+    // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled)
+    double part = 0.0;
+    for (int a = tid; a < nc; a += nt) {
+        double hd = 0.0;
+        for (int b = 0; b < nc; ++b) hd += Hg[a * nc + b] * dl[b];
+        part += -bv.gc[wd.cam0 + a] * dl[a] - 0.5 * dl[a] * hd;
+    }
+    double step2 = 0.0, cand2 = 0.0;
+    for (int k = tid; k < wd.n_kf; k += nt) {
+        const int gk = wd.kf0 + k;
+        const double* d = dl + k * kCamSlots;
+        const double* x = bv.pose + 7 * (int64_t)gk;
+        double* xc = bv.pose_c + 7 * (int64_t)gk;
+        if (cm[k * kCamSlots + 0]) {
+            pose_plus(x, d, xc);
+            for (int i = 0; i < 7; ++i) {
+                step2 += (x[i] - xc[i]) * (x[i] - xc[i]);
+                cand2 += xc[i] * xc[i];
+            }
+        } else {
+            for (int i = 0; i < 7; ++i) xc[i] = x[i];
+        }
+        const double* n = bv.pdir + 3 * (int64_t)gk;
+        double* ncand = bv.pdir_c + 3 * (int64_t)gk;
+        if (cm[k * kCamSlots + 6]) {
+            unitvec_plus(n, d + 6, ncand);
+            for (int i = 0; i < 3; ++i) {
+                step2 += (n[i] - ncand[i]) * (n[i] - ncand[i]);
+                cand2 += ncand[i] * ncand[i];
+            }
+        } else {
+            for (int i = 0; i < 3; ++i) ncand[i] = n[i];
+        }
+        if (cm[k * kCamSlots + 9]) {
+            bv.pdist_c[gk] = bv.pdist[gk] + d[9];
+            step2 += d[9] * d[9];
+            cand2 += bv.pdist_c[gk] * bv.pdist_c[gk];
+        } else {
+            bv.pdist_c[gk] = bv.pdist[gk];
+        }
+    }
+    part = coop_sum(part, tid, nt, red);
+    step2 = coop_sum(step2, tid, nt, red);
+    cand2 = coop_sum(cand2, tid, nt, red);
     if (tid == 0) {
         WinRed& r = bv.red[w];
-        // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled)
-        double gd = 0.0, dHd = 0.0;
-        for (int a = 0; a < nc; ++a) {
-            gd += bv.gc[wd.cam0 + a] * dc[a];
-            double hd = 0.0;
-            for (int b = 0; b < nc; ++b) hd += Hg[a * nc + b] * dc[b];
-            dHd += dc[a] * hd;
-        }
-        double step2 = 0.0, cand2 = 0.0;
-        for (int k = 0; k < wd.n_kf; ++k) {
-            const int gk = wd.kf0 + k;
-            const double* d = dc + k * kCamSlots;
-            const double* x = bv.pose + 7 * (int64_t)gk;
-            double* xc = bv.pose_c + 7 * (int64_t)gk;
-            if (cm[k * kCamSlots + 0]) {
-                pose_plus(x, d, xc);
-                for (int i = 0; i < 7; ++i) {
-                    step2 += (x[i] - xc[i]) * (x[i] - xc[i]);
-                    cand2 += xc[i] * xc[i];
-                }
-            } else {
-                for (int i = 0; i < 7; ++i) xc[i] = x[i];
-            }
-            const double* n = bv.pdir + 3 * (int64_t)gk;
-            double* ncand = bv.pdir_c + 3 * (int64_t)gk;
-            if (cm[k * kCamSlots + 6]) {
-                unitvec_plus(n, d + 6, ncand);
-                for (int i = 0; i < 3; ++i) {
-                    step2 += (n[i] - ncand[i]) * (n[i] - ncand[i]);
-                    cand2 += ncand[i] * ncand[i];
-                }
-            } else {
-                for (int i = 0; i < 3; ++i) ncand[i] = n[i];
-            }
-            if (cm[k * kCamSlots + 9]) {
-                bv.pdist_c[gk] = bv.pdist[gk] + d[9];
-                step2 += d[9] * d[9];
-                cand2 += bv.pdist_c[gk] * bv.pdist_c[gk];
-            } else {
-                bv.pdist_c[gk] = bv.pdist[gk];
-            }
-        }
         r.chol_fail = 0;
-        r.mcc = -gd - 0.5 * dHd;
+        r.mcc = part;
         r.step2 = step2;
         r.cand2 = cand2;
     }
 }
 
-// After backsub + candidate cost kernels: fold the landmark / observation partials into WinRed (single lane).
-KBA_HD void reduce_step(const BatchView& bv, int w, const double* blk_cost_c, const int* blk_fail_c,
-                        const double* gp_cost_c) {
+// After backsub + candidate cost kernels: fold the landmark / observation partials into WinRed (workgroup, red[nt]).
+KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red) {
     const WinDesc& wd = bv.win[w];
-    WinRed& r = bv.red[w];
-    double mcc = 0.0, s2 = 0.0, c2 = 0.0;
-    int lfail = 0;
-    for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
+    double mcc = 0.0, s2 = 0.0, c2 = 0.0, lfail = 0.0, cost = 0.0, cfail = 0.0;
+    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt) {
         mcc += bv.lblk_part[(int64_t)b * 8 + 2];
         s2 += bv.lblk_part[(int64_t)b * 8 + 3];
         c2 += bv.lblk_part[(int64_t)b * 8 + 4];
-        lfail |= (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0);
+        if (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0) lfail = 1.0;
     }
-    r.mcc += mcc;
-    r.step2 += s2;
-    r.cand2 += c2;
-    r.chol_fail |= lfail;
-    double cost = 0.0;
-    int fail = 0;
-    for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b) {
-        cost += blk_cost_c[b];
-        fail |= blk_fail_c[b];
+    for (int b = wd.blk0 + tid; b < wd.blk0 + wd.n_blk; b += nt) {
+        cost += bv.blk_cost_c[b];
+        if (bv.blk_fail_c[b]) cfail = 1.0;
     }
-    for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) cost += gp_cost_c[g];
+    for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost_c[g];
     const int nrows = reg_row_count(wd);
-    for (int i = 0; i < nrows; ++i) {
+    for (int i = tid; i < nrows; i += nt) {
         RegRow row;
         int all_const;
         reg_row_eval(wd, bv.cmask, bv.pose_c, bv.pdir_c, bv.pdist_c, i, false, row, all_const);
         if (!all_const) cost += 0.5 * row.r * row.r;
     }
-    r.cand_cost = cost;
-    r.cand_fail = fail;
+    mcc = coop_sum(mcc, tid, nt, red);
+    s2 = coop_sum(s2, tid, nt, red);
+    c2 = coop_sum(c2, tid, nt, red);
+    cost = coop_sum(cost, tid, nt, red);
+    lfail = coop_max(lfail, tid, nt, red);
+    cfail = coop_max(cfail, tid, nt, red);
+    if (tid == 0) {
+        WinRed& r = bv.red[w];
+        r.mcc += mcc;
+        r.step2 += s2;
+        r.cand2 += c2;
+        if (lfail != 0.0) r.chol_fail = 1;
+        r.cand_cost = cost;
+        r.cand_fail = cfail != 0.0;
+    }
 }
 
 // ======================================================================================= trimming

@@ -166,18 +166,31 @@ __host__ __device__ inline int schur_ld(int ncp) {  // LDS row stride (doubles):
 }
 
 constexpr int kSchurMaxTilesPerWave = 9;  // upper-triangular 16x16 tiles of a 128x128 system over 4 waves
+constexpr int kSchurMaxViews = 64;
+
+__host__ __device__ inline int schur_lds_doubles(int nfp) {
+    return 3 * kSchurLm * schur_ld(nfp) + 3 * kSchurLm + kMaxNc + (kMaxNc + kSchurMaxViews + 1) / 2;
+}
 
 __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
     const int sb = blockIdx.x;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
-    const int nc = wd.nc, ncp = wd.nc_pad, ld = schur_ld(ncp);
+    const int nc = wd.nc, nf = wd.nf, nfp = wd.nf_pad, ld = schur_ld(nfp);
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Z = smem;                       // [3*kSchurLm][ld]
-    double* tt = smem + 3 * kSchurLm * ld;  // [3*kSchurLm]
+    double* Z = smem;                        // [3*kSchurLm][ld]
+    double* tt = Z + 3 * kSchurLm * ld;      // [3*kSchurLm]
+    double* sc_s = tt + 3 * kSchurLm;        // [kMaxNc] camera column scale by full local slot
+    int* cs_s = reinterpret_cast<int*>(sc_s + kMaxNc);  // [kMaxNc] compact slot or -1
+    int* vkl = cs_s + kMaxNc;                // [kSchurMaxViews] keyframe (local) of each view
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = ncp / 16;
+    for (int i = threadIdx.x; i < nc; i += kBlock) {
+        sc_s[i] = bv.scale_c[wd.cam0 + i];
+        cs_s[i] = bv.cslot[wd.cam0 + i];
+    }
+    for (int j = threadIdx.x; j < wd.n_view; j += kBlock) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
+    const int T = nfp / 16;
     const int n_upper = T * (T + 1) / 2;
     v4f64 acc[kSchurMaxTilesPerWave];
 #pragma unroll
@@ -194,17 +207,24 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
         if (li < nl) {
             const int gl = bv.sblk_lm0[sb] + l0 + li;
             if (bv.lm_state[gl] == 1) {
-                for (int j = 0; j < wd.n_view; ++j) {
-                    const int kl = bv.view_kf[wd.view0 + j] - wd.kf0;
-                    if ((kl & 7) != grp) continue;
-                    schur_fill_view(bv, wd, gl, li, j, Z, ld);
-                }
                 const int gg = bv.lm_gp[gl];
-                if (gg >= 0 && ((bv.gp_kf[gg] - wd.kf0) & 7) == grp) schur_fill_gp(bv, wd, gl, li, Z, ld);
-                if (grp == 0) {
-                    tt[3 * li + 0] = bv.lm_t[0 * bv.SL + gl];
-                    tt[3 * li + 1] = bv.lm_t[1 * bv.SL + gl];
-                    tt[3 * li + 2] = bv.lm_t[2 * bv.SL + gl];
+                const int gkl = gg >= 0 ? bv.gp_kf[gg] - wd.kf0 : -1;
+                bool mine = (gkl >= 0 && (gkl & 7) == grp) || grp == 0;
+                for (int j = 0; j < wd.n_view && !mine; ++j) mine = (vkl[j] & 7) == grp;
+                if (mine) {
+                    double lmk[9];
+                    schur_load_lm(bv, gl, lmk);
+                    for (int j = 0; j < wd.n_view; ++j) {
+                        const int kl = vkl[j];
+                        if ((kl & 7) != grp) continue;
+                        schur_fill_view(bv, gl, li, j, kl, lmk, cs_s, sc_s, Z, ld);
+                    }
+                    if (gkl >= 0 && (gkl & 7) == grp) schur_fill_gp(bv, gg, li, gkl, lmk, cs_s, sc_s, Z, ld);
+                    if (grp == 0) {
+                        tt[3 * li + 0] = bv.lm_t[0 * bv.SL + gl];
+                        tt[3 * li + 1] = bv.lm_t[1 * bv.SL + gl];
+                        tt[3 * li + 2] = bv.lm_t[2 * bv.SL + gl];
+                    }
                 }
             }
         }
@@ -215,8 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
         for (int q = 0; q < kSchurMaxTilesPerWave; ++q) {
             const int tile = wave + 4 * q;
             if (tile < n_upper) {
-                // decode upper-triangular tile index -> (tr, tc)
-                int tr = 0, rem = tile;
+                int tr = 0, rem = tile;  // upper-triangular tile index -> (tr, tc)
                 while (rem >= T - tr) {
                     rem -= T - tr;
                     ++tr;
@@ -233,14 +252,14 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
                 acc[q] = a4;
             }
         }
-        if ((int)threadIdx.x < nc) {
+        if ((int)threadIdx.x < nf) {
             double s = 0.0;
             for (int k = 0; k < 3 * nl; ++k) s += Z[k * ld + threadIdx.x] * tt[k];
             rhs_acc += s;
         }
         __syncthreads();
     }
-    const int slab = ncp * ncp + ncp;
+    const int slab = nfp * nfp + nfp;
     double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
 #pragma unroll
     for (int q = 0; q < kSchurMaxTilesPerWave; ++q) {
@@ -257,12 +276,12 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
             for (int r = 0; r < 4; ++r) {
                 const int row = tr * 16 + (lane >> 4) + 4 * r;  // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg
                 const double v = acc[q][r];
-                out[row * ncp + col] = v;
-                if (tr != tc) out[col * ncp + row] = v;
+                out[row * nfp + col] = v;
+                if (tr != tc) out[col * nfp + row] = v;
             }
         }
     }
-    if ((int)threadIdx.x < ncp) out[ncp * ncp + threadIdx.x] = ((int)threadIdx.x < nc) ? rhs_acc : 0.0;
+    if ((int)threadIdx.x < nfp) out[nfp * nfp + threadIdx.x] = ((int)threadIdx.x < nf) ? rhs_acc : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------ camera system
@@ -284,16 +303,16 @@ __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts 
     if (!bv.st[w].active) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
-    const int nc = bv.win[w].nc;
-    cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, smem + nc * nc, &flag);
+    cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, &flag);
 }
 
-__global__ void k_step_decide(BatchView bv, SolveConsts c) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= bv.n_win) return;
+__global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c) {
+    const int w = blockIdx.x;
     if (!bv.st[w].active) return;
-    reduce_step(bv, w, bv.blk_cost_c, bv.blk_fail_c, bv.gp_cost_c);
-    lm_decide_step(bv.st[w], bv.red[w], c);
+    __shared__ double red[64];
+    reduce_step(bv, w, threadIdx.x, blockDim.x, red);
+    __syncthreads();
+    if (threadIdx.x == 0) lm_decide_step(bv.st[w], bv.red[w], c);
 }
 
 // candidate -> current for accepted windows (keyframe part: first TK threads, landmark part: the rest)
@@ -331,10 +350,19 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
     const int w = blockIdx.x;
     const WinDesc& wd = bv.win[w];
     if (!wd.do_trim) return;
+    // stage both value lists in LDS (the rank count re-reads every value n_lm times)
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* vdep = smem;
+    double* vrep = smem + wd.n_lm;
+    for (int l = threadIdx.x; l < wd.n_lm; l += blockDim.x) {
+        vdep[l] = bv.trim_dep[wd.lm0 + l];
+        vrep[l] = bv.trim_rep[wd.lm0 + l];
+    }
+    __syncthreads();
     int removed = 0;
     for (int l = threadIdx.x; l < wd.n_lm; l += blockDim.x) {
-        const int out = trim_is_outlier(bv.trim_dep + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
-                        trim_is_outlier(bv.trim_rep + wd.lm0, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
+        const int out = trim_is_outlier(vdep, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
+                        trim_is_outlier(vrep, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
         if (out && bv.lm_state[wd.lm0 + l]) {
             bv.lm_state[wd.lm0 + l] = 0;
             ++removed;

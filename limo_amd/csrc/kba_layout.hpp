@@ -37,6 +37,7 @@ struct WinDesc {
     int32_t gp0, n_gp;
     int32_t sblk0, n_sblk;    // Schur workgroups
     int32_t nc, nc_pad;       // 10*n_kf, rounded up to 16
+    int32_t nf, nf_pad;       // free camera slots (compact Schur system), rounded up to 16
     int32_t cam0;             // first global camera-slot index = kf0*10
     int32_t reg0;             // first row in the regulariser row buffers
     int32_t has_scale_reg, has_gp_reg;
@@ -57,7 +58,7 @@ struct WinState {
     int32_t compute_scale;     // next linearisation defines the Jacobi scaling
     int32_t n_success, n_unsuccess;
     int32_t acc_solves, acc_iters, acc_success, last_iters;
-    int32_t n_trimmed, pad0;
+    int32_t n_trimmed, acc_lin;
     double radius, decrease_factor;
     double x_cost, x_norm, fixed_cost;
     double solve_initial_cost, solve_final_cost;
@@ -99,8 +100,13 @@ struct BatchView {
     double *pose_c, *pdir_c, *pdist_c, *lm_c;
     // --- constant per keyframe / landmark / view / observation
     const int32_t* kf_win;      // [TK]
+    const int32_t* kf_blk0;     // [TK] first linearize workgroup of this keyframe's views (contiguous)
+    const int32_t* kf_nblk;     // [TK]
+    const int32_t* kf_gp0;      // [TK] first ground-plane row attached to this keyframe (rows sorted by keyframe)
+    const int32_t* kf_ngp;      // [TK]
     uint8_t* cmask;             // [TK*10] 1 = free tangent dim of the reduced program
     uint8_t* cpresent;          // [TK*10] 1 = parameter block is in the problem (free or constant)
+    const int32_t* cslot;       // [TK*10] compact index of a free slot inside its window, -1 otherwise
     const int32_t* lm_win;      // [TL]
     const double* lm_weight;    // [TL]
     uint8_t* lm_state;          // [TL] 1 = in problem, 0 = removed by trimming / not constrained

@@ -71,6 +71,7 @@ KBA_HD void lm_decide_lin(WinState& s, const WinRed& r, double fixed_cost, const
     }
     s.x_cost = r.lin_cost;
     s.gmax = r.gmax;
+    s.acc_lin += 1;
     if (s.first) {
         s.first = 0;
         s.fixed_cost = fixed_cost;

@@ -134,15 +134,15 @@ KBA_HD bool obs_residual(const double* pose, const double* Rc, const double* tc,
     zc[0] += tc[0];
     zc[1] += tc[1];
     zc[2] += tc[2];
-    if (!(fabs(zc[2]) >= 0.01)) return false;
-    r_uv[0] = f * (zc[0] / zc[2]) + cx - static_cast<double>(u);
-    r_uv[1] = f * (zc[1] / zc[2]) + cy - static_cast<double>(v);
-    *r_d = (d > 0.0f) ? zc[2] - static_cast<double>(d) : 0.0;
     if (zc_out) {
         zc_out[0] = zc[0];
         zc_out[1] = zc[1];
         zc_out[2] = zc[2];
     }
+    *r_d = (d > 0.0f) ? zc[2] - static_cast<double>(d) : 0.0;
+    if (!(fabs(zc[2]) >= 0.01)) return false;
+    r_uv[0] = f * (zc[0] / zc[2]) + cx - static_cast<double>(u);
+    r_uv[1] = f * (zc[1] / zc[2]) + cy - static_cast<double>(v);
     return true;
 }
 

@@ -123,8 +123,13 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.pdir.resize((size_t)P.TK * 3);
     P.pdist.resize(P.TK);
     P.kf_win.resize(P.TK);
+    P.kf_blk0.assign(std::max(1, P.TK), 0);
+    P.kf_nblk.assign(std::max(1, P.TK), 0);
+    P.kf_gp0.assign(std::max(1, P.TK), 0);
+    P.kf_ngp.assign(std::max(1, P.TK), 0);
     P.cmask.assign((size_t)P.TK * kCamSlots, 0);
     P.cpresent.assign((size_t)P.TK * kCamSlots, 0);
+    P.cslot.assign((size_t)std::max(1, P.TK) * kCamSlots, -1);
     P.lm.resize((size_t)P.TL * 3);
     P.lm_win.resize(P.TL);
     P.lm_gp.assign(P.TL, -1);
@@ -182,6 +187,9 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             const int start = pos;
             while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
             for (int b0 = start; b0 < pos; b0 += kBlock) {
+                const int gkf = d.kf0 + views[w][v].kf;
+                if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
+                P.kf_nblk[gkf]++;
                 P.blk_view.push_back(d.view0 + v);
                 P.blk_obs0.push_back(d.obs0 + b0);
                 P.blk_n.push_back(std::min(kBlock, pos - b0));
@@ -212,6 +220,11 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
 
         // ---- ground-plane residuals, addGroundPlaneResiduals(10.), bundle_adjuster_keyframes.cpp:517-562
         d.gp0 = (int)P.gp_lm.size();
+        struct GpTmp {
+            int kf, lm;
+            double w;
+        };
+        std::vector<GpTmp> gp_tmp;
         if (!po.pose_only && !po.evaluate_only) {
             const double weight = 10.;
             for (int l = 0; l < W.n_lm; ++l) {
@@ -235,12 +248,20 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 if (kf_id < 0) continue;
                 const double max_valid_dist = 25.;
                 if (min_dist < max_valid_dist) {
-                    P.lm_gp[d.lm0 + l] = (int)P.gp_lm.size();
-                    P.gp_lm.push_back(d.lm0 + l);
-                    P.gp_kf.push_back(d.kf0 + kf_id);
-                    P.gp_w.push_back(weight * (1. - min_dist / max_valid_dist));
+                    gp_tmp.push_back({kf_id, l, weight * (1. - min_dist / max_valid_dist)});
                     if (P.lm_state[d.lm0 + l] == 0) P.lm_state[d.lm0 + l] = 1;  // constrained by its gp block only
                 }
+            }
+            // rows sorted by keyframe (stable in landmark order) so each keyframe owns a contiguous range
+            std::stable_sort(gp_tmp.begin(), gp_tmp.end(), [](const GpTmp& a, const GpTmp& b) { return a.kf < b.kf; });
+            for (const GpTmp& g : gp_tmp) {
+                const int gi = (int)P.gp_lm.size();
+                if (P.kf_ngp[d.kf0 + g.kf] == 0) P.kf_gp0[d.kf0 + g.kf] = gi;
+                P.kf_ngp[d.kf0 + g.kf]++;
+                P.lm_gp[d.lm0 + g.lm] = gi;
+                P.gp_lm.push_back(d.lm0 + g.lm);
+                P.gp_kf.push_back(d.kf0 + g.kf);
+                P.gp_w.push_back(g.w);
             }
         }
         d.n_gp = (int)P.gp_lm.size() - d.gp0;
@@ -297,6 +318,10 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 if (plane_in && !fixed && !(n_depth < 10)) set_block(freem, k, 9, 1);  // :722-728
             }
         }
+        d.nf = 0;
+        for (int i = 0; i < d.nc; ++i)
+            if (freem[i]) P.cslot[(size_t)d.cam0 + i] = d.nf++;
+        d.nf_pad = std::max(16, (d.nf + 15) / 16 * 16);
         d.do_trim = (W.n_lm > opts.min_landmarks_for_trimming) ? 1 : 0;  // :741 / :865
 
         // ---- workgroup tables
@@ -308,7 +333,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         }
         d.n_lblk = (int)P.lblk_win.size() - d.lblk0;
         d.sblk0 = (int)P.sblk_win.size();
-        if (!po.pose_only && !po.evaluate_only) {
+        if (!po.pose_only && !po.evaluate_only && d.nf > 0) {
             const int per = 8 * kSchurLm;
             for (int l0 = 0; l0 < W.n_lm; l0 += per) {
                 P.sblk_win.push_back(w);
@@ -320,7 +345,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.hcc_off = P.hcc_total;
         P.hcc_total += (int64_t)d.nc * d.nc;
         d.spart_off = P.spart_total;
-        P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nc_pad * d.nc_pad + d.nc_pad);
+        P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad + d.nf_pad);
     }
     P.TG = (int)P.gp_lm.size();
     P.SG = pad64(std::max(1, P.TG));

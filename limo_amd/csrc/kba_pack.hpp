@@ -19,8 +19,9 @@ struct PackedBatch {
     int64_t hcc_total = 0, spart_total = 0;
     std::vector<WinDesc> win;
     std::vector<double> pose, pdir, pdist, lm;  // initial parameters
-    std::vector<int32_t> kf_win;
+    std::vector<int32_t> kf_win, kf_blk0, kf_nblk, kf_gp0, kf_ngp;
     std::vector<uint8_t> cmask, cpresent;
+    std::vector<int32_t> cslot;
     std::vector<int32_t> lm_win, lm_gp, lm_slot;
     std::vector<double> lm_weight;
     std::vector<uint8_t> lm_state;

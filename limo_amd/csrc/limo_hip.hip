@@ -57,7 +57,7 @@ struct limo_ba_batch : Executor {
     double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
     uint8_t* d_lm_state0 = nullptr;
     int32_t* h_active = nullptr;  // pinned
-    int max_nc = 0, max_ld_bytes = 0;
+    int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0;
     int rc = LIMO_OK;
     // kernel timing (linearize) via HIP events on the batch's stream
     std::vector<EventPair> ev_pool;
@@ -118,12 +118,22 @@ struct limo_ba_batch : Executor {
         HIP_TRY(ctx, hipMemcpyAsync(d_lm_state0, P.lm_state.data(), P.lm_state.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipHostMalloc((void**)&h_active, 64));
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
-        int max_ncp = (max_nc + 15) / 16 * 16;
-        max_ld_bytes = (3 * kSchurLm * schur_ld(std::max(16, max_ncp)) + 3 * kSchurLm) * (int)sizeof(double);
+        int max_nfp = 16;
+        for (const WinDesc& d : P.win) max_nfp = std::max(max_nfp, (int)d.nf_pad);
+        max_ld_bytes = schur_lds_doubles(max_nfp) * (int)sizeof(double);
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
-        const int cam_bytes = (max_nc * max_nc + 3 * max_nc) * (int)sizeof(double);
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, cam_bytes));
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, cam_bytes));
+        asm_bytes = cam_assemble_scratch(max_nc, kBlock) * (int)sizeof(double);
+        solve_bytes = cam_solve_scratch(max_nc, kBlock) * (int)sizeof(double);
+        int max_lm = 1;
+        for (const WinDesc& d : P.win) max_lm = std::max(max_lm, (int)d.n_lm);
+        trim_bytes = 2 * max_lm * (int)sizeof(double);
+        if (trim_bytes > 160 * 1024) {
+            ctx->err = "window has too many landmarks for the LDS-staged trimmer (max 10240)";
+            return LIMO_ERR_INVALID;
+        }
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, asm_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, solve_bytes));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trim_select, hipFuncAttributeMaxDynamicSharedMemorySize, trim_bytes));
         HIP_TRY(ctx, hipEventCreate(&ev_total_a));
         HIP_TRY(ctx, hipEventCreate(&ev_total_b));
         return reset_state();
@@ -184,7 +194,7 @@ struct limo_ba_batch : Executor {
             LAUNCH_CHECK("k_lm_accum");
         }
         note(hipMemsetAsync(bv.n_active, 0, sizeof(int32_t), s), "memset n_active");
-        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), sizeof(double) * max_nc * max_nc, s, bv, c);
+        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), asm_bytes, s, bv, c);
         LAUNCH_CHECK("k_cam_assemble");
     }
 
@@ -210,7 +220,7 @@ struct limo_ba_batch : Executor {
             hipLaunchKernelGGL(k_schur, dim3(P.n_sblk), dim3(kBlock), max_ld_bytes, s, bv);
             LAUNCH_CHECK("k_schur");
         }
-        hipLaunchKernelGGL(k_cam_solve, dim3(P.n_win), dim3(kBlock), sizeof(double) * (max_nc * max_nc + 3 * max_nc), s, bv, c);
+        hipLaunchKernelGGL(k_cam_solve, dim3(P.n_win), dim3(kBlock), solve_bytes, s, bv, c);
         LAUNCH_CHECK("k_cam_solve");
         if (P.n_lblk) {
             hipLaunchKernelGGL(k_backsub, dim3(P.n_lblk), dim3(kBlock), 0, s, bv);
@@ -224,7 +234,7 @@ struct limo_ba_batch : Executor {
             hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 1);
             LAUNCH_CHECK("k_gp(cand)");
         }
-        hipLaunchKernelGGL(k_step_decide, dim3(cdiv(P.n_win, 64)), dim3(64), 0, s, bv, c);
+        hipLaunchKernelGGL(k_step_decide, dim3(P.n_win), dim3(64), 0, s, bv, c);
         LAUNCH_CHECK("k_step_decide");
         hipLaunchKernelGGL(k_accept, dim3(cdiv((int64_t)P.TK + P.TL, 256)), dim3(256), 0, s, bv);
         LAUNCH_CHECK("k_accept");
@@ -244,7 +254,7 @@ struct limo_ba_batch : Executor {
                                (const double*)d_plane_dep);
             LAUNCH_CHECK("k_trim_max");
         }
-        hipLaunchKernelGGL(k_trim_select, dim3(P.n_win), dim3(kBlock), 0, s, bv, c);
+        hipLaunchKernelGGL(k_trim_select, dim3(P.n_win), dim3(kBlock), trim_bytes, s, bv, c);
         LAUNCH_CHECK("k_trim_select");
     }
 
@@ -430,6 +440,7 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
             r.n_repr_blocks = d.n_repr;
             r.n_gp_blocks = d.n_gp;
             r.n_trimmed_landmarks = s.n_trimmed;
+            r.num_linearizations = s.acc_lin;
             r.initial_cost = s.first_initial_cost;
             r.final_cost = s.solve_final_cost;
             r.time_sec = b->last_solve_sec;

@@ -217,6 +217,7 @@ void print_summary(const SolverSummary& s) {
 struct TrimResult {
     std::vector<SolverSummary> summaries;
     int n_trimmed = 0;
+    int extra_solves = 0, extra_iterations = 0, extra_successful = 0, extra_lin = 0;
 };
 
 // solveTrimmed, robust_solving.cpp:140-248.  trust_region_relaxation_factor is -10 on this path
@@ -233,6 +234,10 @@ TrimResult solve_trimmed(const std::vector<int>& number_iterations,
         Solve(options, &problem, &cur);
         double cost_change = cur.initial_cost - cur.final_cost;
         if (cost_change <= 0.) {
+            R.extra_solves += 1;  // the discarded first attempt still ran (reported in num_solves / iterations)
+            R.extra_iterations += std::max(0, (int)cur.iterations.size() - 1);
+            R.extra_successful += std::max(0, cur.num_successful_steps - 1);
+            R.extra_lin += cur.num_successful_steps;
             options.max_num_iterations = 3 * num_outlier_iter;
             Solve(options, &problem, &cur);
         }
@@ -288,10 +293,14 @@ void fill_report(const TrimResult& R, const Built& B, limo_ba_report* rep, doubl
     if (rep) {
         std::memset(rep, 0, sizeof(*rep));
         rep->termination = (int)R.summaries.back().termination;
-        rep->num_solves = (int)R.summaries.size();
+        rep->num_solves = (int)R.summaries.size() + R.extra_solves;
+        rep->iterations_total = R.extra_iterations;
+        rep->successful_steps = R.extra_successful;
+        rep->num_linearizations = R.extra_lin;
         for (const auto& s : R.summaries) {
             rep->iterations_total += std::max(0, (int)s.iterations.size() - 1);
             rep->successful_steps += std::max(0, s.num_successful_steps - 1);
+            rep->num_linearizations += s.num_successful_steps;
         }
         rep->iterations_final = std::max(0, (int)R.summaries.back().iterations.size() - 1);
         rep->n_depth_blocks = B.n_depth;

@@ -93,7 +93,7 @@ struct EmuBatch : Executor {
             bv.lblk_part[(int64_t)b * 8 + 1] = xn2;
         }
         // camera assemble + LM decision
-        std::vector<double> H((size_t)kMaxNc * kMaxNc);
+        std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1));
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active || !bv.st[w].need_lin) continue;
             cam_assemble(bv, c, w, 0, 1, H.data());
@@ -127,8 +127,14 @@ struct EmuBatch : Executor {
             const int w = bv.sblk_win[sb];
             if (!bv.st[w].active) continue;
             const WinDesc& wd = bv.win[w];
-            const int ncp = wd.nc_pad;
+            const int ncp = wd.nf_pad;
             const int slab = ncp * ncp + ncp;
+            std::vector<int> cs(wd.nc);
+            std::vector<double> scw(wd.nc);
+            for (int i = 0; i < wd.nc; ++i) {
+                cs[i] = bv.cslot[wd.cam0 + i];
+                scw[i] = bv.scale_c[wd.cam0 + i];
+            }
             double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
             for (int i = 0; i < slab; ++i) out[i] = 0.0;
             for (int l0 = 0; l0 < bv.sblk_n[sb]; l0 += kSchurLm) {
@@ -138,26 +144,30 @@ struct EmuBatch : Executor {
                 for (int li = 0; li < nl; ++li) {
                     const int gl = bv.sblk_lm0[sb] + l0 + li;
                     if (bv.lm_state[gl] != 1) continue;
-                    for (int j = 0; j < wd.n_view; ++j) schur_fill_view(bv, wd, gl, li, j, Z.data(), ncp);
-                    schur_fill_gp(bv, wd, gl, li, Z.data(), ncp);
+                    double lmk[9];
+                    schur_load_lm(bv, gl, lmk);
+                    for (int j = 0; j < wd.n_view; ++j)
+                        schur_fill_view(bv, gl, li, j, bv.view_kf[wd.view0 + j] - wd.kf0, lmk, cs.data(), scw.data(), Z.data(), ncp);
+                    const int gg = bv.lm_gp[gl];
+                    if (gg >= 0) schur_fill_gp(bv, gg, li, bv.gp_kf[gg] - wd.kf0, lmk, cs.data(), scw.data(), Z.data(), ncp);
                     for (int cc = 0; cc < 3; ++cc) tt[3 * li + cc] = bv.lm_t[cc * bv.SL + gl];
                 }
                 for (int k = 0; k < 3 * nl; ++k) {
                     const double* zr = Z.data() + (size_t)k * ncp;
-                    for (int a = 0; a < wd.nc; ++a) {
+                    for (int a = 0; a < wd.nf; ++a) {
                         if (zr[a] == 0.0) continue;
-                        for (int bcol = 0; bcol < wd.nc; ++bcol) out[a * ncp + bcol] += zr[a] * zr[bcol];
+                        for (int bcol = 0; bcol < wd.nf; ++bcol) out[a * ncp + bcol] += zr[a] * zr[bcol];
                         out[ncp * ncp + a] += zr[a] * tt[k];
                     }
                 }
             }
         }
         // camera solve
-        std::vector<double> S((size_t)kMaxNc * kMaxNc), v(3 * kMaxNc);
+        std::vector<double> S((size_t)cam_solve_scratch(kMaxNc, 1));
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active) continue;
             int flag = 0;
-            cam_solve(bv, c, w, 0, 1, S.data(), v.data(), &flag);
+            cam_solve(bv, c, w, 0, 1, S.data(), &flag);
         }
         // back-substitution
         for (int b = 0; b < bv.n_lblk; ++b) {
@@ -195,7 +205,8 @@ struct EmuBatch : Executor {
             if (!bv.st[w].active) continue;
             const WinDesc& wd = bv.win[w];
             for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(bv, g, true, bv.gp_cost_c);
-            reduce_step(bv, w, bv.blk_cost_c, bv.blk_fail_c, bv.gp_cost_c);
+            double red1[1];
+            reduce_step(bv, w, 0, 1, red1);
             lm_decide_step(bv.st[w], bv.red[w], c);
         }
         // accept: candidate -> current
@@ -246,6 +257,7 @@ void fill_report(const EmuBatch& B, int w, limo_ba_report* r) {
     r->n_repr_blocks = d.n_repr;
     r->n_gp_blocks = d.n_gp;
     r->n_trimmed_landmarks = s.n_trimmed;
+    r->num_linearizations = s.acc_lin;
     r->initial_cost = s.first_initial_cost;
     r->final_cost = s.solve_final_cost;
 }

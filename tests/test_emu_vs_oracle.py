@@ -1,0 +1,180 @@
+"""CPU-tier tests of the product's HOST logic and KERNEL ARITHMETIC: the serial emulation (tests/cpp/emu_pipeline.cpp)
+executes the same packing, LM state machine and per-lane statements as the gfx950 kernels and must agree with the
+oracle (an independent dual-number / block-sparse implementation) on the same bytes."""
+import numpy as np
+import pytest
+
+from limo_amd import _ffi, default_options, synth
+
+TOL = 1e-4
+
+
+def rel_pose_err(a, b):
+    return np.abs(a[:, 4:] - b[:, 4:]).max() / max(1e-12, np.abs(b[:, 4:]).max())
+
+
+@pytest.mark.parametrize("apply_loss", [False, True])
+def test_analytic_jacobians_match_dual_numbers(oracle, emu, apply_loss):
+    w = synth.make_window(31, n_kf=5, n_lm=400)
+    o = default_options()
+    c0, r0, jp0, jl0, v0 = oracle.evaluate(w, o, apply_loss)
+    c1, r1, jp1, jl1, v1 = emu.evaluate(w, o, apply_loss)
+    assert np.array_equal(v0, v1)
+    assert abs(c0 - c1) <= 1e-12 * abs(c0)
+    assert np.abs(r0 - r1).max() <= 1e-9 * max(1.0, np.abs(r0).max())
+    assert np.abs(jp0 - jp1).max() <= 1e-10 * np.abs(jp0).max()
+    assert np.abs(jl0 - jl1).max() <= 1e-10 * np.abs(jl0).max()
+
+
+CASES = [
+    dict(seed=1, n_kf=3, n_lm=200, depth_prob=0.0, ground_frac=0.0, with_ground_plane=False),  # C1
+    dict(seed=41, n_kf=3, n_lm=80),  # below the trimming threshold (<= 100 landmarks)
+    dict(seed=42, n_kf=4, n_lm=300),
+    dict(seed=43, n_kf=6, n_lm=350, depth_prob=0.02),  # < 10 depth blocks per ... exercises plane-distance fixing
+    dict(seed=44, n_kf=5, n_lm=250, ground_frac=0.0),  # depth but no ground landmarks
+    dict(seed=45, n_kf=12, n_lm=200),  # largest supported window
+    dict(seed=909, n_kf=5, n_lm=2000),  # first solve FAILS at x0 (a reprojection block with |z| < 0.01), trimming removes it
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "kf%d_lm%d_s%d" % (c["n_kf"], c["n_lm"], c["seed"]))
+def test_solve_matches_oracle(oracle, emu, case):
+    kw = dict(case)
+    w = synth.make_window(kw.pop("seed"), **kw)
+    o = default_options()
+    we, wo = w.copy(), w.copy()
+    re_ = emu.solve_batch([we], o)[0]
+    ro, _ = oracle.solve(wo, o)
+    for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks", "num_solves"):
+        assert re_[k] == ro[k], k
+    assert abs(re_["initial_cost"] - ro["initial_cost"]) <= 1e-10 * abs(ro["initial_cost"])
+    assert abs(re_["final_cost"] - ro["final_cost"]) <= TOL * abs(ro["final_cost"])
+    assert rel_pose_err(we.kf_pose, wo.kf_pose) <= TOL
+    assert np.abs(we.kf_plane_dist - wo.kf_plane_dist).max() <= 1e-4
+    assert np.array_equal(we.kf_pose[0], w.kf_pose[0])  # FixationStatus::Pose keyframe untouched
+    assert np.allclose(np.linalg.norm(we.kf_pose[:, :4], axis=1), 1.0, atol=1e-12)
+    assert np.allclose(np.linalg.norm(we.kf_plane_dir, axis=1), 1.0, atol=1e-12)
+
+
+def test_trimming_removes_the_same_landmarks(oracle, emu):
+    """Landmarks removed by trimming keep their last value (Ceres leaves removed blocks untouched), and both
+    implementations remove the same set: compare which landmarks moved after the trimming round."""
+    w = synth.make_window(51, n_kf=5, n_lm=400)
+    o = default_options(max_num_iterations=0)  # final solve does no iteration: landmarks only move in the 2 trim iterations
+    we, wo = w.copy(), w.copy()
+    re_ = emu.solve_batch([we], o)[0]
+    ro, _ = oracle.solve(wo, o)
+    assert re_["n_trimmed_landmarks"] == ro["n_trimmed_landmarks"] > 0
+    assert np.allclose(we.lm_pos, wo.lm_pos, rtol=0, atol=1e-7)
+
+
+def test_batch_is_independent_of_batch_composition(emu):
+    ws = [synth.make_window(60 + i, n_kf=3 + i % 3, n_lm=120 + 60 * i) for i in range(4)]
+    o = default_options()
+    single = []
+    for w in ws:
+        c = w.copy()
+        emu.solve_batch([c], o)
+        single.append(c)
+    batch = [w.copy() for w in ws]
+    emu.solve_batch(batch, o)
+    for a, b in zip(single, batch):
+        assert np.array_equal(a.kf_pose, b.kf_pose) and np.array_equal(a.lm_pos, b.lm_pos)
+
+
+def make_pose_only_case(seed):
+    """New frame against fixed landmarks (adjustPoseOnly): take a solved-ish window, use the newest keyframe as the
+    frame to adjust with a perturbed prior, all landmarks at their ground-truth positions."""
+    w = synth.make_window(seed, n_kf=4, n_lm=300, outlier_frac=0.02)
+    k = w.n_kf - 1
+    sel = w.obs_kf == k
+    from limo_amd.window import Window
+
+    pw = Window(
+        kf_pose=w.kf_pose[k : k + 1].copy(),
+        kf_plane_dir=w.kf_plane_dir[k : k + 1],
+        kf_plane_dist=w.kf_plane_dist[k : k + 1],
+        kf_fixation=np.array([_ffi.LIMO_FIX_NONE], np.int32),
+        cam=w.cam,
+        lm_pos=w.meta["gt_lm"].copy(),
+        lm_weight=w.lm_weight,
+        lm_is_ground=w.lm_is_ground,
+        obs_kf=np.zeros(sel.sum(), np.int32),
+        obs_lm=w.obs_lm[sel],
+        obs_cam=w.obs_cam[sel],
+        obs_u=w.obs_u[sel],
+        obs_v=w.obs_v[sel],
+        obs_d=w.obs_d[sel],
+    )
+    gt = w.meta["gt_pose"][k]
+    prior = _ffi.SpeedPrior()
+    prior.speed_weight = 0.7
+    prior.dt_cur = 0.4
+    pb = w.meta["gt_pose"][k - 1]
+    prior.pose_before[:] = pb.tolist()
+    # velocity of the previous step expressed as the reference does: translation(pose_before * pose_before2^-1)/dt
+    from limo_amd.synth import pose_to_Rt
+
+    Rb, tb = pose_to_Rt(pb)
+    Rbb, tbb = pose_to_Rt(w.meta["gt_pose"][k - 2])
+    v = (tb - Rb @ Rbb.T @ tbb) / 0.4
+    prior.vel_prev[:] = v.tolist()
+    return pw, prior, gt
+
+
+@pytest.mark.parametrize("with_prior", [False, True])
+def test_pose_only_matches_oracle(oracle, emu, with_prior):
+    pw, prior, gt = make_pose_only_case(71)
+    o = default_options(min_landmarks_for_trimming=30)  # adjustPoseOnly trims when selected > 30 (:865)
+    pe, po = pw.copy(), pw.copy()
+    re_ = emu.solve_batch([pe], o, pose_only=True, prior=prior if with_prior else None)[0]
+    ro = oracle.adjust_pose_only(po, prior if with_prior else None, o)
+    assert re_["n_trimmed_landmarks"] == ro["n_trimmed_landmarks"]
+    assert abs(re_["final_cost"] - ro["final_cost"]) <= TOL * abs(ro["final_cost"])
+    assert np.abs(pe.kf_pose - po.kf_pose).max() <= 1e-6
+    assert np.abs(pe.kf_pose[0, 4:] - gt[4:]).max() < 0.05  # pulled back to the true pose
+    assert np.array_equal(pe.lm_pos, pw.lm_pos)  # landmarks are constant in motion-only adjustment
+
+
+def test_not_enough_keyframes_and_bad_input(emu):
+    import ctypes as C
+
+    from limo_amd.window import struct_array
+
+    lib = emu.load()
+    w = synth.make_window(5, n_kf=2, n_lm=50)
+    arr = struct_array([w])
+    o = default_options()
+    assert lib.emu_ba_solve_batch(1, arr, C.byref(o), None, 0, None) == _ffi.LIMO_ERR_NOT_ENOUGH_KF
+    w3 = synth.make_window(5, n_kf=3, n_lm=50)
+    w3.obs_lm[0] = 10**6  # index out of range must be rejected, not read
+    arr = struct_array([w3])
+    assert lib.emu_ba_solve_batch(1, arr, C.byref(o), None, 0, None) == _ffi.LIMO_ERR_INVALID
+
+
+def test_empty_and_ragged_windows(oracle, emu):
+    """A window without observations / with unobserved landmarks must not crash and must leave parameters alone."""
+    w = synth.make_window(81, n_kf=3, n_lm=30)
+    from limo_amd.window import Window
+
+    # no observations at all: only ground-plane rows of the ground landmarks + regularisers remain (the reference
+    # builds those regardless of measurements, bundle_adjuster_keyframes.cpp:517-562) -> compare with the oracle
+    empty = Window(**{n: getattr(w, n)[:0] if n.startswith("obs_") else getattr(w, n) for n, _ in Window.FIELDS})
+    ee, eo = empty.copy(), empty.copy()
+    rep = emu.solve_batch([ee], default_options())[0]
+    ro, _ = oracle.solve(eo, default_options())
+    assert rep["n_repr_blocks"] == 0 and rep["n_gp_blocks"] == ro["n_gp_blocks"]
+    assert abs(rep["final_cost"] - ro["final_cost"]) <= 1e-6 * max(1e-12, abs(ro["final_cost"])) + 1e-12
+    # no landmarks either: the only block is the scale regulariser with zero residual -> nothing moves
+    bare = Window(**{n: (getattr(w, n)[:0] if (n.startswith("obs_") or n.startswith("lm_")) else getattr(w, n)) for n, _ in Window.FIELDS})
+    before = bare.kf_pose.copy()
+    rep = emu.solve_batch([bare], default_options())[0]
+    assert np.array_equal(bare.kf_pose, before) and rep["termination"] == _ffi.LIMO_CONVERGENCE
+    # drop all observations of one landmark: it is not part of the problem and keeps its value
+    keep = w.obs_lm != 3
+    rag = Window(**{n: getattr(w, n)[keep] if n.startswith("obs_") else getattr(w, n) for n, _ in Window.FIELDS})
+    re_, ro = rag.copy(), rag.copy()
+    emu.solve_batch([re_], default_options())
+    oracle.solve(ro, default_options())
+    assert np.array_equal(re_.lm_pos[3], rag.lm_pos[3])
+    assert rel_pose_err(re_.kf_pose, ro.kf_pose) <= TOL
