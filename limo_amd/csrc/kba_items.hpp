@@ -594,11 +594,14 @@ KBA_HD double coop_max(double v, int tid, int nt, double* red) {
 }
 
 // scratch doubles needed by cam_assemble / cam_solve for a system of nc slots and nt lanes
+constexpr int kGpChunk = 128;  // ground-plane rows staged in LDS per pass of cam_assemble
 KBA_HD int cam_assemble_scratch(int nc, int nt) {
-    return nc * nc + nt + (int)((sizeof(RegRow) * kMaxRegRows + 7) / 8);
+    const int rows = (int)((sizeof(RegRow) * kMaxRegRows + 7) / 8);
+    const int gp = kGpChunk * 12;
+    return nc * nc + 6 * nt + (rows > gp ? rows : gp);
 }
 KBA_HD int cam_solve_scratch(int nc, int nt) {
-    return nc * nc + 3 * nc + nt;
+    return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + nt;  // A | y | dl | fl | red, sized for nf == nc
 }
 
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
@@ -609,7 +612,8 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     const int nc = wd.nc;
     double* H = scratch;
     double* red = scratch + nc * nc;
-    RegRow* rows = reinterpret_cast<RegRow*>(red + nt);
+    RegRow* rows = reinterpret_cast<RegRow*>(red + 6 * nt);
+    double* gps = red + 6 * nt;  // ground-plane staging, reused by the regulariser rows afterwards
     double* gc = bv.gc + (int64_t)wd.cam0;
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
@@ -635,20 +639,37 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
     }
     KBA_SYNC();
-    // (2) ground-plane rows (sorted by keyframe: kf_gp0/kf_ngp): F^T F on the 10x10 block of their keyframe
-    for (int e = tid; e < wd.n_kf * 110; e += nt) {
-        const int kl = e / 110, q = e % 110;
-        const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : -1;
-        const int g0 = bv.kf_gp0[wd.kf0 + kl], ng = bv.kf_ngp[wd.kf0 + kl];
-        double acc = 0.0;
-        for (int g = g0; g < g0 + ng; ++g) {
-            const double fa = bv.gp_F[a * bv.SG + g];
-            acc += fa * (bb >= 0 ? bv.gp_F[bb * bv.SG + g] : bv.gp_r[g]);
+    // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe.  Rows are staged through LDS in chunks
+    //     (coalesced plane reads), then one lane per (keyframe, entry) adds the rows of ITS keyframe in row order.
+    for (int g0 = wd.gp0; g0 < wd.gp0 + wd.n_gp; g0 += kGpChunk) {
+        const int ng = (wd.gp0 + wd.n_gp - g0) < kGpChunk ? (wd.gp0 + wd.n_gp - g0) : kGpChunk;
+        for (int i = tid; i < ng * 12; i += nt) {
+            const int q = i / ng, g = g0 + i % ng;  // q-major: consecutive lanes read consecutive rows of a plane
+            double v;
+            if (q < 10)
+                v = bv.gp_F[q * bv.SG + g];
+            else if (q == 10)
+                v = bv.gp_r[g];
+            else
+                v = (double)(bv.gp_kf[g] - wd.kf0);
+            gps[(i % ng) * 12 + q] = v;
         }
-        if (bb >= 0)
-            H[(kl * kCamSlots + a) * nc + kl * kCamSlots + bb] += acc;
-        else
-            gc[kl * kCamSlots + a] += acc;
+        KBA_SYNC();
+        for (int e = tid; e < wd.n_kf * 110; e += nt) {
+            const int kl = e / 110, q = e % 110;
+            const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : 10;
+            // rows are sorted by keyframe: this keyframe owns [kf_gp0, kf_gp0 + kf_ngp), clipped to the chunk
+            int lo = bv.kf_gp0[wd.kf0 + kl] - g0, hi = lo + bv.kf_ngp[wd.kf0 + kl];
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > ng ? ng : hi;
+            double acc = 0.0;
+            for (int g = lo; g < hi; ++g) acc += gps[g * 12 + a] * gps[g * 12 + bb];
+            if (bb < 10)
+                H[(kl * kCamSlots + a) * nc + kl * kCamSlots + bb] += acc;
+            else
+                gc[kl * kCamSlots + a] += acc;
+        }
+        KBA_SYNC();
     }
     // (3) regulariser rows: one lane evaluates one row into scratch ...
     const int nrows = reg_row_count(wd);
@@ -718,12 +739,28 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
             xn2 += bv.pdist[gk] * bv.pdist[gk];
         }
     }
-    reg_free = coop_sum(reg_free, tid, nt, red);
-    reg_fixed = coop_sum(reg_fixed, tid, nt, red);
-    cost = coop_sum(cost, tid, nt, red) + reg_free;
-    failf = coop_max(failf, tid, nt, red);
-    gmax = coop_max(gmax, tid, nt, red);
-    xn2 = coop_sum(xn2, tid, nt, red);
+    {   // six reductions folded in one tree (4 sums, 2 maxima); red holds 6*nt doubles
+        red[0 * nt + tid] = reg_free;
+        red[1 * nt + tid] = reg_fixed;
+        red[2 * nt + tid] = cost;
+        red[3 * nt + tid] = xn2;
+        red[4 * nt + tid] = failf;
+        red[5 * nt + tid] = gmax;
+        KBA_SYNC();
+        for (int s = nt >> 1; s > 0; s >>= 1) {
+            if (tid < s) {
+                for (int q = 0; q < 4; ++q) red[q * nt + tid] += red[q * nt + tid + s];
+                for (int q = 4; q < 6; ++q) red[q * nt + tid] = fmax(red[q * nt + tid], red[q * nt + tid + s]);
+            }
+            KBA_SYNC();
+        }
+        reg_free = red[0];
+        reg_fixed = red[1 * nt];
+        cost = red[2 * nt] + reg_free;
+        xn2 = red[3 * nt];
+        failf = red[4 * nt];
+        gmax = red[5 * nt];
+    }
     if (tid == 0) {
         WinRed& r = bv.red[w];
         r.lin_cost = cost;
@@ -738,64 +775,80 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
 // Workgroup-per-window: S = S_c H S_c + D^2 - sum Schur slabs, rhs = S_c g_c - sum slabs; dense Cholesky; camera
 // step, camera candidate, camera parts of the step reductions.  scratch: S (nc*nc) | v (3*nc) | red (nt).
 KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* scratch, int* flag) {
+    // Works on the COMPACT system of the nf free slots.  scratch: A (nf x (nf+1), the rhs is column nf) | y (nf) |
+    // dl (nc) | fl (nf ints) | red (nt).
     const WinDesc& wd = bv.win[w];
-    const int nc = wd.nc, nfp = wd.nf_pad;
-    double* S = scratch;
-    double* rhs = scratch + nc * nc;
-    double* red = rhs + 3 * nc;
-    const int32_t* cs = bv.cslot + wd.cam0;
+    const int nc = wd.nc, nf = wd.nf, nfp = wd.nf_pad, lda = nf + 1;
+    double* A = scratch;
+    double* y = A + nf * lda;
+    double* dl = y + nf;
+    int* fl = reinterpret_cast<int*>(dl + nc);
+    double* red = dl + nc + (nf + 1) / 2 + 1;
     const double radius = bv.st[w].radius;
     const double* Hg = bv.Hcc + wd.hcc_off;
     const double* sc = bv.scale_c + wd.cam0;
-    const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
+    const int32_t* cs = bv.cslot + wd.cam0;
     double* yc = bv.yc + wd.cam0;
     double* dc = bv.delta_c + wd.cam0;
     const int slab = nfp * nfp + nfp;
-    if (tid == 0) *flag = 0;
-    for (int i = tid; i < nc * nc; i += nt) {
-        const int a = i / nc, b = i % nc;
+    (void)flag;
+    for (int a = tid; a < nc; a += nt)
+        if (cs[a] >= 0) fl[cs[a]] = a;
+    KBA_SYNC();
+    // ---- assemble [S | rhs]: S = S_c H S_c + D^2 - sum slabs (upper triangle), rhs = S_c g_c - sum slabs
+    const double* sp = bv.S_part + wd.spart_off;
+    for (int i = tid; i < nf * lda; i += nt) {
+        const int ca = i / lda, cb = i % lda;
+        if (cb < ca) continue;  // lower triangle unused
+        const int a = fl[ca];
         double s;
-        if (cm[a] && cm[b]) {
-            s = sc[a] * sc[b] * Hg[i];
-            if (a == b) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-            const int ca = cs[a], cb = cs[b];
-            for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + ca * nfp + cb];
+        int64_t off;
+        if (cb < nf) {
+            const int b = fl[cb];
+            s = sc[a] * sc[b] * Hg[a * nc + b];
+            if (ca == cb) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+            off = (int64_t)ca * nfp + cb;
         } else {
-            s = (a == b) ? 1.0 : 0.0;
-        }
-        S[i] = s;
-    }
-    for (int a = tid; a < nc; a += nt) {
-        double s = 0.0;
-        if (cm[a]) {
             s = sc[a] * bv.gc[wd.cam0 + a];
-            for (int q = 0; q < wd.n_sblk; ++q) s -= bv.S_part[wd.spart_off + (int64_t)q * slab + nfp * nfp + cs[a]];
+            off = (int64_t)nfp * nfp + ca;
         }
-        rhs[a] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= wd.n_sblk; q += 4) {  // independent loads in flight
+            s0 += sp[(int64_t)q * slab + off];
+            s1 += sp[(int64_t)(q + 1) * slab + off];
+            s2 += sp[(int64_t)(q + 2) * slab + off];
+            s3 += sp[(int64_t)(q + 3) * slab + off];
+        }
+        for (; q < wd.n_sblk; ++q) s0 += sp[(int64_t)q * slab + off];
+        A[i] = s - ((s0 + s1) + (s2 + s3));
     }
     KBA_SYNC();
-    // right-looking Cholesky on the upper triangle: S = U^T U (Eigen LLT<Upper> semantics: fail when pivot <= 0)
-    for (int k = 0; k < nc; ++k) {
-        if (tid == 0) {
-            const double d = S[k * nc + k];
-            if (!(d > 0.0))
-                *flag = 1;
-            else
-                S[k * nc + k] = sqrt(d);
+    if (c.pad == 1) return;
+    // ---- right-looking Cholesky of the upper triangle fused with the forward substitution (rhs = extra column):
+    //      A = U^T U, y = U^-T rhs.  One barrier per pivot: row k is rescaled while step k+1 updates rows > k.
+    //      Eigen LLT<Upper> semantics: failure when a pivot is <= 0.
+    bool failed = false;
+    const int tw = nt >= 16 ? 16 : 1, th = nt / tw, tx = tid % tw, ty = tid / tw;
+    for (int k = 0; k < nf; ++k) {
+        const double d = A[k * lda + k];
+        if (!(d > 0.0)) {
+            failed = true;  // uniform: every lane reads the same pivot
+            break;
+        }
+        const double inv_d = 1.0 / d;
+        for (int i = k + 1 + ty; i < nf; i += th) {  // 2-D lane grid: no integer division in the inner loop
+            const double aki = A[k * lda + i] * inv_d;
+            for (int j = i + tx; j <= nf; j += tw) A[i * lda + j] -= aki * A[k * lda + j];
+        }
+        if (k > 0) {  // finish row k-1: U[k-1][j] = A[k-1][j] / sqrt(d_{k-1})
+            const double dp = sqrt(A[(k - 1) * lda + (k - 1)]);
+            for (int j = k + tid; j <= nf; j += nt) A[(k - 1) * lda + j] /= dp;
         }
         KBA_SYNC();
-        if (*flag) break;
-        const double dk = S[k * nc + k];
-        for (int j = k + 1 + tid; j < nc; j += nt) S[k * nc + j] /= dk;
-        KBA_SYNC();
-        const int m = nc - k - 1;
-        for (int e = tid; e < m * m; e += nt) {
-            const int i = k + 1 + e / m, j = k + 1 + e % m;
-            if (j >= i) S[i * nc + j] -= S[k * nc + i] * S[k * nc + j];
-        }
-        KBA_SYNC();
+        if (k > 0 && tid == 0) A[(k - 1) * lda + (k - 1)] = sqrt(A[(k - 1) * lda + (k - 1)]);
     }
-    if (*flag) {
+    if (failed) {
         if (tid == 0) {
             WinRed& r = bv.red[w];
             r.chol_fail = 1;
@@ -806,36 +859,44 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         for (int a = tid; a < nc; a += nt) dc[a] = 0.0;
         return;
     }
-    // triangular solves, column oriented:  U^T y = rhs  then  U x = y
-    for (int i = 0; i < nc; ++i) {
-        if (tid == 0) rhs[i] = rhs[i] / S[i * nc + i];
-        KBA_SYNC();
-        const double xi = rhs[i];
-        for (int j = i + 1 + tid; j < nc; j += nt) rhs[j] -= S[i * nc + j] * xi;
-        KBA_SYNC();
-    }
-    for (int i = nc - 1; i >= 0; --i) {
-        if (tid == 0) rhs[i] = rhs[i] / S[i * nc + i];
-        KBA_SYNC();
-        const double xi = rhs[i];
-        for (int j = tid; j < i; j += nt) rhs[j] -= S[j * nc + i] * xi;
-        KBA_SYNC();
-    }
-    for (int a = tid; a < nc; a += nt) {
-        yc[a] = rhs[a];
-        const double d = cm[a] ? -sc[a] * rhs[a] : 0.0;
-        dc[a] = d;
-        rhs[nc + a] = d;  // delta_c copy in scratch
+    if (nf > 0) {  // last row
+        const double dp = sqrt(A[(nf - 1) * lda + (nf - 1)]);
+        if (tid == 0) {
+            A[(nf - 1) * lda + nf] /= dp;
+            A[(nf - 1) * lda + (nf - 1)] = dp;
+        }
     }
     KBA_SYNC();
-    const double* dl = rhs + nc;
+    if (c.pad == 2) return;
+    // ---- backward substitution U x = y (y = column nf), column oriented, one barrier per unknown
+    for (int i = tid; i < nf; i += nt) y[i] = A[i * lda + nf];
+    KBA_SYNC();
+    for (int i = nf - 1; i >= 0; --i) {
+        const double xi = y[i] / A[i * lda + i];
+        for (int j = tid; j < i; j += nt) y[j] -= A[j * lda + i] * xi;
+        KBA_SYNC();
+        if (tid == 0) y[i] = xi;
+    }
+    KBA_SYNC();
+    if (c.pad == 3) return;
+    for (int a = tid; a < nc; a += nt) {
+        const int ca = cs[a];
+        const double yv = ca >= 0 ? y[ca] : 0.0;
+        yc[a] = yv;
+        const double d = ca >= 0 ? -sc[a] * yv : 0.0;
+        dc[a] = d;
+        dl[a] = d;
+    }
+    KBA_SYNC();
     // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled)
     double part = 0.0;
     for (int a = tid; a < nc; a += nt) {
+        if (cs[a] < 0) continue;
         double hd = 0.0;
         for (int b = 0; b < nc; ++b) hd += Hg[a * nc + b] * dl[b];
         part += -bv.gc[wd.cam0 + a] * dl[a] - 0.5 * dl[a] * hd;
     }
+    const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
     double step2 = 0.0, cand2 = 0.0;
     for (int k = tid; k < wd.n_kf; k += nt) {
         const int gk = wd.kf0 + k;
@@ -881,6 +942,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         r.cand2 = cand2;
     }
 }
+
 
 // After backsub + candidate cost kernels: fold the landmark / observation partials into WinRed (workgroup, red[nt]).
 KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red) {

@@ -346,26 +346,86 @@ __global__ void k_trim_max(BatchView bv, const double* plane_rep, const double* 
     trim_max_lane(bv, gl, plane_rep, plane_dep);
 }
 
+// Quantile selection per window and list: bitonic sort of (value, id) in LDS, outliers = sorted positions
+// >= int(n_groups * quantile) (TrimmerQuantile::getOutliers; std::nth_element ties resolved by id).  Falls back to
+// the O(n^2) rank count (same result) when the padded list does not fit in LDS.
+constexpr int kTrimMaxSort = 8192;
+
+__device__ __forceinline__ bool trim_less(double ka, int ia, double kb, int ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
 __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConsts c) {
     const int w = blockIdx.x;
     const WinDesc& wd = bv.win[w];
     if (!wd.do_trim) return;
-    // stage both value lists in LDS (the rank count re-reads every value n_lm times)
+    const int n = wd.n_lm;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* vdep = smem;
-    double* vrep = smem + wd.n_lm;
-    for (int l = threadIdx.x; l < wd.n_lm; l += blockDim.x) {
-        vdep[l] = bv.trim_dep[wd.lm0 + l];
-        vrep[l] = bv.trim_rep[wd.lm0 + l];
-    }
-    __syncthreads();
+    __shared__ int n_valid;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
     int removed = 0;
-    for (int l = threadIdx.x; l < wd.n_lm; l += blockDim.x) {
-        const int out = trim_is_outlier(vdep, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
-                        trim_is_outlier(vrep, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
-        if (out && bv.lm_state[wd.lm0 + l]) {
-            bv.lm_state[wd.lm0 + l] = 0;
-            ++removed;
+    if (np2 <= kTrimMaxSort) {
+        double* keys = smem;                                   // [np2]
+        int* ids = reinterpret_cast<int*>(smem + np2);          // [np2]
+        unsigned char* flags = reinterpret_cast<unsigned char*>(ids + np2);  // [n]
+        for (int i = threadIdx.x; i < n; i += kBlock) flags[i] = 0;
+        for (int list = 0; list < 2; ++list) {
+            const double* vals = (list == 0 ? bv.trim_dep : bv.trim_rep) + wd.lm0;
+            const double q = list == 0 ? c.depth_quantile : c.reprojection_quantile;
+            if (threadIdx.x == 0) n_valid = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int i = threadIdx.x; i < np2; i += kBlock) {
+                double v = i < n ? vals[i] : -1.0;
+                const bool valid = v >= 0.0;  // also true for +inf (failed functor)
+                keys[i] = valid ? v : INFINITY;
+                ids[i] = valid ? i : (i | (1 << 30));  // invalid entries sort after every valid one
+                mine += valid;
+            }
+            if (mine) atomicAdd(&n_valid, mine);
+            __syncthreads();
+            for (int k = 2; k <= np2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = threadIdx.x; t < np2; t += kBlock) {
+                        const int p = t ^ j;
+                        if (p > t) {
+                            const double ka = keys[t], kb = keys[p];
+                            const int ia = ids[t], ib = ids[p];
+                            const bool up = (t & k) == 0;
+                            const bool swap = up ? trim_less(kb, ib, ka, ia) : trim_less(ka, ia, kb, ib);
+                            if (swap) {
+                                keys[t] = kb;
+                                keys[p] = ka;
+                                ids[t] = ib;
+                                ids[p] = ia;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            const int ng = n_valid;
+            if (ng >= c.min_groups) {
+                const int num = (int)((double)ng * q);
+                for (int p = num + threadIdx.x; p < ng; p += kBlock) flags[ids[p]] = 1;
+            }
+            __syncthreads();
+        }
+        for (int l = threadIdx.x; l < n; l += kBlock) {
+            if (flags[l] && bv.lm_state[wd.lm0 + l]) {
+                bv.lm_state[wd.lm0 + l] = 0;
+                ++removed;
+            }
+        }
+    } else {
+        for (int l = threadIdx.x; l < n; l += kBlock) {
+            const int out = trim_is_outlier(bv.trim_dep + wd.lm0, n, l, c.depth_quantile, c.min_groups) ||
+                            trim_is_outlier(bv.trim_rep + wd.lm0, n, l, c.reprojection_quantile, c.min_groups);
+            if (out && bv.lm_state[wd.lm0 + l]) {
+                bv.lm_state[wd.lm0 + l] = 0;
+                ++removed;
+            }
         }
     }
     if (removed) atomicAdd(&bv.st[w].n_trimmed, removed);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -37,6 +38,7 @@ SolveConsts make_consts(const limo_ba_options& o) {
     c.depth_quantile = o.depth_quantile;
     c.reprojection_quantile = o.reprojection_quantile;
     c.min_groups = o.minimum_number_residual_groups;
+    if (const char* e = std::getenv("KBA_DEBUG_STAGE")) c.pad = std::atoi(e);  // profiling aid only
     return c;
 }
 

@@ -56,7 +56,9 @@ struct limo_ba_batch : Executor {
     double *d_plane_rep = nullptr, *d_plane_dep = nullptr;
     double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
     uint8_t* d_lm_state0 = nullptr;
-    int32_t* h_active = nullptr;  // pinned
+    int32_t* h_active = nullptr;  // pinned, 4 slots
+    hipEvent_t act_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int it_no = 0;
     int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0;
     int rc = LIMO_OK;
     // kernel timing (linearize) via HIP events on the batch's stream
@@ -75,6 +77,8 @@ struct limo_ba_batch : Executor {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
         }
+        for (auto& e : act_ev)
+            if (e) (void)hipEventDestroy(e);
         if (ev_total_a) (void)hipEventDestroy(ev_total_a);
         if (ev_total_b) (void)hipEventDestroy(ev_total_b);
     }
@@ -126,14 +130,15 @@ struct limo_ba_batch : Executor {
         solve_bytes = cam_solve_scratch(max_nc, kBlock) * (int)sizeof(double);
         int max_lm = 1;
         for (const WinDesc& d : P.win) max_lm = std::max(max_lm, (int)d.n_lm);
-        trim_bytes = 2 * max_lm * (int)sizeof(double);
-        if (trim_bytes > 160 * 1024) {
-            ctx->err = "window has too many landmarks for the LDS-staged trimmer (max 10240)";
-            return LIMO_ERR_INVALID;
+        {
+            int np2 = 1;
+            while (np2 < max_lm) np2 <<= 1;
+            trim_bytes = np2 <= kTrimMaxSort ? np2 * 12 + max_lm + 16 : 16;
         }
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, asm_bytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_cam_solve, hipFuncAttributeMaxDynamicSharedMemorySize, solve_bytes));
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trim_select, hipFuncAttributeMaxDynamicSharedMemorySize, trim_bytes));
+        for (auto& e : act_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreate(&ev_total_a));
         HIP_TRY(ctx, hipEventCreate(&ev_total_b));
         return reset_state();
@@ -163,6 +168,7 @@ struct limo_ba_batch : Executor {
 
     // ---- Executor
     void solve_init(int max_iter, int select) override {
+        it_no = 0;
         hipLaunchKernelGGL(k_solve_init, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv, c, max_iter, select);
         LAUNCH_CHECK("k_solve_init");
     }
@@ -193,16 +199,26 @@ struct limo_ba_batch : Executor {
             hipLaunchKernelGGL(k_lm_accum, dim3(P.n_lblk), dim3(kBlock), 0, s, bv, c);
             LAUNCH_CHECK("k_lm_accum");
         }
-        note(hipMemsetAsync(bv.n_active, 0, sizeof(int32_t), s), "memset n_active");
-        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), asm_bytes, s, bv, c);
+        // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
+        const int slot = it_no & 3;
+        note(hipMemsetAsync(bv.n_active + slot, 0, sizeof(int32_t), s), "memset n_active");
+        BatchView bvs = bv;
+        bvs.n_active = bv.n_active + slot;
+        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), asm_bytes, s, bvs, c);
         LAUNCH_CHECK("k_cam_assemble");
+        note(hipMemcpyAsync(h_active + slot, bv.n_active + slot, sizeof(int32_t), hipMemcpyDeviceToHost, s), "memcpy n_active");
+        note(hipEventRecord(act_ev[slot], s), "record n_active");
     }
 
+    // Lagging by one iteration: the count of iteration i-1 is read while iteration i is already enqueued, so the
+    // host never drains the stream inside a solve.  The price is at most one extra iteration of no-op launches.
     int active_count() override {
         if (rc != LIMO_OK) return 0;
-        note(hipMemcpyAsync(h_active, bv.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream), "memcpy n_active");
-        note(hipStreamSynchronize(ctx->stream), "sync");
-        return rc == LIMO_OK ? *h_active : 0;
+        const int cur = it_no++;
+        if (cur == 0) return P.n_win;  // iteration zero: nothing to wait for yet
+        const int slot = (cur - 1) & 3;
+        note(hipEventSynchronize(act_ev[slot]), "sync n_active");
+        return rc == LIMO_OK ? h_active[slot] : 0;
     }
 
     void expire(int) override {
