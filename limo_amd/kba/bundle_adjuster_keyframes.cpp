@@ -1,0 +1,480 @@
+// bundle_adjuster_keyframes.cpp — host shim: the reference's window bookkeeping re-implemented on plain containers,
+// with the numerical work delegated to the C-ABI (include/limo_hip.h).
+// Behaviour followed: keyframe_bundle_adjustment/src/bundle_adjuster_keyframes.cpp (push :289-329, landmark creation
+// :332-382, updateLabels :388-431, solve :629-767, adjustPoseOnly :820-888, deactivateKeyframes :907-987,
+// getKeyframe :989-1021) and src/definitions.cpp (conversions :14-28,63-69, calcQuaternionDiff :104-111).
+#include "bundle_adjuster_keyframes.hpp"
+
+#include <cstdlib>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../include/limo_hip.h"
+#include "../csrc/kba_math.hpp"
+
+namespace keyframe_bundle_adjustment {
+
+// ------------------------------------------------------------------------------------------ conversions
+Pose convert(const EigenPose& p) {
+    // rotation matrix -> unit quaternion (what Eigen::Quaterniond(Matrix3d) computes)
+    const double* R = p.R;
+    double w, x, y, z;
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0.0) {
+        double s = std::sqrt(tr + 1.0);
+        w = 0.5 * s;
+        s = 0.5 / s;
+        x = (R[7] - R[5]) * s;
+        y = (R[2] - R[6]) * s;
+        z = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        double q[3];
+        q[i] = 0.5 * s;
+        s = 0.5 / s;
+        w = (R[k * 3 + j] - R[j * 3 + k]) * s;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+        x = q[0];
+        y = q[1];
+        z = q[2];
+    }
+    return Pose{{w, x, y, z, p.t[0], p.t[1], p.t[2]}};
+}
+
+EigenPose convert(const Pose& pose) {
+    EigenPose p;
+    kba::quat_R(pose.data(), p.R);
+    p.t[0] = pose[4];
+    p.t[1] = pose[5];
+    p.t[2] = pose[6];
+    return p;
+}
+
+TimestampSec convert(const TimestampNSec& ts) {
+    return static_cast<TimestampSec>(ts * 1e-09);
+}
+TimestampNSec convert(const TimestampSec& ts) {
+    return static_cast<TimestampNSec>(ts * 1e09);
+}
+
+double calcQuaternionDiff(const Pose& p0, const Pose& p1) {
+    // q10 = q1^-1 * q0 ; angle of AngleAxis(q10)
+    const double n1 = p1[0] * p1[0] + p1[1] * p1[1] + p1[2] * p1[2] + p1[3] * p1[3];
+    const double a[4] = {p1[0] / n1, -p1[1] / n1, -p1[2] / n1, -p1[3] / n1};
+    const double* b = p0.data();
+    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    const double n = std::sqrt(x * x + y * y + z * z);
+    return n != 0.0 ? 2.0 * std::atan2(n, std::fabs(w)) : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------ exceptions
+BundleAdjusterKeyframes::NotEnoughKeyframesException::NotEnoughKeyframesException(size_t is, size_t should)
+        : num_is(is), num_should_be(should) {
+    std::stringstream ss;
+    ss << "Not enough keyframes available in bundle_adjuster_keyframes. Should be " << num_should_be << " is " << num_is;
+    msg = ss.str();
+}
+BundleAdjusterKeyframes::KeyframeNotFoundException::KeyframeNotFoundException(TimestampNSec timestamp) : ts_(timestamp) {
+    std::stringstream ss;
+    ss << "keyframe corresponding to timestamp " << ts_ << " nano seconds not found";
+    msg = ss.str();
+}
+
+// ------------------------------------------------------------------------------------------ lifecycle
+BundleAdjusterKeyframes::BundleAdjusterKeyframes() : solver_time_sec(0.2) {
+    landmark_selector_ = std::make_unique<LandmarkSelector>();
+    landmark_selector_->addScheme(LandmarkRejectionSchemeCheirality::create());  // always first: fast and reliable (:118)
+}
+BundleAdjusterKeyframes::~BundleAdjusterKeyframes() {
+    if (ctx_) limo_ctx_destroy(ctx_);
+}
+
+limo_ctx* BundleAdjusterKeyframes::context() {
+    if (!ctx_) {
+        int dev = 0;
+        if (const char* e = std::getenv("LIMO_DEVICE")) dev = std::atoi(e);
+        const int rc = limo_ctx_create(dev, &ctx_);
+        if (rc != LIMO_OK)
+            throw std::runtime_error("limo_ctx_create failed (rc=" + std::to_string(rc) +
+                                     "): the keyframe BA hot path needs the HIP library and an MI355X; there is no CPU fallback");
+    }
+    return ctx_;
+}
+
+void BundleAdjusterKeyframes::set_solver_time(double s) {
+    this->solver_time_sec = s;
+}
+
+// ------------------------------------------------------------------------------------------ push / landmark creation
+namespace {
+bool containsDepth(const Keyframe& kf, const LandmarkId lId) {
+    for (const auto& cam_meas : kf.measurements_.at(lId))
+        if (cam_meas.second.d >= 0) return true;
+    return false;
+}
+limo_ray make_ray(const Camera& cam, const Keyframe& kf, const Measurement& m) {
+    limo_ray r;
+    const Pose pc = convert(cam.getEigenPose() * kf.getEigenPose());  // camera <- origin
+    for (int i = 0; i < 7; ++i) r.pose_cam_origin[i] = pc[i];
+    r.f = cam.focal_length;
+    r.cx = cam.principal_point[0];
+    r.cy = cam.principal_point[1];
+    r.u = m.u;
+    r.v = m.v;
+    r.d = m.d;
+    r.pad = 0;
+    return r;
+}
+}  // namespace
+
+void BundleAdjusterKeyframes::push(const std::vector<Keyframe>& kfs) {
+    for (const auto& kf : kfs) push(kf);
+}
+
+void BundleAdjusterKeyframes::push(const Keyframe& kf) {
+    keyframes_[kf.timestamp_] = std::make_shared<Keyframe>(kf);
+    active_keyframe_ids_.insert(kf.timestamp_);
+    for (const auto& m : kf.measurements_) {
+        if (landmarks_.find(m.first) == landmarks_.cend()) {
+            Vector3d p;
+            const bool has_depth = containsDepth(kf, m.first);
+            const bool success = has_depth ? calculateLandmark(kf, m.first, p) : calculateLandmark(m.first, p);
+            if (!success) continue;
+            landmarks_[m.first] = std::make_shared<Landmark>(p, has_depth);
+        }
+        active_landmark_ids_.insert(m.first);
+    }
+}
+
+bool BundleAdjusterKeyframes::calculateLandmark(const Keyframe& kf, const LandmarkId& lId, Vector3d& posAbs) {
+    std::vector<limo_ray> rays;
+    for (const auto& m : kf.measurements_.at(lId)) rays.push_back(make_ray(*kf.cameras_.at(m.first), kf, m.second));
+    const int32_t off[2] = {0, (int32_t)rays.size()};
+    const uint8_t use_depth = 1;
+    uint8_t ok = 0;
+    double pos[3];
+    if (limo_landmark_init(nullptr, 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
+    posAbs = Vector3d(pos);
+    return true;
+}
+
+bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d& posAbs) {
+    std::vector<limo_ray> rays;  // getMeasurementsAndPoses (:125-159): every active keyframe / camera that sees it
+    for (const auto& id : active_keyframe_ids_) {
+        const Keyframe& kf = *keyframes_.at(id);
+        for (const auto& id_cam : kf.cameras_)
+            if (kf.hasMeasurement(lId, id_cam.first)) rays.push_back(make_ray(*id_cam.second, kf, kf.getMeasurement(lId, id_cam.first)));
+    }
+    if (rays.size() < 2) return false;
+    const int32_t off[2] = {0, (int32_t)rays.size()};
+    const uint8_t use_depth = 0;
+    uint8_t ok = 0;
+    double pos[3];
+    if (limo_landmark_init(nullptr, 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
+    posAbs = Vector3d(pos);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ labels
+void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_weight) {
+    std::set<LandmarkId> outlier_ids;
+    for (const auto& id : landmark_selector_->getOutliers())
+        if (active_landmark_ids_.count(id)) outlier_ids.insert(id);
+    for (const auto& track : t.tracks)
+        if (track.is_outlier || labels_["outliers"].count(track.label)) outlier_ids.insert(track.id);
+    landmark_selector_->clearOutliers();
+    landmark_selector_->setOutlier(outlier_ids);
+    for (const auto& track : t.tracks) {
+        if (!active_landmark_ids_.count(track.id)) continue;
+        // (the reference uses landmarks_.at(), which throws for an active id that could not be reconstructed)
+        auto it = landmarks_.find(track.id);
+        if (it == landmarks_.end()) continue;
+        if (labels_["shrubbery"].count(track.label)) it->second->weight = shrubbery_weight;
+        it->second->is_ground_plane = labels_["ground"].count(track.label) > 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ getters
+std::map<LandmarkId, Landmark::ConstPtr> BundleAdjusterKeyframes::filterLandmarksById(const std::set<LandmarkId>& ids) const {
+    std::map<LandmarkId, Landmark::ConstPtr> out;
+    for (const auto& id : ids) {
+        auto it = landmarks_.find(id);
+        if (it != landmarks_.cend()) out[id] = it->second;
+    }
+    return out;
+}
+std::map<LandmarkId, Landmark::ConstPtr> BundleAdjusterKeyframes::getActiveLandmarkConstPtrs() const {
+    return filterLandmarksById(active_landmark_ids_);
+}
+std::map<LandmarkId, Landmark::ConstPtr> BundleAdjusterKeyframes::getSelectedLandmarkConstPtrs() const {
+    return filterLandmarksById(selected_landmark_ids_);
+}
+std::map<KeyframeId, Keyframe::Ptr> BundleAdjusterKeyframes::getActiveKeyframePtrs() const {
+    std::map<KeyframeId, Keyframe::Ptr> out;
+    for (const auto& id : active_keyframe_ids_) out[id] = keyframes_.at(id);
+    return out;
+}
+std::map<KeyframeId, Keyframe::ConstPtr> BundleAdjusterKeyframes::getActiveKeyframeConstPtrs() const {
+    std::map<KeyframeId, Keyframe::ConstPtr> out;
+    for (const auto& id : active_keyframe_ids_) out[id] = keyframes_.at(id);
+    return out;
+}
+std::vector<std::pair<KeyframeId, Keyframe::Ptr>> BundleAdjusterKeyframes::getSortedIdsWithActiveKeyframePtrs() const {
+    std::vector<std::pair<KeyframeId, Keyframe::Ptr>> v;
+    for (const auto& id : active_keyframe_ids_) v.push_back({id, keyframes_.at(id)});
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return *(a.second) < *(b.second); });
+    return v;
+}
+std::vector<Keyframe::Ptr> BundleAdjusterKeyframes::getSortedActiveKeyframePtrs() const {
+    std::vector<Keyframe::Ptr> out;
+    for (const auto& el : getSortedIdsWithActiveKeyframePtrs()) out.push_back(el.second);
+    return out;
+}
+
+const Keyframe& BundleAdjusterKeyframes::getKeyframe(TimestampSec timestamp) const {
+    if (keyframes_.size() == 0) throw NotEnoughKeyframesException(keyframes_.size(), 1);
+    if (timestamp < 0.) {
+        const Keyframe* best = nullptr;
+        for (const auto& id : active_keyframe_ids_) {
+            const Keyframe* k = keyframes_.at(id).get();
+            if (!best || best->timestamp_ < k->timestamp_) best = k;
+        }
+        if (!best) throw NotEnoughKeyframesException(0, 1);
+        return *best;
+    }
+    const TimestampNSec ts_nsec = convert(timestamp);
+    for (const auto& id : active_keyframe_ids_)
+        if (keyframes_.at(id)->timestamp_ == ts_nsec) return *keyframes_.at(id);
+    for (const auto& el : keyframes_)
+        if (el.second->timestamp_ == ts_nsec) return *el.second;
+    throw KeyframeNotFoundException(ts_nsec);
+}
+
+// ------------------------------------------------------------------------------------------ window cut (:907-987)
+void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmarks, int min_size_optimization_window,
+                                                  int max_size_optimization_window) {
+    auto sorted = getSortedIdsWithActiveKeyframePtrs();
+    if (sorted.empty()) return;
+    const Keyframe& newest = *sorted.back().second;
+    int n = 0;  // 0 = newest
+    for (auto it = sorted.rbegin(); it != sorted.rend(); ++it, ++n) {
+        Keyframe& cur = *it->second;
+        if (n > max_size_optimization_window - 1) {
+            cur.is_active_ = false;
+        } else if (n < min_size_optimization_window - 1) {
+            cur.is_active_ = true;
+        } else {
+            int common = 0;  // landmark ids measured in both keyframes (std::set_intersection of the map keys, :88-111)
+            for (const auto& m : cur.measurements_)
+                if (newest.measurements_.count(m.first)) ++common;
+            cur.is_active_ = common > min_num_connecting_landmarks;
+        }
+        if (!cur.is_active_) active_keyframe_ids_.erase(it->first);
+    }
+    std::set<LandmarkId> still_active;
+    for (const auto& kf_id : active_keyframe_ids_)
+        for (const auto& m : keyframes_.at(kf_id)->measurements_)
+            if (active_landmark_ids_.count(m.first)) still_active.insert(m.first);
+    active_landmark_ids_ = still_active;
+    // oldest active keyframe fixes the gauge, second oldest carries the scale prior (:962-986)
+    auto rest = getSortedIdsWithActiveKeyframePtrs();
+    if (rest.size() > 0) rest[0].second->fixation_status_ = Keyframe::FixationStatus::Pose;
+    if (rest.size() > 1) rest[1].second->fixation_status_ = Keyframe::FixationStatus::Scale;
+}
+
+// ------------------------------------------------------------------------------------------ flattening
+namespace {
+
+struct Flat {
+    std::vector<double> kf_pose, kf_dir, kf_dist, cam, lm_pos, lm_w;
+    std::vector<int32_t> kf_fix, obs_kf, obs_lm, obs_cam;
+    std::vector<uint8_t> lm_gp;
+    std::vector<float> u, v, d;
+    std::vector<Keyframe*> kfs;
+    std::vector<Landmark*> lms;
+    std::map<const Camera*, int> cam_index;
+    limo_ba_window w;
+
+    int camera(const Camera& c) {
+        auto it = cam_index.find(&c);
+        if (it != cam_index.end()) return it->second;
+        const int idx = (int)cam_index.size();
+        cam_index[&c] = idx;
+        cam.push_back(c.focal_length);
+        cam.push_back(c.principal_point[0]);
+        cam.push_back(c.principal_point[1]);
+        for (int i = 0; i < 7; ++i) cam.push_back(c.pose_camera_vehicle[i]);
+        return idx;
+    }
+    void add_keyframe(Keyframe& kf) {
+        kfs.push_back(&kf);
+        for (int i = 0; i < 7; ++i) kf_pose.push_back(kf.pose_[i]);
+        for (int i = 0; i < 3; ++i) kf_dir.push_back(kf.local_ground_plane_.direction[i]);
+        kf_dist.push_back(kf.local_ground_plane_.distance);
+        kf_fix.push_back(kf.fixation_status_ == Keyframe::FixationStatus::Pose
+                             ? LIMO_FIX_POSE
+                             : kf.fixation_status_ == Keyframe::FixationStatus::Scale ? LIMO_FIX_SCALE : LIMO_FIX_NONE);
+    }
+    void add_observations(int k, const Keyframe& kf, const std::map<LandmarkId, int>& lm_index) {
+        for (const auto& m : kf.measurements_) {  // addKeyframeToProblem, :569-576
+            auto it = lm_index.find(m.first);
+            if (it == lm_index.end()) continue;
+            for (const auto& cam_meas : m.second) {
+                obs_kf.push_back(k);
+                obs_lm.push_back(it->second);
+                obs_cam.push_back(camera(*kf.cameras_.at(cam_meas.first)));
+                u.push_back(cam_meas.second.u);
+                v.push_back(cam_meas.second.v);
+                d.push_back(cam_meas.second.d);
+            }
+        }
+    }
+    void finish() {
+        w.n_kf = (int)kfs.size();
+        w.n_cam = (int)cam_index.size();
+        w.n_lm = (int)lms.size();
+        w.n_obs = (int)obs_kf.size();
+        w.kf_pose = kf_pose.data();
+        w.kf_plane_dir = kf_dir.data();
+        w.kf_plane_dist = kf_dist.data();
+        w.kf_fixation = kf_fix.data();
+        w.cam = cam.data();
+        w.lm_pos = lm_pos.data();
+        w.lm_weight = lm_w.data();
+        w.lm_is_ground = lm_gp.data();
+        w.obs_kf = obs_kf.data();
+        w.obs_lm = obs_lm.data();
+        w.obs_cam = obs_cam.data();
+        w.obs_u = u.data();
+        w.obs_v = v.data();
+        w.obs_d = d.data();
+    }
+    void write_back(bool landmarks) {
+        for (size_t k = 0; k < kfs.size(); ++k) {
+            for (int i = 0; i < 7; ++i) kfs[k]->pose_[i] = kf_pose[7 * k + i];
+            for (int i = 0; i < 3; ++i) kfs[k]->local_ground_plane_.direction[i] = kf_dir[3 * k + i];
+            kfs[k]->local_ground_plane_.distance = kf_dist[k];
+        }
+        if (landmarks)
+            for (size_t l = 0; l < lms.size(); ++l)
+                for (int i = 0; i < 3; ++i) lms[l]->pos[i] = lm_pos[3 * l + i];
+    }
+};
+
+std::string report_string(const limo_ba_report& r, const char* what) {
+    static const char* term[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+    std::stringstream ss;
+    ss << "Merged summaries (" << what << ", MI355X HIP backend):\n"
+       << "  residual blocks: depth " << r.n_depth_blocks << ", reprojection " << r.n_repr_blocks << ", ground plane "
+       << r.n_gp_blocks << "\n  solves " << r.num_solves << ", LM iterations " << r.iterations_total << " (final solve "
+       << r.iterations_final << "), accepted steps " << r.successful_steps << ", trimmed landmarks "
+       << r.n_trimmed_landmarks << "\n  initial cost " << r.initial_cost << " final cost " << r.final_cost
+       << " termination " << (r.termination >= 0 && r.termination < 3 ? term[r.termination] : "?") << "\n"
+       << "Duration solveTrimmed=" << r.time_sec << " sec\n";
+    return ss.str();
+}
+
+}  // namespace
+
+std::string BundleAdjusterKeyframes::solve() {
+    if (keyframes_.size() < 3) throw NotEnoughKeyframesException(keyframes_.size(), 3);
+    selected_landmark_ids_ = landmark_selector_->select(getActiveLandmarkConstPtrs(), getActiveKeyframeConstPtrs());
+
+    Flat F;
+    for (const auto& id : active_keyframe_ids_) F.add_keyframe(*keyframes_.at(id));
+    std::map<LandmarkId, int> lm_index;
+    for (const auto& id : selected_landmark_ids_) {
+        auto it = landmarks_.find(id);
+        if (it == landmarks_.end()) continue;
+        lm_index[id] = (int)F.lms.size();
+        F.lms.push_back(it->second.get());
+        for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
+        F.lm_w.push_back(it->second->weight);
+        F.lm_gp.push_back(it->second->is_ground_plane ? 1 : 0);
+    }
+    for (size_t k = 0; k < F.kfs.size(); ++k) F.add_observations((int)k, *F.kfs[k], lm_index);
+    F.finish();
+
+    limo_ba_options o;
+    limo_ba_default_options(&o);
+    o.depth_thres = outlier_rejection_options_.depth_thres;
+    o.reprojection_thres = outlier_rejection_options_.reprojection_thres;
+    o.depth_quantile = outlier_rejection_options_.depth_quantile;
+    o.reprojection_quantile = outlier_rejection_options_.reprojection_quantile;
+    o.num_trim_rounds = outlier_rejection_options_.num_iterations;
+    o.min_landmarks_for_trimming = 100;  // :741 (compared with selected_landmark_ids_.size())
+    o.max_solver_time_sec = solver_time_sec;
+    limo_ba_report rep;
+    limo_ctx* ctx = context();
+    const int rc = limo_ba_solve(ctx, &F.w, &o, &rep);
+    if (rc == LIMO_ERR_NOT_ENOUGH_KF) throw NotEnoughKeyframesException(F.kfs.size(), 3);
+    if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_ba_solve: ") + limo_last_error(ctx));
+    F.write_back(true);
+    last_report_ = {rep.termination, rep.num_solves, rep.iterations_total, rep.n_trimmed_landmarks, rep.n_depth_blocks,
+                    rep.n_repr_blocks, rep.n_gp_blocks, rep.initial_cost, rep.final_cost, rep.time_sec};
+    return report_string(rep, "solve");
+}
+
+std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
+    selected_landmark_ids_ = landmark_selector_->getLastSelection();  // :828
+    Flat F;
+    F.add_keyframe(kf);
+    std::map<LandmarkId, int> lm_index;
+    for (const auto& id : selected_landmark_ids_) {
+        auto it = landmarks_.find(id);
+        if (it == landmarks_.end()) continue;
+        lm_index[id] = (int)F.lms.size();
+        F.lms.push_back(it->second.get());
+        for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
+        F.lm_w.push_back(it->second->weight);
+        F.lm_gp.push_back(0);
+    }
+    F.add_observations(0, kf, lm_index);
+    F.finish();
+
+    limo_speed_prior prior;
+    prior.speed_weight = 0.0;
+    if (active_keyframe_ids_.size() > 2) {  // :835-853
+        auto sorted = getSortedActiveKeyframePtrs();
+        const Keyframe& k0 = *sorted[sorted.size() - 1];
+        const Keyframe& k1 = *sorted[sorted.size() - 2];
+        const double rot_diff = calcQuaternionDiff(k0.pose_, k1.pose_);
+        if (rot_diff < 0.03) {
+            const double cur_ts = convert(kf.timestamp_), before = convert(k0.timestamp_), before2 = convert(k1.timestamp_);
+            const double dt_cur = cur_ts - before, dt_before = before - before2;
+            if (dt_cur <= 0. || dt_before <= 0.) throw std::runtime_error("In PoseRegularizationSpeed: invalid timestamps");
+            prior.speed_weight = 1. * (1 - rot_diff / 0.03);
+            prior.dt_cur = dt_cur;
+            const Vector3d v = (k0.getEigenPose() * k1.getEigenPose().inverse()).translation() * (1.0 / dt_before);
+            for (int i = 0; i < 3; ++i) prior.vel_prev[i] = v[i];
+            for (int i = 0; i < 7; ++i) prior.pose_before[i] = k0.pose_[i];
+        }
+    }
+    limo_ba_options o;
+    limo_ba_default_options(&o);
+    o.depth_thres = outlier_rejection_options_.depth_thres;
+    o.reprojection_thres = outlier_rejection_options_.reprojection_thres;
+    o.depth_quantile = outlier_rejection_options_.depth_quantile;
+    o.reprojection_quantile = outlier_rejection_options_.reprojection_quantile;
+    o.num_trim_rounds = outlier_rejection_options_.num_iterations;
+    o.min_landmarks_for_trimming = 30;  // :865
+    o.max_solver_time_sec = solver_time_sec;
+    limo_ba_report rep;
+    limo_ctx* ctx = context();
+    const int rc = limo_ba_adjust_pose_only(ctx, &F.w, prior.speed_weight > 0.0 ? &prior : nullptr, &o, &rep);
+    if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_ba_adjust_pose_only: ") + limo_last_error(ctx));
+    F.write_back(false);
+    last_report_ = {rep.termination, rep.num_solves, rep.iterations_total, rep.n_trimmed_landmarks, rep.n_depth_blocks,
+                    rep.n_repr_blocks, rep.n_gp_blocks, rep.initial_cost, rep.final_cost, rep.time_sec};
+    return report_string(rep, "adjustPoseOnly");
+}
+
+}  // namespace keyframe_bundle_adjustment

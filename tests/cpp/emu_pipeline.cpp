@@ -332,3 +332,54 @@ int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Optional: export the product's C-ABI names on top of the emulation, so that C++ code written against
+// include/limo_hip.h (the kba shim, tests/cpp/test_kba_shim.cpp) can be exercised in the CPU-only test tier.
+// Built only into tests/cpp/_build/libkba_emu_abi.so.  NEVER linked into the product.
+#ifdef KBA_EMU_EXPORT_ABI
+struct limo_ctx {
+    std::string err;
+};
+extern "C" {
+int limo_abi_version(void) { return LIMO_ABI_VERSION; }
+int limo_ctx_create(int, limo_ctx** out) {
+    *out = new limo_ctx();
+    return LIMO_OK;
+}
+void limo_ctx_destroy(limo_ctx* c) { delete c; }
+int limo_ctx_set_stream(limo_ctx*, void*) { return LIMO_OK; }
+const char* limo_last_error(const limo_ctx* c) { return c ? c->err.c_str() : ""; }
+void limo_ba_default_options(limo_ba_options* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->depth_thres = 0.16;
+    o->reprojection_thres = 1.6;
+    o->depth_quantile = 0.95;
+    o->reprojection_quantile = 0.95;
+    o->num_trim_rounds = 1;
+    o->trim_solver_iterations = 2;
+    o->min_landmarks_for_trimming = 100;
+    o->minimum_number_residual_groups = 30;
+    o->max_num_iterations = 100;
+    o->max_solver_time_sec = -1.0;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->min_relative_decrease = 1e-3;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+}
+int limo_ba_solve(limo_ctx*, limo_ba_window* w, const limo_ba_options* o, limo_ba_report* r) {
+    return emu_ba_solve_batch(1, w, o, r, 0, nullptr);
+}
+int limo_ba_adjust_pose_only(limo_ctx*, limo_ba_window* w, const limo_speed_prior* p, const limo_ba_options* o,
+                             limo_ba_report* r) {
+    return emu_ba_solve_batch(1, w, o, r, 1, p);
+}
+}
+#endif

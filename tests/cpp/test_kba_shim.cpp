@@ -1,0 +1,282 @@
+// C++ tests of the keyframe_bundle_adjustment shim (limo_amd/kba) — the reference's own gtest scenarios restated
+// without gtest/Eigen (keyframe_bundle_adjustment/test/keyframe_bundle_adjustment.cpp: scene helpers :180-417,
+// deactivateKeyframes :744-805, solve :807-858, solve_depth :1090-1145, CreateWithDepth :1149-1210,
+// adjustMotionOnly :1340-1344).  The same binary is linked twice: against the test-only emulation of the C-ABI
+// (CPU tier) and against liblimo_hip.so (GPU tier).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <tuple>
+
+#include "../../limo_amd/kba/bundle_adjuster_keyframes.hpp"
+
+using namespace keyframe_bundle_adjustment;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        ++g_checks;                                                              \
+        if (!(cond)) {                                                           \
+            ++g_fail;                                                            \
+            std::printf("  CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                        \
+    } while (0)
+
+// ---- scene helpers -------------------------------------------------------------------------------------------------
+// The reference draws every noise value from a FRESH default-seeded engine (test :180-216), i.e. always the first
+// variates of std::default_random_engine; we do the same so the noisy scenes are the reference's scenes.
+static double noise1(double sigma) {
+    std::default_random_engine g;
+    std::normal_distribution<double> d(0., sigma);
+    return d(g);
+}
+static Vector3d noise3(const Vector3d& v, const std::tuple<double, double, double>& s) {
+    std::default_random_engine g;
+    std::normal_distribution<double> dx(0., std::get<0>(s)), dy(0., std::get<1>(s)), dz(0., std::get<2>(s));
+    Vector3d o = v;
+    o[0] += dx(g);
+    o[1] += dy(g);
+    o[2] += dz(g);
+    return o;
+}
+static void noise2(double& a, double& b, double sa, double sb) {
+    std::default_random_engine g;
+    std::normal_distribution<double> dx(0., sa), dy(0., sb);
+    a += dx(g);
+    b += dy(g);
+}
+
+// getPoses, test :232-249 (keyframe <- origin poses, right-multiplied increments)
+static std::map<TimestampNSec, EigenPose> getPoses(double noise_angle, std::tuple<double, double, double> nt,
+                                                   const std::vector<TimestampNSec>& st) {
+    std::map<TimestampNSec, EigenPose> p;
+    const Vector3d Z(0., 0., 1.);
+    p[st[0]] = EigenPose::Identity();
+    p[st[1]] = p[st[0]];
+    p[st[1]].translate(Vector3d(-1.5, 0., -2.));
+    p[st[1]].rotate(-0.05, Z);
+    p[st[2]] = p[st[1]];
+    p[st[2]].translate(noise3(Vector3d(-2.0, 0., 0.), nt));
+    p[st[2]].rotate(-0.05 + noise1(noise_angle), Z);
+    p[st[3]] = p[st[2]];
+    p[st[3]].translate(noise3(Vector3d(-1.5, -0.1, 0.), nt));
+    p[st[4]] = p[st[3]];
+    p[st[4]].translate(noise3(Vector3d(-2.9, -0., 0.), nt));
+    return p;
+}
+
+// makeTracklets / makeTrackletsDepth, test :288-417: every landmark is measured in every keyframe by its camera
+static Tracklets makeTracklets(const std::map<KeyframeId, EigenPose>& poses_gt, const std::vector<Vector3d>& lms,
+                               const std::map<CameraId, Camera::Ptr>& cams, double nu, double nv, bool keep_depth,
+                               const std::map<LandmarkId, CameraIds>& lm_cams, const std::vector<TimestampNSec>& stamps) {
+    Tracklets ts;
+    ts.stamps = stamps;
+    ts.tracks.resize(lms.size());
+    for (size_t i = 0; i < lms.size(); ++i) ts.tracks[i].id = i;
+    for (const auto& p : poses_gt) {
+        for (size_t i = 0; i < lms.size(); ++i) {
+            const CameraId cid = lm_cams.empty() ? 0 : lm_cams.at(i)[0];
+            const Camera& c = *cams.at(cid);
+            const Vector3d q = (c.getEigenPose() * p.second) * lms[i];
+            double u = c.focal_length * q[0] / q[2] + c.principal_point[0];
+            double v = c.focal_length * q[1] / q[2] + c.principal_point[1];
+            noise2(u, v, nu, nv);
+            ts.tracks[i].feature_points.push_back(keep_depth ? FeaturePoint((float)u, (float)v, (float)q[2])
+                                                              : FeaturePoint((float)u, (float)v));
+        }
+    }
+    return ts;
+}
+
+static EigenPose camera_extrinsic_solve() {  // test :808-814
+    EigenPose p = EigenPose::Identity();
+    p.rotate(M_PI / 2., Vector3d(1., 0., 0.));
+    p.rotate(M_PI / 2., Vector3d(0., 0., 1.));
+    p.translate(Vector3d(-1.5, 0.2, -1.35));
+    return p.inverse();
+}
+
+// evaluate_bundle_adjustment (:419-609) and evaluate_bundle_adjustment_depth (:860-1087) in one
+static void evaluate_ba(bool with_depth, double n_u, double n_v, std::tuple<double, double, double, double> noise_poses,
+                        double thr, const std::vector<EigenPose>& cam_poses, bool motion_only = false) {
+    const double f = 600.;
+    const Vector2d pp(200., 100.);
+    const std::vector<TimestampNSec> stamps{0, 1, 2, 3, 4};
+    const auto nt = std::make_tuple(std::get<1>(noise_poses), std::get<2>(noise_poses), std::get<3>(noise_poses));
+    auto poses_gt = getPoses(0., std::make_tuple(0., 0., 0.), stamps);
+    auto noisy = getPoses(std::get<0>(noise_poses), nt, stamps);
+    for (int i = 2; i < 5; ++i) {  // unknown scale: translation().normalize(), :446-449
+        EigenPose& p = noisy[i];
+        const double n = std::sqrt(p.t[0] * p.t[0] + p.t[1] * p.t[1] + p.t[2] * p.t[2]);
+        for (int k = 0; k < 3; ++k) p.t[k] /= n;
+    }
+    const std::vector<Vector3d> lms = with_depth
+                                          ? std::vector<Vector3d>{{10., 3., 5.5}, {11., 1., 6.5}, {14., -5., 6.}, {9., 1., 5.}, {16., -1., 4.}}
+                                          : std::vector<Vector3d>{{10., 0.5, 5.5}, {11., 1., 6.5}, {14., -5., 6.}, {9., 1., 5.}, {16., -1., 4.}};
+    std::map<CameraId, Camera::Ptr> cams;
+    for (size_t i = 0; i < cam_poses.size(); ++i) cams[i] = std::make_shared<Camera>(f, pp, cam_poses[i]);
+    std::map<LandmarkId, CameraIds> lm_cams;
+    for (size_t i = 0; i < lms.size(); ++i) lm_cams[i] = CameraIds{(CameraId)(i % cam_poses.size())};
+    auto ts = makeTracklets(poses_gt, lms, cams, n_u, n_v, with_depth, lm_cams, stamps);
+
+    BundleAdjusterKeyframes b;
+    b.set_solver_time(20.);
+    const int max_ind = with_depth ? 4 : 5;  // the depth test pushes KF0..KF3 only (:936,953)
+    if (motion_only)
+        for (int i = 0; i < max_ind; ++i) noisy[stamps[i]] = poses_gt[stamps[i]];
+    auto make_kf = [&](int i, Keyframe::FixationStatus fs) {
+        if (cam_poses.size() == 1) return Keyframe(stamps[i], ts, cams.at(0), noisy.at(stamps[i]), fs);
+        return Keyframe(stamps[i], ts, cams, lm_cams, noisy.at(stamps[i]), fs);
+    };
+    b.push(make_kf(0, Keyframe::FixationStatus::Pose));
+    b.push(make_kf(1, Keyframe::FixationStatus::Scale));
+    for (int i = 2; i < max_ind; ++i) b.push(make_kf(i, Keyframe::FixationStatus::None));
+    CHECK(b.landmarks_.size() == lms.size());
+    for (size_t i = 0; i < lms.size(); ++i)
+        if (b.landmarks_.count(i)) CHECK((lms[i] - Vector3d(b.landmarks_.at(i)->pos.data())).norm() < 1e-1);
+
+    if (motion_only) {
+        Keyframe kf = make_kf(4, Keyframe::FixationStatus::None);
+        b.landmark_selector_->select(b.getActiveLandmarkConstPtrs(), b.getActiveKeyframeConstPtrs());
+        b.adjustPoseOnly(kf);
+        CHECK(kf.getEigenPose().isApprox(poses_gt.at(kf.timestamp_), thr));
+        return;
+    }
+    std::string summary = b.solve();
+    CHECK(!summary.empty());
+    auto it_gt = poses_gt.cbegin();
+    auto it = b.keyframes_.cbegin();
+    for (; it_gt != poses_gt.cend() && it != b.keyframes_.cend(); ++it_gt, ++it) {
+        const bool ok = it->second->getEigenPose().isApprox(it_gt->second, thr);
+        CHECK(ok);
+        if (!ok) {
+            const Pose g = convert(it_gt->second);
+            std::printf("    kf %lu pose", (unsigned long)it->first);
+            for (int i = 0; i < 7; ++i) std::printf(" %.5f|%.5f", it->second->pose_[i], g[i]);
+            std::printf("\n");
+        }
+    }
+}
+
+// ---- tests ---------------------------------------------------------------------------------------------------------
+static void test_solve() {  // KeyFrameBundleAdjustment.solve, :807-858
+    const EigenPose p = camera_extrinsic_solve();
+    const double a = 5. * M_PI / 180.;
+    evaluate_ba(false, 0., 0., std::make_tuple(0., 0., 0., 0.), 0.001, {p});
+    evaluate_ba(false, 0., 0., std::make_tuple(a, 0.2, 0.1, 0.1), 0.001, {p});
+    evaluate_ba(false, 1.5, 1.5, std::make_tuple(a, 0.2, 0.1, 0.1), 0.01, {p});
+    EigenPose p2 = p;
+    p2.translate(Vector3d(0., -0.5, 0.));
+    p2.rotate(M_PI / 18., Vector3d(0., 1., 0.));
+    p2.rotate(M_PI / 18., Vector3d(1., 0., 0.));
+    evaluate_ba(false, 0., 0., std::make_tuple(0., 0., 0., 0.), 0.001, {p, p2});
+    evaluate_ba(false, 0., 0., std::make_tuple(a, 0.2, 0.1, 0.1), 0.001, {p, p2});
+    evaluate_ba(false, 1.5, 1.5, std::make_tuple(a, 0.2, 0.1, 0.1), 0.01, {p, p2});
+}
+
+static void test_solve_depth() {  // KeyFrameBundleAdjustment.solve_depth, :1090-1145
+    const double a = 5. * M_PI / 180.;
+    const EigenPose I = EigenPose::Identity();
+    evaluate_ba(true, 0., 0., std::make_tuple(0., 0., 0., 0.), 0.001, {I});
+    evaluate_ba(true, 0., 0., std::make_tuple(a, 0.2, 0.1, 0.1), 0.001, {I});
+    evaluate_ba(true, 1.5, 1.5, std::make_tuple(a, 0.2, 0.1, 0.1), 0.01, {I});
+    const EigenPose p = camera_extrinsic_solve();
+    EigenPose p2 = p;
+    p2.translate(Vector3d(0., -0.5, 0.));
+    p2.rotate(M_PI / 18., Vector3d(0., 1., 0.));
+    p2.rotate(M_PI / 18., Vector3d(1., 0., 0.));
+    evaluate_ba(true, 0., 0., std::make_tuple(0., 0., 0., 0.), 0.001, {p, p2});
+    evaluate_ba(true, 0., 0., std::make_tuple(a, 0.2, 0.1, 0.1), 0.001, {p, p2});
+    evaluate_ba(true, 1.5, 1.5, std::make_tuple(a, 0.2, 0.1, 0.1), 0.01, {p, p2});
+}
+
+static void test_adjust_motion_only() {  // BundleAdjusterKeyframes.adjustMotionOnly, :1340-1344
+    evaluate_ba(true, 0., 0., std::make_tuple(0., 0., 0., 0.), 0.5, {EigenPose::Identity()}, true);
+}
+
+static void test_create_with_depth() {  // LandmarkCreator.CreateWithDepth, :1149-1210
+    const std::vector<Vector3d> lms{{0.5, 3., 5.5}, {0., 1., -20.}, {1., -5., 4.}, {2.0, 1., 1.5}, {-2.0, -1., 10.}};
+    const std::vector<TimestampNSec> stamps{0, 1, 2, 3, 4};
+    auto poses = getPoses(0., std::make_tuple(0., 0., 0.), stamps);
+    auto cam = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
+    auto ts = makeTracklets(poses, lms, {{0, cam}}, 0., 0., true, {}, stamps);
+    BundleAdjusterKeyframes adj;
+    adj.set_solver_time(20.);
+    int c = 0;
+    for (const auto& el : poses) adj.push(Keyframe(c++, ts, cam, el.second));
+    for (size_t i = 0; i < lms.size(); ++i) {
+        CHECK(adj.landmarks_.count(i) == 1);
+        if (adj.landmarks_.count(i)) CHECK((lms[i] - Vector3d(adj.landmarks_.at(i)->pos.data())).norm() < 0.01);
+    }
+}
+
+static void test_deactivate_keyframes() {  // BundleAdjusterKeyframes.deactivateKeyframes, :744-805
+    const std::vector<Vector3d> lms{{0.5, 3., 5.5}, {0., 1., -4.}, {0., 3., -4.}, {1., -5., 4.}, {1., -5., 5.}, {2.0, 1., 1.5}, {-2.0, -1., 10.}};
+    std::vector<TimestampNSec> stamps{convert(TimestampSec(0.1)), convert(TimestampSec(0.2)), convert(TimestampSec(0.3)),
+                                      convert(TimestampSec(0.4)), convert(TimestampSec(0.5))};
+    auto poses = getPoses(0., std::make_tuple(0., 0., 0.), stamps);
+    auto cam = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
+    auto ts = makeTracklets(poses, lms, {{0, cam}}, 0., 0., false, {}, stamps);
+    BundleAdjusterKeyframes adj;
+    EigenPose far = EigenPose::Identity();
+    far.translate(Vector3d(10., 10., 10.));
+    adj.push(Keyframe(0, ts, cam, far, Keyframe::FixationStatus::Pose));
+    for (const auto& el : poses) adj.push(Keyframe(el.first, ts, cam, el.second, Keyframe::FixationStatus::None));
+    adj.keyframes_.at(convert(TimestampSec(0.1)))->fixation_status_ = Keyframe::FixationStatus::Scale;
+    adj.deactivateKeyframes(3, 3, 20);
+    CHECK(adj.active_keyframe_ids_.size() == 5);
+    CHECK(adj.active_landmark_ids_.size() == lms.size());
+    CHECK(adj.keyframes_.at(convert(TimestampSec(0.1)))->fixation_status_ == Keyframe::FixationStatus::Pose);
+    CHECK(adj.keyframes_.at(convert(TimestampSec(0.2)))->fixation_status_ == Keyframe::FixationStatus::Scale);
+    adj.deactivateKeyframes(3, 2, 3);
+    CHECK(adj.active_keyframe_ids_.size() == 3);
+}
+
+static void test_exceptions() {
+    BundleAdjusterKeyframes b;
+    bool thrown = false;
+    try {
+        b.solve();
+    } catch (const BundleAdjusterKeyframes::NotEnoughKeyframesException& e) {
+        thrown = std::string(e.what()).find("Should be 3 is 0") != std::string::npos;
+    }
+    CHECK(thrown);
+    thrown = false;
+    try {
+        b.getKeyframe();
+    } catch (const BundleAdjusterKeyframes::NotEnoughKeyframesException&) {
+        thrown = true;
+    }
+    CHECK(thrown);
+}
+
+int main(int argc, char** argv) {
+    struct T {
+        const char* name;
+        void (*fn)();
+    } tests[] = {{"LandmarkCreator.CreateWithDepth", test_create_with_depth},
+                 {"BundleAdjusterKeyframes.deactivateKeyframes", test_deactivate_keyframes},
+                 {"BundleAdjusterKeyframes.exceptions", test_exceptions},
+                 {"KeyFrameBundleAdjustment.solve", test_solve},
+                 {"KeyFrameBundleAdjustment.solve_depth", test_solve_depth},
+                 {"BundleAdjusterKeyframes.adjustMotionOnly", test_adjust_motion_only}};
+    int failed_tests = 0;
+    for (const auto& t : tests) {
+        if (argc > 1 && std::string(t.name).find(argv[1]) == std::string::npos) continue;
+        const int before = g_fail;
+        std::printf("[ RUN  ] %s\n", t.name);
+        try {
+            t.fn();
+        } catch (const std::exception& e) {
+            ++g_fail;
+            std::printf("  EXCEPTION: %s\n", e.what());
+        }
+        std::printf("[ %s ] %s\n", g_fail == before ? " OK " : "FAIL", t.name);
+        failed_tests += g_fail != before;
+    }
+    std::printf("%d checks, %d failed checks, %d failed tests\n", g_checks, g_fail, failed_tests);
+    return failed_tests ? 1 : 0;
+}
