@@ -122,3 +122,38 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def depth_default_params():
+    p = _ffi.DepthParams()
+    _ffi.load().limo_depth_default_params(C.byref(p))
+    return p
+
+
+def depth_estimate(ctx, frame, params=None, use_ground_labels=True):
+    """limo_depth_estimate on one frame dict (see limo_amd.synth_lidar.make_frame): returns float32 depth per feature."""
+    lib = ctx.lib
+    p = params if params is not None else depth_default_params()
+    cloud = np.ascontiguousarray(frame["cloud"], np.float32)
+    uv = np.ascontiguousarray(frame["uv"], np.float32)
+    T = np.ascontiguousarray(frame["T_cam_lidar"], np.float64)
+    g = np.ascontiguousarray(frame["is_ground"], np.uint8) if use_ground_labels else None
+    out = np.zeros(uv.shape[0], np.float32)
+    rc = lib.limo_depth_estimate(
+        ctx.ptr,
+        cloud.ctypes.data_as(_ffi.c_float_p),
+        cloud.shape[0],
+        T.ctypes.data_as(_ffi.c_double_p),
+        frame["f"],
+        frame["cx"],
+        frame["cy"],
+        frame["w"],
+        frame["h"],
+        uv.ctypes.data_as(_ffi.c_float_p),
+        uv.shape[0],
+        None if g is None else g.ctypes.data_as(_ffi.c_uint8_p),
+        C.byref(p),
+        out.ctypes.data_as(_ffi.c_float_p),
+    )
+    _check(rc, ctx.ptr, "limo_depth_estimate")
+    return out

@@ -18,12 +18,7 @@
 
 using namespace kba;
 
-struct limo_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t own = nullptr;
-    std::string err;
-};
+#include "limo_ctx.hpp"
 
 #define HIP_TRY(ctx, expr)                                                                       \
     do {                                                                                         \
@@ -315,6 +310,7 @@ int limo_ctx_create(int device, limo_ctx** out) {
 
 void limo_ctx_destroy(limo_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->depth_ws && ctx->depth_ws_free) ctx->depth_ws_free(ctx->depth_ws);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
 }

@@ -155,3 +155,38 @@ def landmark_init(ray_off, rays, use_depth):
     ok = np.zeros(n, np.uint8)
     lib.oracle_landmark_init(n, ray_off.ctypes.data_as(_ffi.c_int32_p), rays, use_depth.ctypes.data_as(_ffi.c_uint8_p), _dp(pos), ok.ctypes.data_as(_ffi.c_uint8_p))
     return pos, ok
+
+
+def depth_default_params():
+    lib = load()
+    p = _ffi.DepthParams()
+    lib.oracle_depth_default_params.argtypes = [C.POINTER(_ffi.DepthParams)]
+    lib.oracle_depth_default_params.restype = None
+    lib.oracle_depth_default_params(C.byref(p))
+    return p
+
+
+def depth_estimate(frame, params=None, use_ground_labels=True):
+    lib = load()
+    lib.oracle_depth_estimate.argtypes = [_ffi.c_float_p, C.c_size_t, _ffi.c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _ffi.c_float_p, C.c_size_t, _ffi.c_uint8_p, C.POINTER(_ffi.DepthParams), _ffi.c_float_p]
+    p = params if params is not None else depth_default_params()
+    cloud = np.ascontiguousarray(frame["cloud"], np.float32)
+    uv = np.ascontiguousarray(frame["uv"], np.float32)
+    T = np.ascontiguousarray(frame["T_cam_lidar"], np.float64)
+    g = np.ascontiguousarray(frame["is_ground"], np.uint8) if use_ground_labels else None
+    out = np.zeros(uv.shape[0], np.float32)
+    rc = lib.oracle_depth_estimate(cloud.ctypes.data_as(_ffi.c_float_p), cloud.shape[0], _dp(T), frame["f"], frame["cx"], frame["cy"], frame["w"], frame["h"], uv.ctypes.data_as(_ffi.c_float_p), uv.shape[0], None if g is None else g.ctypes.data_as(_ffi.c_uint8_p), C.byref(p), out.ctypes.data_as(_ffi.c_float_p))
+    if rc != 0:
+        raise RuntimeError("oracle_depth_estimate rc=%d" % rc)
+    return out
+
+
+def ground_plane(frame, params=None):
+    lib = load()
+    lib.oracle_ground_plane.argtypes = [_ffi.c_float_p, C.c_size_t, _ffi.c_double_p, C.POINTER(_ffi.DepthParams), _ffi.c_double_p]
+    p = params if params is not None else depth_default_params()
+    cloud = np.ascontiguousarray(frame["cloud"], np.float32)
+    T = np.ascontiguousarray(frame["T_cam_lidar"], np.float64)
+    pl = np.zeros(4)
+    n = lib.oracle_ground_plane(cloud.ctypes.data_as(_ffi.c_float_p), cloud.shape[0], _dp(T), C.byref(p), _dp(pl))
+    return n, pl
