@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="independent windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="independent windows per GPU per step")
     ap.add_argument("--n-kf", type=int, default=5)
     ap.add_argument("--n-lm", type=int, default=2000)
     ap.add_argument("--distinct", type=int, default=0, help="distinct windows generated per rank (0 = every window of the batch is different)")
@@ -110,6 +110,16 @@ def main():
         launches = max(1, stats["linearize_launches"])
         lin_ms = stats["linearize_ms"]
         achieved = alg_bytes / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else 0.0
+        # HBM traffic per launch: PMC counters cannot be collected inside this process; the committed rocprofv3
+        # FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_linearize.json, gfx950-corrected) give the ratio
+        # traffic / algorithmic bytes of the kernel, applied to this run's algorithmic bytes per launch
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_linearize.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                ratio = json.load(f)["traffic_over_algorithmic"]
+            traffic = ratio * alg_bytes / launches
+            traffic_src = "profiles/r01_pmc_linearize.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, ratio %.3f x algorithmic bytes/launch" % ratio
         out = {
             "metric": "keyframe-BA window solves/sec (5 KF, ~2k landmarks)",
             "value": value,
@@ -141,7 +151,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": stats["linearize_launches"],
                 "avg_launch_ms": lin_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,

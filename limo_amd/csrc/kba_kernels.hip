@@ -63,6 +63,12 @@ __global__ void k_solve_init(BatchView bv, SolveConsts c, int max_iter, int sele
     lm_solve_init(s, sel, max_iter, c);
 }
 
+// activity flags for host-side re-batching (worklists of the windows that still iterate)
+__global__ void k_export_active(BatchView bv, int32_t* flags) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < bv.n_win) flags[w] = bv.st[w].active;
+}
+
 __global__ void k_expire(BatchView bv) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= bv.n_win) return;
@@ -70,8 +76,8 @@ __global__ void k_expire(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ observations
-__global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, SolveConsts c) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.view_win[bv.blk_view[b]];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
@@ -85,12 +91,16 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, SolveConsts 
 #pragma unroll
     for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
     const int any_fail = __syncthreads_or(l.fail);
-    block_sum<kLinPartial>(vals, lds, bv.blk_part + (int64_t)b * kLinPartial);
+    if (c.pad == 21) {  // profiling aid: skip the workgroup reduction
+        if (threadIdx.x < kLinPartial) bv.blk_part[(int64_t)b * kLinPartial + threadIdx.x] = vals[0];
+    } else {
+        block_sum<kLinPartial>(vals, lds, bv.blk_part + (int64_t)b * kLinPartial);
+    }
     if (threadIdx.x == 0) bv.blk_fail[b] = any_fail;
 }
 
-__global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.st[w].active) return;
     __shared__ double lds[4];
@@ -113,8 +123,8 @@ __global__ void k_gp(BatchView bv, int candidate) {
 }
 
 // ------------------------------------------------------------------------------------------ landmarks
-__global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
@@ -135,8 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     int fail = 0;
@@ -145,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c)
     if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 5] = any ? 1.0 : 0.0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     __shared__ double lds[12];
@@ -159,10 +169,12 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
 // ------------------------------------------------------------------------------------------ Schur complement (MFMA)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline int schur_ld(int ncp) {  // LDS row stride (doubles): >= ncp and == 16 (mod 32)
-    int ld = ncp;
-    while ((ld & 31) != 16) ld += 16;
-    return ld;
+// LDS row stride (doubles) of the Schur tile.  ODD on purpose: the fill phase has the 32 lanes of a group write rows
+// k = 3*li + c (stride 3*ld doubles): with ld = 48 that is 288 dwords == 0 (mod 32 banks), a 32-way conflict on every
+// store; with ld = 49 the lanes land on distinct banks.  The MFMA operand reads (lanes along a row, 4 k-rows per
+// instruction) then overlap on two banks only.
+__host__ __device__ inline int schur_ld(int ncp) {
+    return ncp + 1;
 }
 
 constexpr int kSchurMaxTilesPerWave = 9;  // upper-triangular 16x16 tiles of a 128x128 system over 4 waves
@@ -172,8 +184,8 @@ __host__ __device__ inline int schur_lds_doubles(int nfp) {
     return 3 * kSchurLm * schur_ld(nfp) + 3 * kSchurLm + kMaxNc + (kMaxNc + kSchurMaxViews + 1) / 2;
 }
 
-__global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
-    const int sb = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_schur(BatchView bv, const int32_t* wl, int dbg) {
+    const int sb = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
@@ -201,10 +213,10 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
     const int n_lm_blk = bv.sblk_n[sb];
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         const int nl = min(kSchurLm, n_lm_blk - l0);
-        for (int i = threadIdx.x; i < 3 * kSchurLm * ld; i += kBlock) Z[i] = 0.0;
+        if (dbg != 34) for (int i = threadIdx.x; i < 3 * kSchurLm * ld; i += kBlock) Z[i] = 0.0;
         if (threadIdx.x < 3 * kSchurLm) tt[threadIdx.x] = 0.0;
         __syncthreads();
-        if (li < nl) {
+        if (li < nl && dbg != 31) {
             const int gl = bv.sblk_lm0[sb] + l0 + li;
             if (bv.lm_state[gl] == 1) {
                 const int gg = bv.lm_gp[gl];
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
 #pragma unroll
         for (int q = 0; q < kSchurMaxTilesPerWave; ++q) {
             const int tile = wave + 4 * q;
-            if (tile < n_upper) {
+            if (tile < n_upper && dbg != 32) {
                 int tr = 0, rem = tile;  // upper-triangular tile index -> (tr, tc)
                 while (rem >= T - tr) {
                     rem -= T - tr;
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
                 acc[q] = a4;
             }
         }
-        if ((int)threadIdx.x < nf) {
+        if ((int)threadIdx.x < nf && dbg != 33) {
             double s = 0.0;
             for (int k = 0; k < 3 * nl; ++k) s += Z[k * ld + threadIdx.x] * tt[k];
             rhs_acc += s;
@@ -285,8 +297,8 @@ __global__ __launch_bounds__(kBlock) void k_schur(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ camera system
-__global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveConsts c) {
-    const int w = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
     WinState& st = bv.st[w];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (st.active && st.need_lin) {
@@ -298,16 +310,16 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
     if (threadIdx.x == 0 && st.active) atomicAdd(bv.n_active, 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts c) {
-    const int w = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
     if (!bv.st[w].active) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
     cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, &flag);
 }
 
-__global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c) {
-    const int w = blockIdx.x;
+__global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
     if (!bv.st[w].active) return;
     __shared__ double red[64];
     reduce_step(bv, w, threadIdx.x, blockDim.x, red);

@@ -54,6 +54,13 @@ struct limo_ba_batch : Executor {
     int32_t* h_active = nullptr;  // pinned, 4 slots
     hipEvent_t act_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int it_no = 0;
+    // worklists of the windows that still iterate (nullptr = every workgroup): rebuilt on the host whenever the
+    // active set has halved, so late LM iterations only launch the workgroups that have work
+    int32_t *d_wl_blk = nullptr, *d_wl_lblk = nullptr, *d_wl_sblk = nullptr, *d_wl_win = nullptr, *d_flags = nullptr;
+    int32_t* h_flags = nullptr;  // pinned
+    std::vector<int32_t> h_wl;
+    bool use_wl = false;
+    int n_wl_blk = 0, n_wl_lblk = 0, n_wl_sblk = 0, n_wl_win = 0, listed = 0;
     int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0;
     int rc = LIMO_OK;
     // kernel timing (linearize) via HIP events on the batch's stream
@@ -68,6 +75,7 @@ struct limo_ba_batch : Executor {
     ~limo_ba_batch() override {
         for (void* p : allocs) (void)hipFree(p);
         if (h_active) (void)hipHostFree(h_active);
+        if (h_flags) (void)hipHostFree(h_flags);
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -116,6 +124,12 @@ struct limo_ba_batch : Executor {
         HIP_TRY(ctx, hipMemcpyAsync(d_lm0, P.lm.data(), sizeof(double) * P.lm.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_lm_state0, P.lm_state.data(), P.lm_state.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipHostMalloc((void**)&h_active, 64));
+        HIP_TRY(ctx, hipHostMalloc((void**)&h_flags, sizeof(int32_t) * std::max(1, P.n_win)));
+        if (dmalloc((void**)&d_wl_blk, sizeof(int32_t) * std::max(1, P.n_blk))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_wl_lblk, sizeof(int32_t) * std::max(1, P.n_lblk))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_wl_sblk, sizeof(int32_t) * std::max(1, P.n_sblk))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_wl_win, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_flags, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
         int max_nfp = 16;
         for (const WinDesc& d : P.win) max_nfp = std::max(max_nfp, (int)d.nf_pad);
@@ -162,15 +176,57 @@ struct limo_ba_batch : Executor {
 #define LAUNCH_CHECK(what) note(hipGetLastError(), what)
 
     // ---- Executor
+    void full_lists() {
+        use_wl = false;
+        n_wl_blk = P.n_blk;
+        n_wl_lblk = P.n_lblk;
+        n_wl_sblk = P.n_sblk;
+        n_wl_win = P.n_win;
+        listed = P.n_win;
+    }
+
+    // Rebuild the worklists from the windows that are active right now (synchronises the stream).
+    void rebatch() {
+        hipStream_t s = ctx->stream;
+        hipLaunchKernelGGL(k_export_active, dim3(cdiv(P.n_win, 256)), dim3(256), 0, s, bv, d_flags);
+        note(hipMemcpyAsync(h_flags, d_flags, sizeof(int32_t) * P.n_win, hipMemcpyDeviceToHost, s), "memcpy flags");
+        note(hipStreamSynchronize(s), "sync flags");
+        if (rc != LIMO_OK) return;
+        std::vector<int32_t> wb, wlb, wsb, ww;
+        for (int w = 0; w < P.n_win; ++w) {
+            if (!h_flags[w]) continue;
+            const WinDesc& d = P.win[w];
+            ww.push_back(w);
+            for (int i = 0; i < d.n_blk; ++i) wb.push_back(d.blk0 + i);
+            for (int i = 0; i < d.n_lblk; ++i) wlb.push_back(d.lblk0 + i);
+            for (int i = 0; i < d.n_sblk; ++i) wsb.push_back(d.sblk0 + i);
+        }
+        auto up = [&](int32_t* dst, const std::vector<int32_t>& v) {
+            if (!v.empty()) note(hipMemcpyAsync(dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s), "upload worklist");
+        };
+        up(d_wl_blk, wb);
+        up(d_wl_lblk, wlb);
+        up(d_wl_sblk, wsb);
+        up(d_wl_win, ww);
+        note(hipStreamSynchronize(s), "sync worklists");  // the host vectors go out of scope
+        use_wl = true;
+        n_wl_blk = (int)wb.size();
+        n_wl_lblk = (int)wlb.size();
+        n_wl_sblk = (int)wsb.size();
+        n_wl_win = (int)ww.size();
+        listed = n_wl_win;
+    }
+
     void solve_init(int max_iter, int select) override {
         it_no = 0;
+        full_lists();
         hipLaunchKernelGGL(k_solve_init, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv, c, max_iter, select);
         LAUNCH_CHECK("k_solve_init");
     }
 
     void linearize() override {
         hipStream_t s = ctx->stream;
-        if (P.n_blk) {
+        if (n_wl_blk) {
             EventPair* ep = nullptr;
             if (ev_used < 8192) {
                 if (ev_used == ev_pool.size()) {
@@ -182,7 +238,7 @@ struct limo_ba_batch : Executor {
                 ep = &ev_pool[ev_used++];
                 note(hipEventRecord(ep->a, s), "hipEventRecord");
             }
-            hipLaunchKernelGGL(k_linearize, dim3(P.n_blk), dim3(kBlock), 0, s, bv, c);
+            hipLaunchKernelGGL(k_linearize, dim3(n_wl_blk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_blk : nullptr);
             LAUNCH_CHECK("k_linearize");
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
@@ -190,8 +246,8 @@ struct limo_ba_batch : Executor {
             hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 0);
             LAUNCH_CHECK("k_gp");
         }
-        if (P.n_lblk) {
-            hipLaunchKernelGGL(k_lm_accum, dim3(P.n_lblk), dim3(kBlock), 0, s, bv, c);
+        if (n_wl_lblk) {
+            hipLaunchKernelGGL(k_lm_accum, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_lblk : nullptr);
             LAUNCH_CHECK("k_lm_accum");
         }
         // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
@@ -199,7 +255,7 @@ struct limo_ba_batch : Executor {
         note(hipMemsetAsync(bv.n_active + slot, 0, sizeof(int32_t), s), "memset n_active");
         BatchView bvs = bv;
         bvs.n_active = bv.n_active + slot;
-        hipLaunchKernelGGL(k_cam_assemble, dim3(P.n_win), dim3(kBlock), asm_bytes, s, bvs, c);
+        if (n_wl_win) hipLaunchKernelGGL(k_cam_assemble, dim3(n_wl_win), dim3(kBlock), asm_bytes, s, bvs, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_cam_assemble");
         note(hipMemcpyAsync(h_active + slot, bv.n_active + slot, sizeof(int32_t), hipMemcpyDeviceToHost, s), "memcpy n_active");
         note(hipEventRecord(act_ev[slot], s), "record n_active");
@@ -213,7 +269,11 @@ struct limo_ba_batch : Executor {
         if (cur == 0) return P.n_win;  // iteration zero: nothing to wait for yet
         const int slot = (cur - 1) & 3;
         note(hipEventSynchronize(act_ev[slot]), "sync n_active");
-        return rc == LIMO_OK ? h_active[slot] : 0;
+        if (rc != LIMO_OK) return 0;
+        const int a = h_active[slot];
+        // re-batch when at most half of the listed windows still iterate (and the list is worth shrinking)
+        if (a > 0 && listed >= 8 && 2 * a <= listed) rebatch();
+        return a;
     }
 
     void expire(int) override {
@@ -223,29 +283,29 @@ struct limo_ba_batch : Executor {
 
     void step() override {
         hipStream_t s = ctx->stream;
-        if (P.n_lblk) {
-            hipLaunchKernelGGL(k_lm_damp, dim3(P.n_lblk), dim3(kBlock), 0, s, bv, c);
+        if (n_wl_lblk) {
+            hipLaunchKernelGGL(k_lm_damp, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_lblk : nullptr);
             LAUNCH_CHECK("k_lm_damp");
         }
-        if (P.n_sblk) {
-            hipLaunchKernelGGL(k_schur, dim3(P.n_sblk), dim3(kBlock), max_ld_bytes, s, bv);
+        if (n_wl_sblk) {
+            hipLaunchKernelGGL(k_schur, dim3(n_wl_sblk), dim3(kBlock), max_ld_bytes, s, bv, use_wl ? d_wl_sblk : nullptr, (int)c.pad);
             LAUNCH_CHECK("k_schur");
         }
-        hipLaunchKernelGGL(k_cam_solve, dim3(P.n_win), dim3(kBlock), solve_bytes, s, bv, c);
+        if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_cam_solve");
-        if (P.n_lblk) {
-            hipLaunchKernelGGL(k_backsub, dim3(P.n_lblk), dim3(kBlock), 0, s, bv);
+        if (n_wl_lblk) {
+            hipLaunchKernelGGL(k_backsub, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, use_wl ? d_wl_lblk : nullptr);
             LAUNCH_CHECK("k_backsub");
         }
-        if (P.n_blk) {
-            hipLaunchKernelGGL(k_cost, dim3(P.n_blk), dim3(kBlock), 0, s, bv, c);
+        if (n_wl_blk) {
+            hipLaunchKernelGGL(k_cost, dim3(n_wl_blk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_blk : nullptr);
             LAUNCH_CHECK("k_cost");
         }
         if (P.TG) {
             hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 1);
             LAUNCH_CHECK("k_gp(cand)");
         }
-        hipLaunchKernelGGL(k_step_decide, dim3(P.n_win), dim3(64), 0, s, bv, c);
+        if (n_wl_win) hipLaunchKernelGGL(k_step_decide, dim3(n_wl_win), dim3(64), 0, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_step_decide");
         hipLaunchKernelGGL(k_accept, dim3(cdiv((int64_t)P.TK + P.TL, 256)), dim3(256), 0, s, bv);
         LAUNCH_CHECK("k_accept");
