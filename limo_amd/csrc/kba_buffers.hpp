@@ -49,6 +49,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(cpresent, TK * kCamSlots, P.cpresent.data());
     KBA_BUF(cslot, TK * kCamSlots * I, P.cslot.data());
     KBA_BUF(lm_win, TL * I, P.lm_win.data());
+    KBA_BUF(lm_id, TL * I, P.lm_id.data());
     KBA_BUF(lm_weight, TL * D, P.lm_weight.data());
     KBA_BUF(lm_state, TL, P.lm_state.data());
     KBA_BUF(lm_gp, TL * I, P.lm_gp.data());
@@ -78,8 +79,9 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(gp_cost, TG * D, nullptr);
     KBA_BUF(gp_cost_c, TG * D, nullptr);
     KBA_BUF(obs_r, (size_t)P.SO * 3 * D, nullptr);
-    KBA_BUF(obs_Jp, (size_t)P.SO * 18 * D, nullptr);
-    KBA_BUF(obs_Jl, (size_t)P.SO * 9 * D, nullptr);
+    KBA_BUF(obs_Ft, (size_t)(P.evaluate_only ? 1 : P.SO * 9) * D, nullptr);
+    KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
+    KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
     KBA_BUF(blk_part, NB * kLinPartial * D, nullptr);
     KBA_BUF(blk_fail, NB * I, nullptr);
     KBA_BUF(blk_cost_c, NB * D, nullptr);

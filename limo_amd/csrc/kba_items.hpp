@@ -53,8 +53,8 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
     }
     if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
         for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
-        for (int i = 0; i < 18; ++i) bv.obs_Jp[i * bv.SO + o] = oo.Jp[i];
-        for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
+        for (int row = 0; row < 3; ++row)  // Ft = translation columns of Jp (see BatchView::obs_Ft)
+            for (int j = 0; j < 3; ++j) bv.obs_Ft[(row * 3 + j) * bv.SO + o] = oo.Jp[row * 6 + 3 + j];
     } else if (oo.cost == 1.2345) {
         bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
     }
@@ -152,9 +152,11 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
     for (int j = 0; j < wd.n_view; ++j) {
         const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
         if (s < 0) continue;
-        double E[9], r[3];
-        for (int i = 0; i < 9; ++i) E[i] = bv.obs_Jl[i * bv.SO + s];
+        double E[9], Ft[9], R[9], r[3];
+        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
         for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
+        quat_R(bv.pose + 7 * (int64_t)bv.view_kf[wd.view0 + j], R);
+        mat3_mul(Ft, R, E);
         for (int row = 0; row < 3; ++row) {
             const double e0 = E[row * 3], e1 = E[row * 3 + 1], e2 = E[row * 3 + 2];
             V[0] += e0 * e0;
@@ -222,57 +224,103 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
 }
 
 // ======================================================================================= Schur tiles
-// The Schur complement only involves the FREE camera slots of a window; they are numbered compactly
-// (cslot: full local slot -> compact index or -1; nf free slots, nf_pad rounded up to 16).
-// Z tile layout: Z[k * ld + row], k = 3*li + c' (li = landmark within tile), row = compact camera slot.
-// Y' = W' L^-T with W' = S_c F^T E S_l;  sum_i Y'_i Y'_i^T = W' (V'+D^2)^-1 W'^T.
-// lmk[9] = {sl[3], Li[6]} of the landmark (loaded once per lane), cs / sc = the window's compact-slot table and
-// camera scale by FULL local slot (LDS on the device).  All global loads are issued before any use so that the
-// 27 plane reads of an observation are in flight together.
-KBA_HD void schur_fill_view(const BatchView& bv, int gl, int li, int j, int kl, const double* lmk, const int* cs,
-                            const double* sc, double* Z, int ld) {
-    const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
-    if (s < 0) return;
-    double E[9], F[18];
+// The Schur complement only involves the FREE camera slots of a window; they are numbered compactly (cslot: full
+// local slot -> compact index or -1), pose slots first.  A Schur tile row (landmark i, coordinate c') is
+//   Z[3i+c'][col(r)] = Y'_i[r][c'],   Y'_i = S_c F^T E S_l L^-T   (r over the free slots),   Z[3i+c'][nfq] = t_i[c']
+// with col(r) = r + (r >= nfq): the rhs rides along as one more column, so  Z^T Z  delivers  sum Y'Y'^T  AND
+// sum Y' t  in one symmetric rank-k update.  Landmarks without a ground-plane row only fill pose columns.
+//
+// schur_pair_block: the 3 x 10 block of Y' that landmark gl contributes to keyframe kl (local index): all of the
+// keyframe's views of the landmark (F = Ft [M | I], E = Ft R rebuilt from the factored planes) plus its ground-plane
+// row when that row is attached to kl.  Y[a*3 + c'] for local slot a; masked slots are left zero.
+//   lmk = landmark scale (3) | L^-1 (6, lower, row-major);  sc = Jacobi scale of the window's slots (local index);
+//   vkl[j] = local keyframe of view j.
+// Pose part of one observation:  Y[a*3 + c'] += sc[a] (F^T E)[a][c] s_c Li[c'][c]   for the six pose slots, with
+// F^T E = [M^T G ; G],  G = Ft^T Ft R  (F = Ft [M | I], E = Ft R).
+KBA_HD void schur_pose_block(const double* Ft, const double* R, const double* M, const double* lmk, const double* sc6,
+                             double* Y) {
+    // A = Ft^T Ft (symmetric)
+    const double a00 = Ft[0] * Ft[0] + Ft[3] * Ft[3] + Ft[6] * Ft[6];
+    const double a01 = Ft[0] * Ft[1] + Ft[3] * Ft[4] + Ft[6] * Ft[7];
+    const double a02 = Ft[0] * Ft[2] + Ft[3] * Ft[5] + Ft[6] * Ft[8];
+    const double a11 = Ft[1] * Ft[1] + Ft[4] * Ft[4] + Ft[7] * Ft[7];
+    const double a12 = Ft[1] * Ft[2] + Ft[4] * Ft[5] + Ft[7] * Ft[8];
+    const double a22 = Ft[2] * Ft[2] + Ft[5] * Ft[5] + Ft[8] * Ft[8];
+    double G[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) E[i] = bv.obs_Jl[i * bv.SO + s];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) F[i] = bv.obs_Jp[i * bv.SO + s];
-    const int row0 = kl * kCamSlots;
-    if (cs[row0] < 0) return;  // pose block constant: all six slots masked together
+    for (int j = 0; j < 3; ++j) {
+        G[0 + j] = a00 * R[j] + a01 * R[3 + j] + a02 * R[6 + j];
+        G[3 + j] = a01 * R[j] + a11 * R[3 + j] + a12 * R[6 + j];
+        G[6 + j] = a02 * R[j] + a12 * R[3 + j] + a22 * R[6 + j];
+    }
+    // landmark-side factor  B[c][c'] = s_c Li[c'][c]  (Li lower triangular, row-major 6)
+    const double b00 = lmk[0] * lmk[3], b01 = lmk[0] * lmk[4], b02 = lmk[0] * lmk[6];
+    const double b11 = lmk[1] * lmk[5], b12 = lmk[1] * lmk[7];
+    const double b22 = lmk[2] * lmk[8];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        const int r = cs[row0 + a];
-        const double f0 = F[a], f1 = F[6 + a], f2 = F[12 + a];
-        const double sca = sc[row0 + a];
-        const double w0 = sca * (f0 * E[0] + f1 * E[3] + f2 * E[6]) * lmk[0];
-        const double w1 = sca * (f0 * E[1] + f1 * E[4] + f2 * E[7]) * lmk[1];
-        const double w2 = sca * (f0 * E[2] + f1 * E[5] + f2 * E[8]) * lmk[2];
-        // Y'[a][c'] = sum_c W[a][c] Li[c'][c]
-        Z[(3 * li + 0) * ld + r] += w0 * lmk[3];
-        Z[(3 * li + 1) * ld + r] += w0 * lmk[4] + w1 * lmk[5];
-        Z[(3 * li + 2) * ld + r] += w0 * lmk[6] + w1 * lmk[7] + w2 * lmk[8];
+        double w0, w1, w2;
+        if (a < 3) {  // rotation slots: row a of M^T G
+            w0 = M[a] * G[0] + M[3 + a] * G[3] + M[6 + a] * G[6];
+            w1 = M[a] * G[1] + M[3 + a] * G[4] + M[6 + a] * G[7];
+            w2 = M[a] * G[2] + M[3 + a] * G[5] + M[6 + a] * G[8];
+        } else {
+            w0 = G[(a - 3) * 3];
+            w1 = G[(a - 3) * 3 + 1];
+            w2 = G[(a - 3) * 3 + 2];
+        }
+        const double sca = sc6[a];
+        Y[a * 3 + 0] += sca * (w0 * b00);
+        Y[a * 3 + 1] += sca * (w0 * b01 + w1 * b11);
+        Y[a * 3 + 2] += sca * (w0 * b02 + w1 * b12 + w2 * b22);
     }
 }
 
-KBA_HD void schur_fill_gp(const BatchView& bv, int gg, int li, int kl, const double* lmk, const int* cs,
-                          const double* sc, double* Z, int ld) {
-    double E[3], F[10];
+// Ground-plane row of landmark gl (row gg, attached to the keyframe whose free mask is cm / scale sc10).
+KBA_HD void schur_gp_block(const BatchView& bv, int gg, const uint8_t* cm, const double* lmk, const double* sc10, double* Y) {
+    double E[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = bv.gp_E[i * bv.SG + gg];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) F[i] = bv.gp_F[i * bv.SG + gg];
-    const int row0 = kl * kCamSlots;
+    const double e0 = E[0] * lmk[0], e1 = E[1] * lmk[1], e2 = E[2] * lmk[2];
+    const double y0 = e0 * lmk[3], y1 = e0 * lmk[4] + e1 * lmk[5], y2 = e0 * lmk[6] + e1 * lmk[7] + e2 * lmk[8];
 #pragma unroll
     for (int a = 0; a < kCamSlots; ++a) {
-        const int r = cs[row0 + a];
-        if (r < 0) continue;
-        const double f = F[a] * sc[row0 + a];
-        const double w0 = f * E[0] * lmk[0], w1 = f * E[1] * lmk[1], w2 = f * E[2] * lmk[2];
-        Z[(3 * li + 0) * ld + r] += w0 * lmk[3];
-        Z[(3 * li + 1) * ld + r] += w0 * lmk[4] + w1 * lmk[5];
-        Z[(3 * li + 2) * ld + r] += w0 * lmk[6] + w1 * lmk[7] + w2 * lmk[8];
+        if (!cm[a]) continue;
+        const double f = bv.gp_F[a * bv.SG + gg] * sc10[a];
+        Y[a * 3 + 0] += f * y0;
+        Y[a * 3 + 1] += f * y1;
+        Y[a * 3 + 2] += f * y2;
     }
+}
+
+KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int kl, const double* lmk, const double* sc,
+                             const int* vkl, bool with_plane, double* Y) {
+    for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
+    const int row0 = kl * kCamSlots;
+    const uint8_t* cm = bv.cmask + (int64_t)wd.cam0 + row0;
+    if (cm[0]) {  // pose block free (all six slots are masked together)
+        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + kl);
+        double R[9], M[9];
+        bool have = false;
+        for (int j = 0; j < wd.n_view; ++j) {
+            if (vkl[j] != kl) continue;
+            const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+            if (s < 0) continue;
+            if (!have) {
+                quat_R(pose, R);
+                rot_tangent_jac(pose, bv.lm + 3 * (int64_t)gl, M);
+                have = true;
+            }
+            double Ft[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+            schur_pose_block(Ft, R, M, lmk, sc + row0, Y);
+        }
+    }
+    if (!with_plane) return;
+    const int gg = bv.lm_gp[gl];
+    if (gg < 0 || bv.gp_kf[gg] - wd.kf0 != kl) return;
+    schur_gp_block(bv, gg, cm, lmk, sc + row0, Y);
 }
 
 KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
@@ -280,6 +328,11 @@ KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
     for (int i = 0; i < 3; ++i) lmk[i] = bv.lm_scale[i * bv.SL + gl];
 #pragma unroll
     for (int i = 0; i < 6; ++i) lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
+}
+
+// column of compact slot i in the Schur tile / slab (the rhs sits at column nfq)
+KBA_HD int schur_col(int i, int nfq) {
+    return i + (i >= nfq ? 1 : 0);
 }
 
 // ======================================================================================= back-substitution
@@ -303,15 +356,19 @@ KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
         if (s < 0) continue;
         const int gk = bv.view_kf[wd.view0 + j];
         const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
-        double q[3];
-        for (int row = 0; row < 3; ++row) {
-            double acc = 0.0;
-            for (int k = 0; k < 6; ++k) acc += bv.obs_Jp[(row * 6 + k) * bv.SO + s] * dc[k];
-            q[row] = acc;
-        }
-        for (int cc = 0; cc < 3; ++cc)
-            a[cc] += bv.obs_Jl[(0 * 3 + cc) * bv.SO + s] * q[0] + bv.obs_Jl[(1 * 3 + cc) * bv.SO + s] * q[1] +
-                     bv.obs_Jl[(2 * 3 + cc) * bv.SO + s] * q[2];
+        // F dc = Ft (M d_rot + d_trans);  E^T (F dc) = R^T Ft^T (F dc)
+        const double* pose = bv.pose + 7 * (int64_t)gk;
+        double Ft[9], R[9], M[9], m[3], q[3], v[3];
+        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+        quat_R(pose, R);
+        rot_tangent_jac(pose, x, M);
+        mat3_vec(M, dc, m);
+        m[0] += dc[3];
+        m[1] += dc[4];
+        m[2] += dc[5];
+        mat3_vec(Ft, m, q);
+        for (int cc = 0; cc < 3; ++cc) v[cc] = Ft[cc] * q[0] + Ft[3 + cc] * q[1] + Ft[6 + cc] * q[2];
+        for (int cc = 0; cc < 3; ++cc) a[cc] += R[cc] * v[0] + R[3 + cc] * v[1] + R[6 + cc] * v[2];
     }
     const int gg = bv.lm_gp[gl];
     if (gg >= 0) {
@@ -794,7 +851,8 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     const int32_t* cs = bv.cslot + wd.cam0;
     double* yc = bv.yc + wd.cam0;
     double* dc = bv.delta_c + wd.cam0;
-    const int slab = nfp * nfp + nfp;
+    const int slab = nfp * nfp;
+    const int nfq = wd.nfq;
     (void)flag;
     for (int a = tid; a < nc; a += nt)
         if (cs[a] >= 0) fl[cs[a]] = a;
@@ -811,10 +869,11 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             const int b = fl[cb];
             s = sc[a] * sc[b] * Hg[a * nc + b];
             if (ca == cb) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-            off = (int64_t)ca * nfp + cb;
+            off = (int64_t)schur_col(ca, nfq) * nfp + schur_col(cb, nfq);
         } else {
             s = sc[a] * bv.gc[wd.cam0 + a];
-            off = (int64_t)nfp * nfp + ca;
+            const int za = schur_col(ca, nfq);  // upper-triangle entry (za, nfq) or (nfq, za)
+            off = za < nfq ? (int64_t)za * nfp + nfq : (int64_t)nfq * nfp + za;
         }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int q = 0;
@@ -1006,9 +1065,9 @@ KBA_HD void trim_max_lane(const BatchView& bv, int gl, const double* plane_rep, 
 }
 
 // Rank-based quantile selection (TrimmerQuantile::getOutliers, trimmer_quantile.hpp:40-63): an element is an
-// outlier iff its rank in (value, id) order is >= int(n_groups * quantile).  Returns 1 if landmark li (local
-// index) of window wd is an outlier of the list `vals`.
-KBA_HD int trim_is_outlier(const double* vals, int n_lm, int li, double quantile, int min_groups) {
+// outlier iff its rank in (value, id) order is >= int(n_groups * quantile).  Returns 1 if landmark li (packed local
+// index) is an outlier of the list `vals`; ids = the landmarks' indices in the caller's window (tie order).
+KBA_HD int trim_is_outlier(const double* vals, const int32_t* ids, int n_lm, int li, double quantile, int min_groups) {
     const double v = vals[li];
     if (v < 0.0) return 0;
     int n_groups = 0, rank = 0;
@@ -1016,7 +1075,7 @@ KBA_HD int trim_is_outlier(const double* vals, int n_lm, int li, double quantile
         const double u = vals[j];
         if (u < 0.0) continue;
         ++n_groups;
-        if (u < v || (u == v && j < li)) ++rank;
+        if (u < v || (u == v && ids[j] < ids[li])) ++rank;
     }
     if (n_groups < min_groups) return 0;
     const int num = (int)((double)n_groups * quantile);

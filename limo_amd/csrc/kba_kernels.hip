@@ -9,7 +9,7 @@
 // k_gp            1 per ground-plane row     -       GroundPlaneHeightRegularization (cost_functors_ceres.hpp:355-392)
 // k_lm_accum      1 per landmark             HBM     E^T E, E^T r (SchurEliminator chunk), Jacobi column scale
 // k_lm_damp       1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark
-// k_schur         workgroup per 256 lm       MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
+// k_schur<T>      wave per 256 lm            MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
 // k_cam_assemble  workgroup per window       -       camera-camera blocks, regularisers, IterationZero / step tail
 // k_cam_solve     workgroup per window       -       reduced camera system: dense Cholesky in LDS, camera step
 // k_backsub       1 per landmark             HBM     BackSubstitute + candidate point + model-cost-change parts
@@ -167,133 +167,247 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------ Schur complement (MFMA)
+// One WAVE per Schur workgroup (<= 256 landmarks of one window), no cross-wave synchronisation:
+//   per tile of 16 landmarks   fill:  lane (li = lane&15, kq = lane>>4) builds the 3 x 10 block of Y' of landmark li
+//                                     and free keyframe kq (+4, +8: one pass for up to four free keyframes) from the
+//                                     factored Jacobian planes and WRITES it (zeros included: no clearing, no
+//                                     read-modify-write) into the LDS tile Z[48][ld];
+//                              syrk:  12 k-steps of v_mfma_f64_16x16x4_f64; the 16-column panels of a k-step are read
+//                                     from LDS once and feed every upper tile (tr <= tc) of Z^T Z held in registers.
+//   Tiles of plain landmarks stop at the pose panels (columns [0, nfq]); ground-plane landmarks come last in every
+//   window (kba_pack.cpp), their tiles cover all panels.  The rhs rides along as column nfq (kba_items.hpp).
+// LDS per wave: 48 x (16 T + 1) doubles (18.8 KB at T = 3) -> 8 waves per CU overlap fill (VALU / memory) and syrk
+// (matrix pipe) of different workgroups.  TM = compile-time bound on T = nf_pad / 16.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// LDS row stride (doubles) of the Schur tile.  ODD on purpose: the fill phase has the 32 lanes of a group write rows
-// k = 3*li + c (stride 3*ld doubles): with ld = 48 that is 288 dwords == 0 (mod 32 banks), a 32-way conflict on every
-// store; with ld = 49 the lanes land on distinct banks.  The MFMA operand reads (lanes along a row, 4 k-rows per
-// instruction) then overlap on two banks only.
-__host__ __device__ inline int schur_ld(int ncp) {
-    return ncp + 1;
+// LDS row stride (doubles) of the Schur tile: odd, so the rows of one MFMA operand (4 consecutive k) and the rows
+// written by neighbouring landmarks (stride 3 rows) spread over the banks.
+__host__ __device__ inline int schur_ld(int nfp) {
+    return nfp + 1;
 }
 
-constexpr int kSchurMaxTilesPerWave = 9;  // upper-triangular 16x16 tiles of a 128x128 system over 4 waves
 constexpr int kSchurMaxViews = 64;
 
-__host__ __device__ inline int schur_lds_doubles(int nfp) {
-    return 3 * kSchurLm * schur_ld(nfp) + 3 * kSchurLm + kMaxNc + (kMaxNc + kSchurMaxViews + 1) / 2;
+__host__ __device__ inline int schur_lds_bytes(int nfp) {
+    return (3 * kSchurLm * schur_ld(nfp) + kMaxNc) * (int)sizeof(double) + (kMaxNc + kSchurMaxViews + kMaxKf + 4) * (int)sizeof(int);
 }
 
-__global__ __launch_bounds__(kBlock) void k_schur(BatchView bv, const int32_t* wl, int dbg) {
+// What a lane of the fast path holds one tile ahead (its landmark of the next tile, its keyframe is fixed).
+struct SchurPre {
+    double Ft[9];   // factored Jacobian of the (landmark, keyframe) observation
+    double lmk[9];  // landmark scale (3) | L^-1 (6)
+    double p[3];    // landmark position
+    double t[3];    // L^-1 S g (lanes kq == 0 only)
+    int gl;
+    bool live, seen;  // landmark in the problem; it has an observation in this lane's keyframe
+};
+
+// FAST: every window of the batch has at most four keyframes with free slots and one view per keyframe (checked on
+// the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
+template <int TM, bool FAST>
+__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl) {
     const int sb = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
-    const int nc = wd.nc, nf = wd.nf, nfp = wd.nf_pad, ld = schur_ld(nfp);
+    const int nc = wd.nc, nfp = wd.nf_pad, nfq = wd.nfq, ld = schur_ld(nfp);
+    const int T = nfp / 16, Tq = (nfq + 16) / 16;  // panels of a full tile / of a pose-only tile (columns 0..nfq)
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Z = smem;                        // [3*kSchurLm][ld]
-    double* tt = Z + 3 * kSchurLm * ld;      // [3*kSchurLm]
-    double* sc_s = tt + 3 * kSchurLm;        // [kMaxNc] camera column scale by full local slot
-    int* cs_s = reinterpret_cast<int*>(sc_s + kMaxNc);  // [kMaxNc] compact slot or -1
-    int* vkl = cs_s + kMaxNc;                // [kSchurMaxViews] keyframe (local) of each view
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < nc; i += kBlock) {
+    double* Z = smem;                                    // [3*kSchurLm][ld]
+    double* sc_s = Z + 3 * kSchurLm * ld;                // [kMaxNc] Jacobi scale by local slot
+    int* zc_s = reinterpret_cast<int*>(sc_s + kMaxNc);   // [kMaxNc] tile column of a local slot or -1
+    int* vkl = zc_s + kMaxNc;                            // [kSchurMaxViews] local keyframe of each view
+    int* fk = vkl + kSchurMaxViews;                      // [kMaxKf] local keyframes with a free slot; [kMaxKf] count,
+                                                         // [kMaxKf+1] fast-path flag
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nc; i += 64) {
         sc_s[i] = bv.scale_c[wd.cam0 + i];
-        cs_s[i] = bv.cslot[wd.cam0 + i];
+        const int ci = bv.cslot[wd.cam0 + i];
+        zc_s[i] = ci < 0 ? -1 : schur_col(ci, nfq);
     }
-    for (int j = threadIdx.x; j < wd.n_view; j += kBlock) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
-    const int T = nfp / 16;
-    const int n_upper = T * (T + 1) / 2;
-    v4f64 acc[kSchurMaxTilesPerWave];
+    for (int j = lane; j < wd.n_view; j += 64) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
+    for (int i = lane; i < 3 * kSchurLm * ld; i += 64) Z[i] = 0.0;
+    __syncthreads();
+    if (lane == 0) {
+        int n = 0, mono = 1;
+        for (int k = 0; k < wd.n_kf; ++k) {
+            if (zc_s[k * kCamSlots] >= 0 || zc_s[k * kCamSlots + 6] >= 0) fk[n++] = k;
+            int nv = 0;
+            for (int j = 0; j < wd.n_view; ++j) nv += vkl[j] == k;
+            if (nv > 1) mono = 0;
+        }
+        fk[kMaxKf] = n;
+        fk[kMaxKf + 1] = (n <= 4 && mono) ? 1 : 0;  // one (landmark, keyframe) pair per lane, one view per keyframe
+    }
+    __syncthreads();
+    const int nfk = fk[kMaxKf];
+    constexpr bool fast = FAST;
+    constexpr int NT = TM * (TM + 1) / 2;
+    v4f64 acc[NT];
 #pragma unroll
-    for (int i = 0; i < kSchurMaxTilesPerWave; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    double rhs_acc = 0.0;
-    const int li = threadIdx.x & (kSchurLm - 1);
-    const int grp = threadIdx.x / kSchurLm;  // 0..7 : owns keyframes kf_local == grp (mod 8)
-    const int n_lm_blk = bv.sblk_n[sb];
+    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int li = lane & 15, kq = lane >> 4;
+    const int n_lm_blk = bv.sblk_n[sb], lm_first = bv.sblk_lm0[sb];
+
+    // ---- fast path: lane constants (its keyframe) and the software pipeline over tiles
+    const int my_kl = (fast && kq < nfk) ? fk[kq] : -1;
+    int my_view = -1;
+    bool pose_free = false;
+    double Rk[9], qk[4];
+    if (my_kl >= 0) {
+        for (int j = 0; j < wd.n_view; ++j)
+            if (vkl[j] == my_kl) my_view = j;
+        pose_free = zc_s[my_kl * kCamSlots] >= 0;
+        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + my_kl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qk[i] = pose[i];
+        quat_R(qk, Rk);
+    }
+    const int32_t* my_slots = bv.lm_slot + (int64_t)(my_view >= 0 ? my_view : 0) * bv.SL;
+    auto fetch_index = [&](int l0, int& gl, int& st, int& slot) {
+        gl = lm_first + l0 + li;
+        st = 0;
+        slot = -1;
+        if (l0 + li < n_lm_blk) {
+            st = bv.lm_state[gl];
+            if (my_view >= 0 && pose_free) slot = my_slots[gl];
+        }
+    };
+    auto fetch_data = [&](int gl, int st, int slot, SchurPre& P) {
+        P.gl = gl;
+        P.live = st == 1;
+        P.seen = P.live && slot >= 0;
+        if (P.live && my_kl >= 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.lmk[i] = bv.lm_scale[i * bv.SL + gl];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) P.lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
+        }
+        if (P.live && kq == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.t[i] = bv.lm_t[i * bv.SL + gl];
+        }
+        if (P.seen) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P.p[i] = bv.lm[3 * (int64_t)gl + i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) P.Ft[i] = bv.obs_Ft[i * bv.SO + slot];
+        }
+    };
+    SchurPre nxt;
+    int n_gl = 0, n_st = 0, n_slot = -1;  // indices of the tile after next
+    if constexpr (FAST) {
+        int gl0, st0, slot0;
+        fetch_index(0, gl0, st0, slot0);
+        fetch_index(kSchurLm, n_gl, n_st, n_slot);
+        fetch_data(gl0, st0, slot0, nxt);
+    }
+
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         const int nl = min(kSchurLm, n_lm_blk - l0);
-        if (dbg != 34) for (int i = threadIdx.x; i < 3 * kSchurLm * ld; i += kBlock) Z[i] = 0.0;
-        if (threadIdx.x < 3 * kSchurLm) tt[threadIdx.x] = 0.0;
-        __syncthreads();
-        if (li < nl && dbg != 31) {
-            const int gl = bv.sblk_lm0[sb] + l0 + li;
-            if (bv.lm_state[gl] == 1) {
-                const int gg = bv.lm_gp[gl];
-                const int gkl = gg >= 0 ? bv.gp_kf[gg] - wd.kf0 : -1;
-                bool mine = (gkl >= 0 && (gkl & 7) == grp) || grp == 0;
-                for (int j = 0; j < wd.n_view && !mine; ++j) mine = (vkl[j] & 7) == grp;
-                if (mine) {
-                    double lmk[9];
-                    schur_load_lm(bv, gl, lmk);
-                    for (int j = 0; j < wd.n_view; ++j) {
-                        const int kl = vkl[j];
-                        if ((kl & 7) != grp) continue;
-                        schur_fill_view(bv, gl, li, j, kl, lmk, cs_s, sc_s, Z, ld);
+        const bool tile_gp = lm_first + l0 + nl > wd.lm_gp0;  // wave-uniform
+        const int Tt = tile_gp ? T : Tq;
+        if constexpr (FAST) {
+            const SchurPre cur = nxt;
+            // issue the loads of the next tile (and the indices of the one after) before this tile's arithmetic
+            fetch_data(n_gl, n_st, n_slot, nxt);
+            fetch_index(l0 + 2 * kSchurLm, n_gl, n_st, n_slot);
+            if (kq == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Z[(3 * li + c) * ld + nfq] = cur.live ? cur.t[c] : 0.0;
+            }
+            if (my_kl >= 0) {
+                double Y[3 * kCamSlots];
+#pragma unroll
+                for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
+                if (cur.seen) {
+                    double M[9];
+                    rot_tangent_jac(qk, cur.p, M);
+                    schur_pose_block(cur.Ft, Rk, M, cur.lmk, sc_s + my_kl * kCamSlots, Y);
+                }
+                if (tile_gp && cur.live) {
+                    const int gg = bv.lm_gp[cur.gl];
+                    if (gg >= 0 && bv.gp_kf[gg] - wd.kf0 == my_kl)
+                        schur_gp_block(bv, gg, bv.cmask + (int64_t)wd.cam0 + my_kl * kCamSlots, cur.lmk,
+                                       sc_s + my_kl * kCamSlots, Y);
+                }
+#pragma unroll
+                for (int a = 0; a < kCamSlots; ++a) {
+                    if (a < 6 || tile_gp) {
+                        const int zc = zc_s[my_kl * kCamSlots + a];
+                        if (zc >= 0) {
+                            Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
+                            Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
+                            Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
+                        }
                     }
-                    if (gkl >= 0 && (gkl & 7) == grp) schur_fill_gp(bv, gg, li, gkl, lmk, cs_s, sc_s, Z, ld);
-                    if (grp == 0) {
-                        tt[3 * li + 0] = bv.lm_t[0 * bv.SL + gl];
-                        tt[3 * li + 1] = bv.lm_t[1 * bv.SL + gl];
-                        tt[3 * li + 2] = bv.lm_t[2 * bv.SL + gl];
+                }
+            }
+        } else {
+            const int gl = lm_first + l0 + li;
+            const bool live = li < nl && bv.lm_state[gl] == 1;
+            double lmk[9];
+            if (live) schur_load_lm(bv, gl, lmk);
+            if (kq == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Z[(3 * li + c) * ld + nfq] = live ? bv.lm_t[c * bv.SL + gl] : 0.0;
+            }
+            for (int q = kq; q < nfk; q += 4) {
+                const int kl = fk[q];
+                double Y[3 * kCamSlots];
+                if (live) {
+                    schur_pair_block(bv, wd, gl, kl, lmk, sc_s, vkl, tile_gp, Y);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < kCamSlots; ++a) {
+                    if (a < 6 || tile_gp) {
+                        const int zc = zc_s[kl * kCamSlots + a];
+                        if (zc >= 0) {
+                            Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
+                            Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
+                            Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        // SYRK on the tile: D[tr][tc] += sum_k Z[k][tr*16+i] * Z[k][tc*16+j]
+        // Z^T Z, upper tiles: D[tr][tc] += sum_k Z[k][16 tr + i] Z[k][16 tc + j]   (A and B share the lane mapping)
         const int ksteps = (3 * nl + 3) / 4;
+        const double* zp = Z + kq * ld + li;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            double pan[TM];
 #pragma unroll
-        for (int q = 0; q < kSchurMaxTilesPerWave; ++q) {
-            const int tile = wave + 4 * q;
-            if (tile < n_upper && dbg != 32) {
-                int tr = 0, rem = tile;  // upper-triangular tile index -> (tr, tc)
-                while (rem >= T - tr) {
-                    rem -= T - tr;
-                    ++tr;
+            for (int t = 0; t < TM; ++t) pan[t] = t < Tt ? zp[ks * 4 * ld + 16 * t] : 0.0;
+            int idx = 0;
+#pragma unroll
+            for (int tr = 0; tr < TM; ++tr)
+#pragma unroll
+                for (int tc = tr; tc < TM; ++tc) {
+                    if (tc < Tt) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[tr], pan[tc], acc[idx], 0, 0, 0);
+                    ++idx;
                 }
-                const int tc = tr + rem;
-                const double* za = Z + (lane >> 4) * ld + tr * 16 + (lane & 15);
-                const double* zb = Z + (lane >> 4) * ld + tc * 16 + (lane & 15);
-                v4f64 a4 = acc[q];
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    const double a = za[ks * 4 * ld];
-                    const double bb = zb[ks * 4 * ld];
-                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, a4, 0, 0, 0);
-                }
-                acc[q] = a4;
-            }
-        }
-        if ((int)threadIdx.x < nf && dbg != 33) {
-            double s = 0.0;
-            for (int k = 0; k < 3 * nl; ++k) s += Z[k * ld + threadIdx.x] * tt[k];
-            rhs_acc += s;
         }
         __syncthreads();
     }
-    const int slab = nfp * nfp + nfp;
-    double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
+    double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * ((int64_t)nfp * nfp);
+    int idx = 0;
 #pragma unroll
-    for (int q = 0; q < kSchurMaxTilesPerWave; ++q) {
-        const int tile = wave + 4 * q;
-        if (tile < n_upper) {
-            int tr = 0, rem = tile;
-            while (rem >= T - tr) {
-                rem -= T - tr;
-                ++tr;
-            }
-            const int tc = tr + rem;
-            const int col = tc * 16 + (lane & 15);
+    for (int tr = 0; tr < TM; ++tr)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = tr * 16 + (lane >> 4) + 4 * r;  // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg
-                const double v = acc[q][r];
-                out[row * nfp + col] = v;
-                if (tr != tc) out[col * nfp + row] = v;
+        for (int tc = tr; tc < TM; ++tc) {
+            if (tc < T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+                    out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = acc[idx][r];
+                }
             }
+            ++idx;
         }
-    }
-    if ((int)threadIdx.x < nfp) out[nfp * nfp + threadIdx.x] = ((int)threadIdx.x < nf) ? rhs_acc : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------ camera system
@@ -384,6 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
         for (int i = threadIdx.x; i < n; i += kBlock) flags[i] = 0;
         for (int list = 0; list < 2; ++list) {
             const double* vals = (list == 0 ? bv.trim_dep : bv.trim_rep) + wd.lm0;
+            const int32_t* lid = bv.lm_id + wd.lm0;
             const double q = list == 0 ? c.depth_quantile : c.reprojection_quantile;
             if (threadIdx.x == 0) n_valid = 0;
             __syncthreads();
@@ -392,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
                 double v = i < n ? vals[i] : -1.0;
                 const bool valid = v >= 0.0;  // also true for +inf (failed functor)
                 keys[i] = valid ? v : INFINITY;
-                ids[i] = valid ? i : (i | (1 << 30));  // invalid entries sort after every valid one
+                ids[i] = valid ? lid[i] : (i | (1 << 30));  // invalid entries sort after every valid one
                 mine += valid;
             }
             if (mine) atomicAdd(&n_valid, mine);
@@ -425,15 +540,15 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
             __syncthreads();
         }
         for (int l = threadIdx.x; l < n; l += kBlock) {
-            if (flags[l] && bv.lm_state[wd.lm0 + l]) {
+            if (flags[bv.lm_id[wd.lm0 + l]] && bv.lm_state[wd.lm0 + l]) {
                 bv.lm_state[wd.lm0 + l] = 0;
                 ++removed;
             }
         }
     } else {
         for (int l = threadIdx.x; l < n; l += kBlock) {
-            const int out = trim_is_outlier(bv.trim_dep + wd.lm0, n, l, c.depth_quantile, c.min_groups) ||
-                            trim_is_outlier(bv.trim_rep + wd.lm0, n, l, c.reprojection_quantile, c.min_groups);
+            const int out = trim_is_outlier(bv.trim_dep + wd.lm0, bv.lm_id + wd.lm0, n, l, c.depth_quantile, c.min_groups) ||
+                            trim_is_outlier(bv.trim_rep + wd.lm0, bv.lm_id + wd.lm0, n, l, c.reprojection_quantile, c.min_groups);
             if (out && bv.lm_state[wd.lm0 + l]) {
                 bv.lm_state[wd.lm0 + l] = 0;
                 ++removed;

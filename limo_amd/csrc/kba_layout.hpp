@@ -21,7 +21,8 @@ constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimiza
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
-constexpr int kSchurLm = 32;      // landmarks per Schur LDS tile
+constexpr int kSchurLm = 16;      // landmarks per Schur LDS tile (48 rows = 12 MFMA k-steps)
+constexpr int kSchurLmPerBlock = 256;  // landmarks per Schur workgroup (one wave, one partial slab)
 constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per pair (3+1+1) + global normal 3/kf
 
 // number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
@@ -37,7 +38,10 @@ struct WinDesc {
     int32_t gp0, n_gp;
     int32_t sblk0, n_sblk;    // Schur workgroups
     int32_t nc, nc_pad;       // 10*n_kf, rounded up to 16
-    int32_t nf, nf_pad;       // free camera slots (compact Schur system), rounded up to 16
+    int32_t nf, nf_pad;       // free camera slots (compact Schur system); nf + 1 (rhs column) rounded up to 16
+    int32_t nfq;              // free POSE slots: compact indices [0,nfq) are pose slots, [nfq,nf) plane slots.  In the
+                              // Schur tile / slab column nfq holds the rhs, so compact index i sits in column i + (i >= nfq)
+    int32_t lm_gp0;           // first (global) landmark of the window that carries a ground-plane row (they are packed last)
     int32_t cam0;             // first global camera-slot index = kf0*10
     int32_t reg0;             // first row in the regulariser row buffers
     int32_t has_scale_reg, has_gp_reg;
@@ -108,6 +112,7 @@ struct BatchView {
     uint8_t* cpresent;          // [TK*10] 1 = parameter block is in the problem (free or constant)
     const int32_t* cslot;       // [TK*10] compact index of a free slot inside its window, -1 otherwise
     const int32_t* lm_win;      // [TL]
+    const int32_t* lm_id;       // [TL] index of the landmark in the caller's window (ties in trimming resolve by id)
     const double* lm_weight;    // [TL]
     uint8_t* lm_state;          // [TL] 1 = in problem, 0 = removed by trimming / not constrained
     const int32_t* lm_gp;       // [TL] ground-plane residual index or -1
@@ -134,7 +139,12 @@ struct BatchView {
     double* gp_cost;            // [TG] cost at the linearisation point
     double* gp_cost_c;          // [TG] cost at the candidate
     // --- materialised linearisation (planes over observations)
-    double *obs_r, *obs_Jp, *obs_Jl;  // [3|18|9][SO]
+    // Solver batches keep the FACTORED Jacobian: every row of an observation is  c_row^T Rc [ M(q,p) | I ]  towards its
+    // pose and  c_row^T Rc R(q)  towards its landmark, so only  Ft = c^T Rc  (3x3, loss-scaled) is stored and the
+    // landmark-parallel kernels rebuild  F = Ft [M | I],  E = Ft R  from the pose / landmark they hold anyway
+    // (96 B per observation instead of 240 B).  Evaluate-only batches (Problem::Evaluate) materialise Jp / Jl in full.
+    double *obs_r, *obs_Ft;           // [3|9][SO]
+    double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* blk_part;           // [n_blk*kLinPartial]
     int32_t* blk_fail;          // [n_blk]
     double* blk_cost_c;         // [n_blk] candidate cost partials

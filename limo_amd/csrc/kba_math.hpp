@@ -55,6 +55,12 @@ KBA_HD void mat3_vec(const double* R, const double* p, double* out) {
     out[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2];
 }
 
+// C = A B (3x3, row-major)
+KBA_HD void mat3_mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
 // M (3x3, row-major) = d(R(q)p)/dq (3x4) * dPlus/ddelta (4x3) of the left-multiplying quaternion update
 // q (+) delta = [cos|d|, sin|d|/|d| d] (x) q.   For unit q this equals -2 [R p]_x.
 KBA_HD void rot_tangent_jac(const double* q, const double* p, double* M) {

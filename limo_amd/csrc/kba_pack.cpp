@@ -50,6 +50,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     }
     P = PackedBatch();
     P.n_win = n;
+    P.evaluate_only = po.evaluate_only;
     P.win.resize(n);
     // ---- pass 1: sizes, views
     struct View {
@@ -134,6 +135,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.cslot.assign((size_t)std::max(1, P.TK) * kCamSlots, -1);
     P.lm.resize((size_t)P.TL * 3);
     P.lm_win.resize(P.TL);
+    P.lm_id.resize(P.TL);
     P.lm_gp.assign(P.TL, -1);
     P.lm_weight.resize(P.TL);
     P.lm_state.assign(P.TL, 0);
@@ -155,78 +157,15 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         std::memcpy(P.pdir.data() + (size_t)d.kf0 * 3, W.kf_plane_dir, sizeof(double) * 3 * W.n_kf);
         std::memcpy(P.pdist.data() + d.kf0, W.kf_plane_dist, sizeof(double) * W.n_kf);
         for (int k = 0; k < W.n_kf; ++k) P.kf_win[d.kf0 + k] = w;
-        if (W.n_lm) {
-            std::memcpy(P.lm.data() + (size_t)d.lm0 * 3, W.lm_pos, sizeof(double) * 3 * W.n_lm);
-            std::memcpy(P.lm_weight.data() + d.lm0, W.lm_weight, sizeof(double) * W.n_lm);
-        }
-        for (int l = 0; l < W.n_lm; ++l) P.lm_win[d.lm0 + l] = w;
-        for (int v = 0; v < d.n_view; ++v) {
-            const int gv = d.view0 + v;
-            P.view_kf[gv] = d.kf0 + views[w][v].kf;
-            P.view_win[gv] = w;
-            const double* cam = W.cam + 10 * views[w][v].cam;
-            double* vc = P.view_cam.data() + (size_t)gv * 16;
-            vc[0] = cam[0];
-            vc[1] = cam[1];
-            vc[2] = cam[2];
-            quat_R(cam + 3, vc + 4);
-            vc[13] = cam[7];
-            vc[14] = cam[8];
-            vc[15] = cam[9];
-        }
-        // observations sorted by (view, landmark)
-        std::vector<int> order(W.n_obs);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
-            return W.obs_lm[a] < W.obs_lm[b];
-        });
-        d.blk0 = (int)P.blk_view.size();
-        std::vector<int> lm_nobs(W.n_lm, 0);
-        int depth_blocks = 0;
-        int pos = 0;
-        for (int v = 0; v < d.n_view; ++v) {
-            const int start = pos;
-            while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
-            for (int b0 = start; b0 < pos; b0 += kBlock) {
-                const int gkf = d.kf0 + views[w][v].kf;
-                if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
-                P.kf_nblk[gkf]++;
-                P.blk_view.push_back(d.view0 + v);
-                P.blk_obs0.push_back(d.obs0 + b0);
-                P.blk_n.push_back(std::min(kBlock, pos - b0));
-            }
-            for (int i = start; i < pos; ++i) {
-                const int src = order[i];
-                const int o = d.obs0 + i;
-                const int l = W.obs_lm[src];
-                P.obs_lm[o] = d.lm0 + l;
-                P.obs_u[o] = W.obs_u[src];
-                P.obs_v[o] = W.obs_v[src];
-                P.obs_d[o] = W.obs_d[src];
-                P.obs_src[o] = src;
-                int32_t& slot = P.lm_slot[(size_t)v * P.SL + d.lm0 + l];
-                if (slot != -1) {
-                    err = "duplicate (keyframe, landmark, camera) observation";
-                    return LIMO_ERR_INVALID;
-                }
-                slot = o;
-                lm_nobs[l]++;
-                if (W.obs_d[src] > 0.0f) depth_blocks++;
-            }
-        }
-        d.n_blk = (int)P.blk_view.size() - d.blk0;
-        d.n_depth = depth_blocks;
-        d.n_repr = W.n_obs;
-        for (int l = 0; l < W.n_lm; ++l) P.lm_state[d.lm0 + l] = lm_nobs[l] > 0 ? (po.pose_only ? 2 : 1) : 0;
-
         // ---- ground-plane residuals, addGroundPlaneResiduals(10.), bundle_adjuster_keyframes.cpp:517-562
-        d.gp0 = (int)P.gp_lm.size();
+        //      (decided first: landmarks carrying a ground-plane row are packed LAST in their window, so a Schur
+        //      tile of plain landmarks only touches the pose slots of the reduced camera system)
         struct GpTmp {
             int kf, lm;
             double w;
         };
         std::vector<GpTmp> gp_tmp;
+        std::vector<uint8_t> has_gp(W.n_lm, 0);
         if (!po.pose_only && !po.evaluate_only) {
             const double weight = 10.;
             for (int l = 0; l < W.n_lm; ++l) {
@@ -251,17 +190,99 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 const double max_valid_dist = 25.;
                 if (min_dist < max_valid_dist) {
                     gp_tmp.push_back({kf_id, l, weight * (1. - min_dist / max_valid_dist)});
-                    if (P.lm_state[d.lm0 + l] == 0) P.lm_state[d.lm0 + l] = 1;  // constrained by its gp block only
+                    has_gp[l] = 1;
                 }
             }
+        }
+        // packed landmark order: plain landmarks (input order), then ground-plane landmarks (input order)
+        std::vector<int> perm(W.n_lm);
+        {
+            int nxt = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int l = 0; l < W.n_lm; ++l)
+                    if (has_gp[l] == pass) perm[l] = nxt++;
+            d.lm_gp0 = d.lm0 + W.n_lm - (int)gp_tmp.size();
+        }
+        for (int l = 0; l < W.n_lm; ++l) {
+            const int g = d.lm0 + perm[l];
+            P.lm_win[g] = w;
+            P.lm_id[g] = l;
+            P.lm_weight[g] = W.lm_weight[l];
+            for (int i = 0; i < 3; ++i) P.lm[(size_t)g * 3 + i] = W.lm_pos[3 * l + i];
+        }
+        for (int v = 0; v < d.n_view; ++v) {
+            const int gv = d.view0 + v;
+            P.view_kf[gv] = d.kf0 + views[w][v].kf;
+            P.view_win[gv] = w;
+            const double* cam = W.cam + 10 * views[w][v].cam;
+            double* vc = P.view_cam.data() + (size_t)gv * 16;
+            vc[0] = cam[0];
+            vc[1] = cam[1];
+            vc[2] = cam[2];
+            quat_R(cam + 3, vc + 4);
+            vc[13] = cam[7];
+            vc[14] = cam[8];
+            vc[15] = cam[9];
+        }
+        // observations sorted by (view, landmark)
+        std::vector<int> order(W.n_obs);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
+            return perm[W.obs_lm[a]] < perm[W.obs_lm[b]];
+        });
+        d.blk0 = (int)P.blk_view.size();
+        std::vector<int> lm_nobs(W.n_lm, 0);
+        int depth_blocks = 0;
+        int pos = 0;
+        for (int v = 0; v < d.n_view; ++v) {
+            const int start = pos;
+            while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
+            for (int b0 = start; b0 < pos; b0 += kBlock) {
+                const int gkf = d.kf0 + views[w][v].kf;
+                if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
+                P.kf_nblk[gkf]++;
+                P.blk_view.push_back(d.view0 + v);
+                P.blk_obs0.push_back(d.obs0 + b0);
+                P.blk_n.push_back(std::min(kBlock, pos - b0));
+            }
+            for (int i = start; i < pos; ++i) {
+                const int src = order[i];
+                const int o = d.obs0 + i;
+                const int l = perm[W.obs_lm[src]];
+                P.obs_lm[o] = d.lm0 + l;
+                P.obs_u[o] = W.obs_u[src];
+                P.obs_v[o] = W.obs_v[src];
+                P.obs_d[o] = W.obs_d[src];
+                P.obs_src[o] = src;
+                int32_t& slot = P.lm_slot[(size_t)v * P.SL + d.lm0 + l];
+                if (slot != -1) {
+                    err = "duplicate (keyframe, landmark, camera) observation";
+                    return LIMO_ERR_INVALID;
+                }
+                slot = o;
+                lm_nobs[l]++;
+                if (W.obs_d[src] > 0.0f) depth_blocks++;
+            }
+        }
+        d.n_blk = (int)P.blk_view.size() - d.blk0;
+        d.n_depth = depth_blocks;
+        d.n_repr = W.n_obs;
+        for (int l = 0; l < W.n_lm; ++l) P.lm_state[d.lm0 + l] = lm_nobs[l] > 0 ? (po.pose_only ? 2 : 1) : 0;
+
+        // ---- ground-plane rows
+        d.gp0 = (int)P.gp_lm.size();
+        {
+            for (const GpTmp& g : gp_tmp)
+                if (P.lm_state[d.lm0 + perm[g.lm]] == 0) P.lm_state[d.lm0 + perm[g.lm]] = 1;  // constrained by its gp block only
             // rows sorted by keyframe (stable in landmark order) so each keyframe owns a contiguous range
             std::stable_sort(gp_tmp.begin(), gp_tmp.end(), [](const GpTmp& a, const GpTmp& b) { return a.kf < b.kf; });
             for (const GpTmp& g : gp_tmp) {
                 const int gi = (int)P.gp_lm.size();
                 if (P.kf_ngp[d.kf0 + g.kf] == 0) P.kf_gp0[d.kf0 + g.kf] = gi;
                 P.kf_ngp[d.kf0 + g.kf]++;
-                P.lm_gp[d.lm0 + g.lm] = gi;
-                P.gp_lm.push_back(d.lm0 + g.lm);
+                P.lm_gp[d.lm0 + perm[g.lm]] = gi;
+                P.gp_lm.push_back(d.lm0 + perm[g.lm]);
                 P.gp_kf.push_back(d.kf0 + g.kf);
                 P.gp_w.push_back(g.w);
             }
@@ -320,10 +341,14 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 if (plane_in && !fixed && !(n_depth < 10)) set_block(freem, k, 9, 1);  // :722-728
             }
         }
+        // compact numbering of the free slots: every pose slot first, then the plane slots (kba_layout.hpp, WinDesc::nfq)
         d.nf = 0;
-        for (int i = 0; i < d.nc; ++i)
-            if (freem[i]) P.cslot[(size_t)d.cam0 + i] = d.nf++;
-        d.nf_pad = std::max(16, (d.nf + 15) / 16 * 16);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < d.nc; ++i)
+                if (freem[i] && ((i % kCamSlots) >= 6) == (pass == 1)) P.cslot[(size_t)d.cam0 + i] = d.nf++;
+            if (pass == 0) d.nfq = d.nf;
+        }
+        d.nf_pad = (d.nf + 1 + 15) / 16 * 16;  // + the rhs column
         d.do_trim = (W.n_lm > opts.min_landmarks_for_trimming) ? 1 : 0;  // :741 / :865
 
         // ---- workgroup tables
@@ -336,7 +361,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.n_lblk = (int)P.lblk_win.size() - d.lblk0;
         d.sblk0 = (int)P.sblk_win.size();
         if (!po.pose_only && !po.evaluate_only && d.nf > 0) {
-            const int per = 8 * kSchurLm;
+            const int per = kSchurLmPerBlock;
             for (int l0 = 0; l0 < W.n_lm; l0 += per) {
                 P.sblk_win.push_back(w);
                 P.sblk_lm0.push_back(d.lm0 + l0);
@@ -347,7 +372,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.hcc_off = P.hcc_total;
         P.hcc_total += (int64_t)d.nc * d.nc;
         d.spart_off = P.spart_total;
-        P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad + d.nf_pad);
+        P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
     }
     P.TG = (int)P.gp_lm.size();
     P.SG = pad64(std::max(1, P.TG));

@@ -17,12 +17,14 @@ struct PackedBatch {
     int32_t n_win = 0, TK = 0, TL = 0, TO = 0, TV = 0, TG = 0, n_blk = 0, n_lblk = 0, n_sblk = 0, Vmax = 0;
     int64_t SO = 0, SL = 0, SG = 0;
     int64_t hcc_total = 0, spart_total = 0;
+    bool evaluate_only = false;  // planes hold the full Jacobians instead of the factored form
     std::vector<WinDesc> win;
     std::vector<double> pose, pdir, pdist, lm;  // initial parameters
     std::vector<int32_t> kf_win, kf_blk0, kf_nblk, kf_gp0, kf_ngp;
     std::vector<uint8_t> cmask, cpresent;
     std::vector<int32_t> cslot;
     std::vector<int32_t> lm_win, lm_gp, lm_slot;
+    std::vector<int32_t> lm_id;  // packed landmark -> index in the caller's window
     std::vector<double> lm_weight;
     std::vector<uint8_t> lm_state;
     std::vector<int32_t> view_kf, view_win;

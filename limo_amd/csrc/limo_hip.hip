@@ -61,7 +61,18 @@ struct limo_ba_batch : Executor {
     std::vector<int32_t> h_wl;
     bool use_wl = false;
     int n_wl_blk = 0, n_wl_lblk = 0, n_wl_sblk = 0, n_wl_win = 0, listed = 0;
-    int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0;
+    int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0, schur_T = 1;
+    const void* schur_fn = nullptr;
+    bool schur_fast = false;
+
+    static const void* pick_schur(int T, bool fast) {
+        if (fast) {
+            return T <= 2 ? (const void*)k_schur<2, true> : T <= 3 ? (const void*)k_schur<3, true>
+                 : T <= 4 ? (const void*)k_schur<4, true> : T <= 6 ? (const void*)k_schur<6, true> : (const void*)k_schur<8, true>;
+        }
+        return T <= 2 ? (const void*)k_schur<2, false> : T <= 3 ? (const void*)k_schur<3, false>
+             : T <= 4 ? (const void*)k_schur<4, false> : T <= 6 ? (const void*)k_schur<6, false> : (const void*)k_schur<8, false>;
+    }
     int rc = LIMO_OK;
     // kernel timing (linearize) via HIP events on the batch's stream
     std::vector<EventPair> ev_pool;
@@ -133,8 +144,22 @@ struct limo_ba_batch : Executor {
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
         int max_nfp = 16;
         for (const WinDesc& d : P.win) max_nfp = std::max(max_nfp, (int)d.nf_pad);
-        max_ld_bytes = schur_lds_doubles(max_nfp) * (int)sizeof(double);
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
+        max_ld_bytes = schur_lds_bytes(max_nfp);
+        schur_T = max_nfp / 16;
+        schur_fast = true;  // k_schur<.., true>: <= 4 keyframes with free slots, one view per keyframe, in every window
+        for (const WinDesc& d : P.win) {
+            int nfk = 0;
+            for (int k = 0; k < d.n_kf; ++k) {
+                const int32_t* cs = P.cslot.data() + (size_t)d.cam0 + (size_t)k * kCamSlots;
+                nfk += (cs[0] >= 0 || cs[6] >= 0) ? 1 : 0;
+                int nv = 0;
+                for (int v = 0; v < d.n_view; ++v) nv += P.view_kf[d.view0 + v] == d.kf0 + k;
+                if (nv > 1) schur_fast = false;
+            }
+            if (nfk > 4) schur_fast = false;
+        }
+        schur_fn = pick_schur(schur_T, schur_fast);
+        HIP_TRY(ctx, hipFuncSetAttribute(schur_fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
         asm_bytes = cam_assemble_scratch(max_nc, kBlock) * (int)sizeof(double);
         solve_bytes = cam_solve_scratch(max_nc, kBlock) * (int)sizeof(double);
         int max_lm = 1;
@@ -288,7 +313,9 @@ struct limo_ba_batch : Executor {
             LAUNCH_CHECK("k_lm_damp");
         }
         if (n_wl_sblk) {
-            hipLaunchKernelGGL(k_schur, dim3(n_wl_sblk), dim3(kBlock), max_ld_bytes, s, bv, use_wl ? d_wl_sblk : nullptr, (int)c.pad);
+            const int32_t* wlp = use_wl ? d_wl_sblk : nullptr;
+            void* args[] = {(void*)&bv, (void*)&wlp};
+            note(hipLaunchKernel(schur_fn, dim3(n_wl_sblk), dim3(64), args, max_ld_bytes, s), "launch k_schur");
             LAUNCH_CHECK("k_schur");
         }
         if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);
@@ -497,7 +524,8 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
             std::memcpy(W.kf_pose, pose.data() + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
             std::memcpy(W.kf_plane_dir, pdir.data() + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
             std::memcpy(W.kf_plane_dist, pdist.data() + d.kf0, sizeof(double) * d.n_kf);
-            if (d.n_lm) std::memcpy(W.lm_pos, lm.data() + 3 * (size_t)d.lm0, sizeof(double) * 3 * d.n_lm);
+            for (int l = 0; l < d.n_lm; ++l)  // packed order -> the caller's landmark order
+                std::memcpy(W.lm_pos + 3 * (size_t)P.lm_id[d.lm0 + l], lm.data() + 3 * (size_t)(d.lm0 + l), sizeof(double) * 3);
         }
         if (reports) {
             limo_ba_report& r = reports[w];

@@ -121,43 +121,38 @@ struct EmuBatch : Executor {
             for (int t = 0; t < bv.lblk_n[b]; ++t) fail |= lm_damp_lane(bv, c, bv.lblk_lm0[b] + t);
             bv.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
         }
-        // Schur slabs
-        std::vector<double> Z, tt;
+        // Schur slabs: upper triangle of Z^T Z per Schur workgroup (rhs = column nfq, see kba_items.hpp)
+        std::vector<double> z;
         for (int sb = 0; sb < bv.n_sblk; ++sb) {
             const int w = bv.sblk_win[sb];
             if (!bv.st[w].active) continue;
             const WinDesc& wd = bv.win[w];
-            const int ncp = wd.nf_pad;
-            const int slab = ncp * ncp + ncp;
-            std::vector<int> cs(wd.nc);
-            std::vector<double> scw(wd.nc);
-            for (int i = 0; i < wd.nc; ++i) {
-                cs[i] = bv.cslot[wd.cam0 + i];
-                scw[i] = bv.scale_c[wd.cam0 + i];
-            }
+            const int nfp = wd.nf_pad, nfq = wd.nfq;
+            const int slab = nfp * nfp;
+            std::vector<int> vkl(wd.n_view);
+            for (int j = 0; j < wd.n_view; ++j) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
             double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
             for (int i = 0; i < slab; ++i) out[i] = 0.0;
-            for (int l0 = 0; l0 < bv.sblk_n[sb]; l0 += kSchurLm) {
-                const int nl = std::min(kSchurLm, bv.sblk_n[sb] - l0);
-                Z.assign((size_t)3 * kSchurLm * ncp, 0.0);
-                tt.assign((size_t)3 * kSchurLm, 0.0);
-                for (int li = 0; li < nl; ++li) {
-                    const int gl = bv.sblk_lm0[sb] + l0 + li;
-                    if (bv.lm_state[gl] != 1) continue;
-                    double lmk[9];
-                    schur_load_lm(bv, gl, lmk);
-                    for (int j = 0; j < wd.n_view; ++j)
-                        schur_fill_view(bv, gl, li, j, bv.view_kf[wd.view0 + j] - wd.kf0, lmk, cs.data(), scw.data(), Z.data(), ncp);
-                    const int gg = bv.lm_gp[gl];
-                    if (gg >= 0) schur_fill_gp(bv, gg, li, bv.gp_kf[gg] - wd.kf0, lmk, cs.data(), scw.data(), Z.data(), ncp);
-                    for (int cc = 0; cc < 3; ++cc) tt[3 * li + cc] = bv.lm_t[cc * bv.SL + gl];
+            for (int li = 0; li < bv.sblk_n[sb]; ++li) {
+                const int gl = bv.sblk_lm0[sb] + li;
+                if (bv.lm_state[gl] != 1) continue;
+                double lmk[9], Y[3 * kCamSlots];
+                schur_load_lm(bv, gl, lmk);
+                z.assign((size_t)3 * nfp, 0.0);
+                for (int kl = 0; kl < wd.n_kf; ++kl) {
+                    schur_pair_block(bv, wd, gl, kl, lmk, bv.scale_c + wd.cam0, vkl.data(), gl >= wd.lm_gp0, Y);
+                    for (int a = 0; a < kCamSlots; ++a) {
+                        const int ci = bv.cslot[wd.cam0 + kl * kCamSlots + a];
+                        if (ci < 0) continue;
+                        for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + schur_col(ci, nfq)] = Y[a * 3 + cc];
+                    }
                 }
-                for (int k = 0; k < 3 * nl; ++k) {
-                    const double* zr = Z.data() + (size_t)k * ncp;
-                    for (int a = 0; a < wd.nf; ++a) {
+                for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + nfq] = bv.lm_t[cc * bv.SL + gl];
+                for (int cc = 0; cc < 3; ++cc) {
+                    const double* zr = z.data() + (size_t)cc * nfp;
+                    for (int a = 0; a <= wd.nf; ++a) {
                         if (zr[a] == 0.0) continue;
-                        for (int bcol = 0; bcol < wd.nf; ++bcol) out[a * ncp + bcol] += zr[a] * zr[bcol];
-                        out[ncp * ncp + a] += zr[a] * tt[k];
+                        for (int bcol = a; bcol <= wd.nf; ++bcol) out[a * nfp + bcol] += zr[a] * zr[bcol];
                     }
                 }
             }
@@ -232,8 +227,8 @@ struct EmuBatch : Executor {
             for (int l = 0; l < wd.n_lm; ++l) trim_max_lane(bv, wd.lm0 + l, plane_rep.data(), plane_dep.data());
             std::vector<uint8_t> out(wd.n_lm, 0);
             for (int l = 0; l < wd.n_lm; ++l) {
-                out[l] = trim_is_outlier(bv.trim_dep + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
-                         trim_is_outlier(bv.trim_rep + wd.lm0, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
+                out[l] = trim_is_outlier(bv.trim_dep + wd.lm0, bv.lm_id + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
+                         trim_is_outlier(bv.trim_rep + wd.lm0, bv.lm_id + wd.lm0, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
             }
             for (int l = 0; l < wd.n_lm; ++l)
                 if (out[l] && bv.lm_state[wd.lm0 + l]) {
@@ -268,7 +263,8 @@ void write_back(const EmuBatch& B, limo_ba_window* windows) {
         std::memcpy(windows[w].kf_pose, B.bv.pose + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
         std::memcpy(windows[w].kf_plane_dir, B.bv.pdir + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
         std::memcpy(windows[w].kf_plane_dist, B.bv.pdist + d.kf0, sizeof(double) * d.n_kf);
-        if (d.n_lm) std::memcpy(windows[w].lm_pos, B.bv.lm + 3 * (size_t)d.lm0, sizeof(double) * 3 * d.n_lm);
+        for (int l = 0; l < d.n_lm; ++l)
+            for (int i = 0; i < 3; ++i) windows[w].lm_pos[3 * (size_t)B.bv.lm_id[d.lm0 + l] + i] = B.bv.lm[3 * (size_t)(d.lm0 + l) + i];
     }
 }
 
