@@ -877,13 +877,14 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int q = 0;
-        for (; q + 4 <= wd.n_sblk; q += 4) {  // independent loads in flight
+        const int n_slab = (wd.n_sblk + c.schur_span - 1) / c.schur_span;
+        for (; q + 4 <= n_slab; q += 4) {  // independent loads in flight
             s0 += sp[(int64_t)q * slab + off];
             s1 += sp[(int64_t)(q + 1) * slab + off];
             s2 += sp[(int64_t)(q + 2) * slab + off];
             s3 += sp[(int64_t)(q + 3) * slab + off];
         }
-        for (; q < wd.n_sblk; ++q) s0 += sp[(int64_t)q * slab + off];
+        for (; q < n_slab; ++q) s0 += sp[(int64_t)q * slab + off];
         A[i] = s - ((s0 + s1) + (s2 + s3));
     }
     KBA_SYNC();

@@ -205,8 +205,8 @@ struct SchurPre {
 // FAST: every window of the batch has at most four keyframes with free slots and one view per keyframe (checked on
 // the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
 template <int TM, bool FAST>
-__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl) {
-    const int sb = wl ? wl[blockIdx.x] : blockIdx.x;
+__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span) {
+    const int sb = wl[blockIdx.x];  // first Schur block of this wave (worklist entry, a multiple of span past wd.sblk0)
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, kq = lane >> 4;
-    const int n_lm_blk = bv.sblk_n[sb], lm_first = bv.sblk_lm0[sb];
+    const int sb_last = min(sb + span, wd.sblk0 + wd.n_sblk) - 1;
+    const int lm_first = bv.sblk_lm0[sb];
+    const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
 
     // ---- fast path: lane constants (its keyframe) and the software pipeline over tiles
     const int my_kl = (fast && kq < nfk) ? fk[kq] : -1;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl) {
         }
         __syncthreads();
     }
-    double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * ((int64_t)nfp * nfp);
+    double* out = bv.S_part + wd.spart_off + (int64_t)((sb - wd.sblk0) / span) * ((int64_t)nfp * nfp);
     int idx = 0;
 #pragma unroll
     for (int tr = 0; tr < TM; ++tr)

@@ -22,7 +22,8 @@ constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced ca
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
 constexpr int kSchurLm = 16;      // landmarks per Schur LDS tile (48 rows = 12 MFMA k-steps)
-constexpr int kSchurLmPerBlock = 256;  // landmarks per Schur workgroup (one wave, one partial slab)
+constexpr int kSchurLmPerBlock = 64;   // landmarks per Schur block; a wave takes SolveConsts::schur_span (1, 2 or 4)
+                                       // consecutive blocks of a window and writes one partial slab
 constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per pair (3+1+1) + global normal 3/kf
 
 // number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
@@ -90,6 +91,7 @@ struct SolveConsts {  // subset of limo_ba_options the kernels need
     int32_t max_invalid, jacobi_scaling;
     double depth_quantile, reprojection_quantile;
     int32_t min_groups, pad;
+    int32_t schur_span, pad2;  // Schur blocks per wave in this iteration (slab q of a window covers blocks [q*span, ..))
 };
 
 // Raw pointers to every buffer of a batch (device pointers in the library, host pointers in the emulator).

@@ -57,6 +57,10 @@ struct limo_ba_batch : Executor {
     // worklists of the windows that still iterate (nullptr = every workgroup): rebuilt on the host whenever the
     // active set has halved, so late LM iterations only launch the workgroups that have work
     int32_t *d_wl_blk = nullptr, *d_wl_lblk = nullptr, *d_wl_sblk = nullptr, *d_wl_win = nullptr, *d_flags = nullptr;
+    int32_t* d_wl_sblk_part = nullptr;                          // Schur worklist of a re-batched active set
+    int32_t* d_wl_sblk_full[3] = {nullptr, nullptr, nullptr};   // ... of every window, for spans 1, 2, 4
+    int n_wl_sblk_full[3] = {0, 0, 0};
+    int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
     std::vector<int32_t> h_wl;
     bool use_wl = false;
@@ -138,7 +142,16 @@ struct limo_ba_batch : Executor {
         HIP_TRY(ctx, hipHostMalloc((void**)&h_flags, sizeof(int32_t) * std::max(1, P.n_win)));
         if (dmalloc((void**)&d_wl_blk, sizeof(int32_t) * std::max(1, P.n_blk))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_wl_lblk, sizeof(int32_t) * std::max(1, P.n_lblk))) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_wl_sblk, sizeof(int32_t) * std::max(1, P.n_sblk))) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_wl_sblk_part, sizeof(int32_t) * std::max(1, P.n_sblk))) return LIMO_ERR_RUNTIME;
+        avg_sblk = P.n_win ? (P.n_sblk + P.n_win - 1) / P.n_win : 0;
+        for (int k = 0; k < 3; ++k) {  // every window listed, for spans 1, 2, 4
+            std::vector<int32_t> v;
+            for (const WinDesc& d : P.win)
+                for (int i = 0; i < d.n_sblk; i += (1 << k)) v.push_back(d.sblk0 + i);
+            n_wl_sblk_full[k] = (int)v.size();
+            if (dmalloc((void**)&d_wl_sblk_full[k], sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
+            if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d_wl_sblk_full[k], v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+        }
         if (dmalloc((void**)&d_wl_win, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_flags, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
@@ -201,13 +214,24 @@ struct limo_ba_batch : Executor {
 #define LAUNCH_CHECK(what) note(hipGetLastError(), what)
 
     // ---- Executor
+    // Schur granularity: coarse waves (4 blocks = 256 landmarks, fewer partial slabs) while there are enough of them
+    // to fill the chip (8 waves per CU), finer ones for small active sets where the serial tile chain of a wave is
+    // the latency floor of the iteration.
+    void set_span(int n_windows_listed) {
+        const int64_t coarse_waves = (int64_t)n_windows_listed * std::max(1, avg_sblk) / 4;
+        c.schur_span = coarse_waves >= 2048 ? 4 : coarse_waves >= 1024 ? 2 : 1;
+    }
+
     void full_lists() {
         use_wl = false;
         n_wl_blk = P.n_blk;
         n_wl_lblk = P.n_lblk;
-        n_wl_sblk = P.n_sblk;
         n_wl_win = P.n_win;
         listed = P.n_win;
+        set_span(P.n_win);
+        const int k = c.schur_span == 4 ? 2 : c.schur_span == 2 ? 1 : 0;
+        d_wl_sblk = d_wl_sblk_full[k];
+        n_wl_sblk = n_wl_sblk_full[k];
     }
 
     // Rebuild the worklists from the windows that are active right now (synchronises the stream).
@@ -224,13 +248,18 @@ struct limo_ba_batch : Executor {
             ww.push_back(w);
             for (int i = 0; i < d.n_blk; ++i) wb.push_back(d.blk0 + i);
             for (int i = 0; i < d.n_lblk; ++i) wlb.push_back(d.lblk0 + i);
-            for (int i = 0; i < d.n_sblk; ++i) wsb.push_back(d.sblk0 + i);
+        }
+        set_span((int)ww.size());
+        for (int w : ww) {
+            const WinDesc& d = P.win[w];
+            for (int i = 0; i < d.n_sblk; i += c.schur_span) wsb.push_back(d.sblk0 + i);
         }
         auto up = [&](int32_t* dst, const std::vector<int32_t>& v) {
             if (!v.empty()) note(hipMemcpyAsync(dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s), "upload worklist");
         };
         up(d_wl_blk, wb);
         up(d_wl_lblk, wlb);
+        d_wl_sblk = d_wl_sblk_part;
         up(d_wl_sblk, wsb);
         up(d_wl_win, ww);
         note(hipStreamSynchronize(s), "sync worklists");  // the host vectors go out of scope
@@ -313,8 +342,9 @@ struct limo_ba_batch : Executor {
             LAUNCH_CHECK("k_lm_damp");
         }
         if (n_wl_sblk) {
-            const int32_t* wlp = use_wl ? d_wl_sblk : nullptr;
-            void* args[] = {(void*)&bv, (void*)&wlp};
+            const int32_t* wlp = d_wl_sblk;
+            int span = c.schur_span;
+            void* args[] = {(void*)&bv, (void*)&wlp, (void*)&span};
             note(hipLaunchKernel(schur_fn, dim3(n_wl_sblk), dim3(64), args, max_ld_bytes, s), "launch k_schur");
             LAUNCH_CHECK("k_schur");
         }
