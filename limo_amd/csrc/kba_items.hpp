@@ -14,6 +14,11 @@
 #ifndef KBA_SYNC
 #define KBA_SYNC() ((void)0)
 #endif
+// Ordering point inside ONE wave (serial sections run by the first wave of a workgroup: LDS operations of a wave
+// execute in program order, the fence only keeps the compiler from moving them).  No-op in the serial emulator.
+#ifndef KBA_WAVE_SYNC
+#define KBA_WAVE_SYNC() ((void)0)
+#endif
 
 namespace kba {
 
@@ -26,11 +31,8 @@ struct LinLane {
 };
 
 // Lane t of linearize workgroup b: residuals + Jacobians of one observation at the CURRENT parameters.
-KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out) {
-    out.cost = 0.0;
-    out.fail = 0;
-    for (int i = 0; i < 21; ++i) out.U[i] = 0.0;
-    for (int i = 0; i < 6; ++i) out.g[i] = 0.0;
+// (ACCUMULATES cost / fail / U / g into `out`: a GPU lane folds kObsPerLane observations before the reduction.)
+KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
@@ -42,7 +44,7 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
         const double* cam = bv.view_cam + 16 * (int64_t)view;
         ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
                                    bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
-                                   c.a_rep, c.a_dep, true, &oo);
+                                   c.a_rep, c.a_dep, true, &oo, want_cost);
     }
     if (!live || !ok) {
         for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
@@ -58,13 +60,21 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
     } else if (oo.cost == 1.2345) {
         bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
     }
-    out.cost = oo.cost;
+    out.cost += oo.cost;
     int k = 0;
     for (int a = 0; a < 6; ++a) {
         for (int bb = a; bb < 6; ++bb)
-            out.U[k++] = oo.Jp[a] * oo.Jp[bb] + oo.Jp[6 + a] * oo.Jp[6 + bb] + oo.Jp[12 + a] * oo.Jp[12 + bb];
-        out.g[a] = oo.Jp[a] * oo.r[0] + oo.Jp[6 + a] * oo.r[1] + oo.Jp[12 + a] * oo.r[2];
+            out.U[k++] += oo.Jp[a] * oo.Jp[bb] + oo.Jp[6 + a] * oo.Jp[6 + bb] + oo.Jp[12 + a] * oo.Jp[12 + bb];
+        out.g[a] += oo.Jp[a] * oo.r[0] + oo.Jp[6 + a] * oo.r[1] + oo.Jp[12 + a] * oo.r[2];
     }
+}
+
+KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
+    out.cost = 0.0;
+    out.fail = 0;
+    for (int i = 0; i < 21; ++i) out.U[i] = 0.0;
+    for (int i = 0; i < 6; ++i) out.g[i] = 0.0;
+    linearize_lane_acc(bv, c, b, t, out, want_cost);
 }
 
 // Cost of one observation at the CANDIDATE parameters.
@@ -662,7 +672,7 @@ KBA_HD int cam_assemble_scratch(int nc, int nt) {
     return nc * nc + 6 * nt + (rows > gp ? rows : gp);
 }
 KBA_HD int cam_solve_scratch(int nc, int nt) {
-    return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + nt;  // A | y | dl | fl | red, sized for nf == nc
+    return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + 3 * nt;  // A | y | dl | fl | red, sized for nf == nc
 }
 
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
@@ -741,14 +751,21 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     }
     KBA_SYNC();
     // ... then rows are added one after another (fixed order), each row's <=16x16 outer product spread over lanes
-    for (int i = 0; i < nrows; ++i) {
-        const RegRow& row = rows[i];
-        if (row.n > 0) {
-            for (int e = tid; e < row.n * row.n; e += nt) {
-                const int p = e / row.n, q = e % row.n;
-                H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+    //     (serial in the rows: run by the first wave alone, no workgroup barrier per row)
+    {
+        const int nw = nt < 64 ? nt : 64;
+        if (tid < nw) {
+            for (int i = 0; i < nrows; ++i) {
+                const RegRow& row = rows[i];
+                if (row.n > 0) {
+                    for (int e = tid; e < row.n * row.n; e += nw) {
+                        const int p = e / row.n, q = e % row.n;
+                        H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+                    }
+                    for (int p = tid; p < row.n; p += nw) gc[row.col[p]] += row.val[p] * row.r;
+                }
+                KBA_WAVE_SYNC();
             }
-            for (int p = tid; p < row.n; p += nt) gc[row.col[p]] += row.val[p] * row.r;
         }
         KBA_SYNC();
     }
@@ -995,15 +1012,25 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             bv.pdist_c[gk] = bv.pdist[gk];
         }
     }
-    part = coop_sum(part, tid, nt, red);
-    step2 = coop_sum(step2, tid, nt, red);
-    cand2 = coop_sum(cand2, tid, nt, red);
+    // three sums folded in one tree (red holds 3*nt doubles)
+    red[0 * nt + tid] = part;
+    red[1 * nt + tid] = step2;
+    red[2 * nt + tid] = cand2;
+    KBA_SYNC();
+    for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+        if (tid < sft) {
+            red[0 * nt + tid] += red[0 * nt + tid + sft];
+            red[1 * nt + tid] += red[1 * nt + tid + sft];
+            red[2 * nt + tid] += red[2 * nt + tid + sft];
+        }
+        KBA_SYNC();
+    }
     if (tid == 0) {
         WinRed& r = bv.red[w];
         r.chol_fail = 0;
-        r.mcc = part;
-        r.step2 = step2;
-        r.cand2 = cand2;
+        r.mcc = red[0];
+        r.step2 = red[nt];
+        r.cand2 = red[2 * nt];
     }
 }
 

@@ -21,6 +21,12 @@
 #include <hip/hip_runtime.h>
 
 #define KBA_SYNC() __syncthreads()
+#define KBA_WAVE_SYNC()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 #include "kba_items.hpp"
 
 namespace kba {
@@ -76,21 +82,31 @@ __global__ void k_expire(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ observations
-__global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.view_win[bv.blk_view[b]];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
+    const bool want_cost = st.first != 0;  // workgroup-uniform
     __shared__ double lds[4 * kLinPartial];
     LinLane l;
-    linearize_lane(bv, c, b, threadIdx.x, l);
+    l.cost = 0.0;
+    l.fail = 0;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) l.U[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < kObsPerLane; ++q)  // consecutive lanes take consecutive observations in every pass
+        linearize_lane_acc(bv, c, b, threadIdx.x + q * kBlock, l, want_cost);
     double vals[kLinPartial];
     vals[0] = l.cost;
 #pragma unroll
     for (int i = 0; i < 21; ++i) vals[1 + i] = l.U[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
-    const int any_fail = __syncthreads_or(l.fail);
+    const int fail = l.fail;
+    const int any_fail = __syncthreads_or(fail);
     if (c.pad == 21) {  // profiling aid: skip the workgroup reduction
         if (threadIdx.x < kLinPartial) bv.blk_part[(int64_t)b * kLinPartial + threadIdx.x] = vals[0];
     } else {
@@ -104,9 +120,15 @@ __global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, co
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.st[w].active) return;
     __shared__ double lds[4];
-    double cost;
-    int fail;
-    cost_lane(bv, c, b, threadIdx.x, cost, fail);
+    double cost = 0.0;
+    int fail = 0;
+    for (int q = 0; q < kObsPerLane; ++q) {
+        double cq;
+        int fq;
+        cost_lane(bv, c, b, threadIdx.x + q * kBlock, cq, fq);
+        cost += cq;
+        fail |= fq;
+    }
     const int any_fail = __syncthreads_or(fail);
     block_sum<1>(&cost, lds, bv.blk_cost_c + b);
     if (threadIdx.x == 0) bv.blk_fail_c[b] = any_fail;
@@ -205,7 +227,7 @@ struct SchurPre {
 // FAST: every window of the batch has at most four keyframes with free slots and one view per keyframe (checked on
 // the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
 template <int TM, bool FAST>
-__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span) {
+__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span, int dbg) {
     const int sb = wl[blockIdx.x];  // first Schur block of this wave (worklist entry, a multiple of span past wd.sblk0)
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
 #pragma unroll
             for (int i = 0; i < 3; ++i) P.t[i] = bv.lm_t[i * bv.SL + gl];
         }
-        if (P.seen) {
+        if (P.seen && dbg != 35) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) P.p[i] = bv.lm[3 * (int64_t)gl + i];
 #pragma unroll
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
                 double Y[3 * kCamSlots];
 #pragma unroll
                 for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
-                if (cur.seen) {
+                if (cur.seen && dbg != 31) {
                     double M[9];
                     rot_tangent_jac(qk, cur.p, M);
                     schur_pose_block(cur.Ft, Rk, M, cur.lmk, sc_s + my_kl * kCamSlots, Y);
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
             for (int tr = 0; tr < TM; ++tr)
 #pragma unroll
                 for (int tc = tr; tc < TM; ++tc) {
-                    if (tc < Tt) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[tr], pan[tc], acc[idx], 0, 0, 0);
+                    if (tc < Tt && dbg != 32) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[tr], pan[tc], acc[idx], 0, 0, 0);
                     ++idx;
                 }
         }
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_trim_residual(BatchView bv, double* 
     const int b = blockIdx.x;
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.win[w].do_trim) return;
-    trim_residual_lane(bv, b, threadIdx.x, plane_rep, plane_dep);
+    for (int q = 0; q < kObsPerLane; ++q) trim_residual_lane(bv, b, threadIdx.x + q * kBlock, plane_rep, plane_dep);
 }
 
 __global__ void k_trim_max(BatchView bv, const double* plane_rep, const double* plane_dep) {
@@ -561,11 +583,10 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
 }
 
 // ------------------------------------------------------------------------------------------ evaluate (Problem::Evaluate)
-// Writes per-observation residuals / Jacobians into the planes and per-observation cost / valid flags.
-__global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* obs_cost,
-                                                     uint8_t* obs_valid) {
-    const int b = blockIdx.x;
-    const int t = threadIdx.x;
+// Writes per-observation residuals / Jacobians (fully materialised) into the planes and per-observation cost / valid
+// flags.
+__device__ __forceinline__ void evaluate_lane(const BatchView& bv, const SolveConsts& c, int b, int t, int apply_loss,
+                                              double* obs_cost, uint8_t* obs_valid) {
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
@@ -586,6 +607,12 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c
     for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
     obs_cost[o] = oo.cost;
     obs_valid[o] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* obs_cost,
+                                                     uint8_t* obs_valid) {
+    const int b = blockIdx.x;
+    for (int q = 0; q < kObsPerLane; ++q) evaluate_lane(bv, c, b, threadIdx.x + q * kBlock, apply_loss, obs_cost, obs_valid);
 }
 
 }  // namespace kba

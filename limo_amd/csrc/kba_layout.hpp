@@ -21,6 +21,9 @@ constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimiza
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
+constexpr int kObsPerLane = 4;    // observations per lane of the view-major kernels: the camera-side partials are
+                                  // accumulated in registers over them before the one workgroup reduction
+constexpr int kObsBlock = kBlock * kObsPerLane;  // observations per linearize / cost workgroup
 constexpr int kSchurLm = 16;      // landmarks per Schur LDS tile (48 rows = 12 MFMA k-steps)
 constexpr int kSchurLmPerBlock = 64;   // landmarks per Schur block; a wave takes SolveConsts::schur_span (1, 2 or 4)
                                        // consecutive blocks of a window and writes one partial slab
@@ -68,7 +71,7 @@ struct WinState {
     double x_cost, x_norm, fixed_cost;
     double solve_initial_cost, solve_final_cost;
     double first_initial_cost;
-    double rho_pending, xnorm_pending;
+    double rho_pending, xnorm_pending, cost_pending;
     double gmax;
 };
 

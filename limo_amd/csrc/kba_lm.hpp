@@ -69,7 +69,9 @@ KBA_HD void lm_decide_lin(WinState& s, const WinRed& r, double fixed_cost, const
         s.first = 0;
         return;
     }
-    s.x_cost = r.lin_cost;
+    // the cost at an accepted candidate is already known (HandleSuccessfulStep: x_cost = candidate_cost); only the
+    // first linearisation of a solve evaluates it (kernels skip the cost value otherwise)
+    s.x_cost = s.first ? r.lin_cost : s.cost_pending;
     s.gmax = r.gmax;
     s.acc_lin += 1;
     if (s.first) {
@@ -131,6 +133,7 @@ KBA_HD void lm_decide_step(WinState& s, const WinRed& r, const SolveConsts& c) {
         s.need_lin = 1;
         s.rho_pending = rho;
         s.xnorm_pending = sqrt(r.cand2);
+        s.cost_pending = cand_cost;
     } else {  // HandleUnsuccessfulStep
         s.radius = s.radius / s.decrease_factor;
         s.decrease_factor *= 2.0;

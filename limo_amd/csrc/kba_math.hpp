@@ -97,6 +97,14 @@ KBA_HD void loss_cauchy(double a, double weight, double s, double* rho) {
     rho[1] = weight * fmax(2.2250738585072014e-308, inv);
     rho[2] = weight * (-c * (inv * inv));
 }
+// rho' only (same arithmetic as loss_cauchy)
+KBA_HD double loss_cauchy_d1(double a, double weight, double s) {
+    const double b = a * a;
+    const double c = 1.0 / b;
+    const double sum = 1.0 + s * c;
+    const double inv = 1.0 / sum;
+    return weight * fmax(2.2250738585072014e-308, inv);
+}
 // ScaledLoss(HuberLoss(a), weight)
 KBA_HD void loss_huber(double a, double weight, double s, double* rho) {
     const double b = a * a;
@@ -152,9 +160,11 @@ KBA_HD bool obs_residual(const double* pose, const double* Rc, const double* tc,
     return true;
 }
 
+// want_cost = false skips the cost value (two logarithms): after an accepted step the cost at the new linearisation
+// point is the candidate cost the step evaluation has already produced.
 KBA_HD bool obs_residual_jacobian(const double* pose, const double* Rc, const double* tc, double f, double cx,
                                   double cy, const double* lm, float u, float v, float d, double lw, double a_rep,
-                                  double a_dep, bool apply_loss, ObsOut* o) {
+                                  double a_dep, bool apply_loss, ObsOut* o, bool want_cost = true) {
     double R[9], Rp[3], y[3], zc[3];
     quat_R(pose, R);
     mat3_vec(R, lm, Rp);
@@ -187,13 +197,19 @@ KBA_HD bool obs_residual_jacobian(const double* pose, const double* Rc, const do
     const double s_d = rd * rd;
     if (apply_loss) {
         double rho[3];
-        loss_cauchy(a_rep, lw, s_uv, rho);
-        su = sqrt(rho[1]);  // corrector: rho'' <= 0 for Cauchy  ->  plain sqrt(rho') scaling
-        cost = 0.5 * rho[0];
-        if (has_d) {
-            loss_cauchy(a_dep, lw, s_d, rho);
-            sd = sqrt(rho[1]);
-            cost += 0.5 * rho[0];
+        if (want_cost) {
+            loss_cauchy(a_rep, lw, s_uv, rho);
+            su = sqrt(rho[1]);  // corrector: rho'' <= 0 for Cauchy  ->  plain sqrt(rho') scaling
+            cost = 0.5 * rho[0];
+            if (has_d) {
+                loss_cauchy(a_dep, lw, s_d, rho);
+                sd = sqrt(rho[1]);
+                cost += 0.5 * rho[0];
+            }
+        } else {
+            su = sqrt(loss_cauchy_d1(a_rep, lw, s_uv));
+            if (has_d) sd = sqrt(loss_cauchy_d1(a_dep, lw, s_d));
+            cost = 0.0;
         }
     } else {
         cost = 0.5 * s_uv + 0.5 * s_d;

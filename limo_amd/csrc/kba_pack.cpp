@@ -239,13 +239,13 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         for (int v = 0; v < d.n_view; ++v) {
             const int start = pos;
             while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
-            for (int b0 = start; b0 < pos; b0 += kBlock) {
+            for (int b0 = start; b0 < pos; b0 += kObsBlock) {
                 const int gkf = d.kf0 + views[w][v].kf;
                 if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
                 P.kf_nblk[gkf]++;
                 P.blk_view.push_back(d.view0 + v);
                 P.blk_obs0.push_back(d.obs0 + b0);
-                P.blk_n.push_back(std::min(kBlock, pos - b0));
+                P.blk_n.push_back(std::min(kObsBlock, pos - b0));
             }
             for (int i = start; i < pos; ++i) {
                 const int src = order[i];

@@ -325,6 +325,8 @@ struct limo_ba_batch : Executor {
         note(hipEventSynchronize(act_ev[slot]), "sync n_active");
         if (rc != LIMO_OK) return 0;
         const int a = h_active[slot];
+        static const bool trace = std::getenv("KBA_TRACE_ACTIVE") != nullptr;  // profiling aid
+        if (trace) std::fprintf(stderr, "[kba] iteration %d: active %d, listed %d, span %d\n", cur - 1, a, listed, c.schur_span);
         // re-batch when at most half of the listed windows still iterate (and the list is worth shrinking)
         if (a > 0 && listed >= 8 && 2 * a <= listed) rebatch();
         return a;
@@ -343,8 +345,8 @@ struct limo_ba_batch : Executor {
         }
         if (n_wl_sblk) {
             const int32_t* wlp = d_wl_sblk;
-            int span = c.schur_span;
-            void* args[] = {(void*)&bv, (void*)&wlp, (void*)&span};
+            int span = c.schur_span, dbg = c.pad;
+            void* args[] = {(void*)&bv, (void*)&wlp, (void*)&span, (void*)&dbg};
             note(hipLaunchKernel(schur_fn, dim3(n_wl_sblk), dim3(64), args, max_ld_bytes, s), "launch k_schur");
             LAUNCH_CHECK("k_schur");
         }

@@ -17,7 +17,7 @@ KBA_DEBUG_STAGE=$st rocprofv3 --kernel-trace --stats -d gpurun_out/prof_quick -o
 python - <<PY
 import sqlite3
 db=sqlite3.connect('gpurun_out/prof_quick/s${st}_results.db')
-for r in db.execute("select name,total_calls,average from top_kernels where name like '%kba::%'"): print("stage $st %-40s %4d %9.1f us"%(r[0][:40],r[1],r[2]))
+for r in db.execute("select name,count(*),max(end-start)/1e3,avg(end-start)/1e3 from kernels where name like '%kba::%' group by name order by 3 desc"): print("stage $st %-40s %4d  max %9.1f us  avg %9.1f us"%(r[0][:40],r[1],r[2],r[3]))
 PY
 done
 python scripts/gpu_sweep.py ${SIZES:-256 1024}

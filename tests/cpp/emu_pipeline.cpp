@@ -61,9 +61,9 @@ struct EmuBatch : Executor {
             double part[kLinPartial];
             for (int i = 0; i < kLinPartial; ++i) part[i] = 0.0;
             int fail = 0;
-            for (int t = 0; t < kBlock; ++t) {
+            for (int t = 0; t < kObsBlock; ++t) {
                 LinLane l;
-                linearize_lane(bv, c, b, t, l);
+                linearize_lane(bv, c, b, t, l, bv.st[w].first != 0);
                 part[0] += l.cost;
                 for (int i = 0; i < 21; ++i) part[1 + i] += l.U[i];
                 for (int i = 0; i < 6; ++i) part[22 + i] += l.g[i];
@@ -186,7 +186,7 @@ struct EmuBatch : Executor {
             if (!bv.st[w].active) continue;
             double cost = 0.0;
             int fail = 0;
-            for (int t = 0; t < kBlock; ++t) {
+            for (int t = 0; t < kObsBlock; ++t) {
                 double cst;
                 int f;
                 cost_lane(bv, c, b, t, cst, f);
@@ -219,7 +219,7 @@ struct EmuBatch : Executor {
         for (int b = 0; b < bv.n_blk; ++b) {
             const int w = bv.view_win[bv.blk_view[b]];
             if (!bv.win[w].do_trim) continue;
-            for (int t = 0; t < kBlock; ++t) trim_residual_lane(bv, b, t, plane_rep.data(), plane_dep.data());
+            for (int t = 0; t < kObsBlock; ++t) trim_residual_lane(bv, b, t, plane_rep.data(), plane_dep.data());
         }
         for (int w = 0; w < bv.n_win; ++w) {
             const WinDesc& wd = bv.win[w];
