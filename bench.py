@@ -20,8 +20,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-BYTES_PER_REPR_OBS = 212  # read 52 B + write r(16) + J_pose 2x6x8 + J_point 2x3x8
-BYTES_PER_DEPTH_OBS = 84  # + d (4 B) read, r(8) + J_pose 1x6x8 + J_point 1x3x8 written
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix = fp64 vector peak: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (v_mfma_f64_16x16x4 = 2048 FLOP / 64 clk)
+# Algorithmic bytes of one Jacobian evaluation (k_linearize) per observation.  The solver stores the FACTORED Jacobian
+# (DESIGN.md §4): read 52 B + write residual 3x8 B + Ft 3x3x8 B = 148 B, depth row included for every
+# observation.  (SURVEY's 212 B + 84 B/depth-observation is the fully materialised form, which only
+# limo_ba_evaluate / k_evaluate writes.)
+BYTES_PER_OBS = 148
 
 
 def main():
@@ -105,7 +109,7 @@ def main():
         # roofline of the dominant kernel (k_linearize = Jacobian evaluation, materialised): algorithmic bytes of all
         # window linearisations performed in the timed steps / device time of the kernel over the same steps
         lin_per_step = sum(r["num_linearizations"] for r in reps)
-        per_window_bytes = [BYTES_PER_REPR_OBS * w.n_obs + BYTES_PER_DEPTH_OBS * int((w.obs_d > 0).sum()) for w in windows]
+        per_window_bytes = [BYTES_PER_OBS * w.n_obs for w in windows]
         alg_bytes = sum(r["num_linearizations"] * b for r, b in zip(reps, per_window_bytes)) * args.steps
         launches = max(1, stats["linearize_launches"])
         lin_ms = stats["linearize_ms"]
@@ -120,6 +124,13 @@ def main():
                 ratio = json.load(f)["traffic_over_algorithmic"]
             traffic = ratio * alg_bytes / launches
             traffic_src = "profiles/r01_pmc_linearize.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, ratio %.3f x algorithmic bytes/launch" % ratio
+        # second dominant kernel: k_schur (Schur complement, f64 MFMA).  Algorithmic flops of one launch over a window
+        # = n_c^2 * 3N (SYRK of the 3N x n_c landmark-eliminated block, n_c free camera slots, N landmarks
+        # in the problem); one launch per LM iteration of the window.
+        nf = [10 * (w.n_kf - 1) for w in windows]  # first keyframe Pose-fixed, every other keyframe 6 + 3 + 1 slots
+        schur_flops = sum(r["iterations_total"] * (n * n * 3.0 * (w.n_lm - r["n_trimmed_landmarks"])) for r, n, w in zip(reps, nf, windows)) * args.steps
+        schur_ms = stats["schur_ms"]
+        schur_tf = schur_flops / (schur_ms * 1e-3) / 1e12 if schur_ms > 0 else 0.0
         out = {
             "metric": "keyframe-BA window solves/sec (5 KF, ~2k landmarks)",
             "value": value,
@@ -158,6 +169,19 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "kernel_share_of_device_time": lin_ms / stats["total_ms"] if stats["total_ms"] > 0 else None,
             },
+        }
+        out["roofline_schur"] = {
+            "kernel": "k_schur",
+            "bound": "mfma",
+            "achieved": schur_tf,
+            "peak": F64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": schur_tf / F64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches": stats["schur_launches"],
+            "avg_launch_ms": schur_ms / max(1, stats["schur_launches"]),
+            "algorithmic_flops_per_launch": schur_flops / max(1, stats["schur_launches"]),
+            "kernel_share_of_device_time": schur_ms / stats["total_ms"] if stats["total_ms"] > 0 else None,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(base, opts, args.cpu_windows)

@@ -181,6 +181,10 @@ void limo_ba_batch_destroy(limo_ba_batch* batch);
  * accumulated since create()/the last call with reset != 0; either output may be NULL. */
 int limo_ba_batch_kernel_stats(limo_ba_batch* batch, int reset, double* linearize_ms, int64_t* linearize_launches,
                                double* total_ms);
+/* Same accumulation window, per timed kernel (the two that dominate an LM iteration). */
+#define LIMO_KERNEL_LINEARIZE 0 /* k_linearize: residuals + (factored) Jacobians of every observation          */
+#define LIMO_KERNEL_SCHUR 1     /* k_schur: Schur complement of the landmark blocks (f64 MFMA)                   */
+int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int64_t* launches);
 
 /*
  * Evaluate the reprojection / depth residual blocks of a window at its current parameters

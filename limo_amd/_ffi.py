@@ -162,6 +162,7 @@ ABI_SYMBOLS = [
     "limo_ba_batch_download",
     "limo_ba_batch_destroy",
     "limo_ba_batch_kernel_stats",
+    "limo_ba_batch_kernel_time",
     "limo_ba_evaluate",
     "limo_ba_adjust_pose_only",
     "limo_landmark_init",
@@ -202,6 +203,7 @@ def load():
     lib.limo_ba_batch_destroy.argtypes = [vp]
     lib.limo_ba_batch_destroy.restype = None
     lib.limo_ba_batch_kernel_stats.argtypes = [vp, C.c_int, c_double_p, c_int64_p, c_double_p]
+    lib.limo_ba_batch_kernel_time.argtypes = [vp, C.c_int, c_double_p, c_int64_p]
     lib.limo_ba_evaluate.argtypes = [
         vp,
         C.POINTER(BaWindow),

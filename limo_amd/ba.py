@@ -109,8 +109,12 @@ class Batch:
         ms = C.c_double()
         n = C.c_int64()
         tot = C.c_double()
+        sms, sn = C.c_double(), C.c_int64()
+        _check(self.lib.limo_ba_batch_kernel_time(self.ptr, 1, C.byref(sms), C.byref(sn)), self.ctx.ptr, "limo_ba_batch_kernel_time")
+        out = {"schur_ms": sms.value, "schur_launches": sn.value}
         _check(self.lib.limo_ba_batch_kernel_stats(self.ptr, int(reset), C.byref(ms), C.byref(n), C.byref(tot)), self.ctx.ptr, "limo_ba_batch_kernel_stats")
-        return {"linearize_ms": ms.value, "linearize_launches": n.value, "total_ms": tot.value}
+        out.update({"linearize_ms": ms.value, "linearize_launches": n.value, "total_ms": tot.value})
+        return out
 
     def close(self):
         if self.ptr:

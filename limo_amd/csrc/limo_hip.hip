@@ -37,6 +37,7 @@ inline int cdiv(int64_t a, int64_t b) {
 
 struct EventPair {
     hipEvent_t a, b;
+    int kernel;  // LIMO_KERNEL_*
 };
 
 }  // namespace
@@ -81,8 +82,8 @@ struct limo_ba_batch : Executor {
     // kernel timing (linearize) via HIP events on the batch's stream
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
-    double lin_ms_acc = 0.0;
-    int64_t lin_launches = 0;
+    double k_ms_acc[2] = {0.0, 0.0};      // indexed by LIMO_KERNEL_LINEARIZE / LIMO_KERNEL_SCHUR
+    int64_t k_launches[2] = {0, 0};
     hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
     double total_ms_acc = 0.0;
     double last_solve_sec = 0.0;
@@ -278,20 +279,26 @@ struct limo_ba_batch : Executor {
         LAUNCH_CHECK("k_solve_init");
     }
 
+    // Event pair around one launch of a timed kernel (nullptr once the pool is exhausted).
+    EventPair* timed(int kernel) {
+        if (ev_used >= 16384) return nullptr;
+        if (ev_used == ev_pool.size()) {
+            EventPair e;
+            e.kernel = kernel;
+            note(hipEventCreate(&e.a), "hipEventCreate");
+            note(hipEventCreate(&e.b), "hipEventCreate");
+            ev_pool.push_back(e);
+        }
+        EventPair* ep = &ev_pool[ev_used++];
+        ep->kernel = kernel;
+        note(hipEventRecord(ep->a, ctx->stream), "hipEventRecord");
+        return ep;
+    }
+
     void linearize() override {
         hipStream_t s = ctx->stream;
         if (n_wl_blk) {
-            EventPair* ep = nullptr;
-            if (ev_used < 8192) {
-                if (ev_used == ev_pool.size()) {
-                    EventPair e;
-                    note(hipEventCreate(&e.a), "hipEventCreate");
-                    note(hipEventCreate(&e.b), "hipEventCreate");
-                    ev_pool.push_back(e);
-                }
-                ep = &ev_pool[ev_used++];
-                note(hipEventRecord(ep->a, s), "hipEventRecord");
-            }
+            EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
             hipLaunchKernelGGL(k_linearize, dim3(n_wl_blk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_blk : nullptr);
             LAUNCH_CHECK("k_linearize");
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
@@ -347,7 +354,9 @@ struct limo_ba_batch : Executor {
             const int32_t* wlp = d_wl_sblk;
             int span = c.schur_span, dbg = c.pad;
             void* args[] = {(void*)&bv, (void*)&wlp, (void*)&span, (void*)&dbg};
+            EventPair* ep = timed(LIMO_KERNEL_SCHUR);
             note(hipLaunchKernel(schur_fn, dim3(n_wl_sblk), dim3(64), args, max_ld_bytes, s), "launch k_schur");
+            if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
             LAUNCH_CHECK("k_schur");
         }
         if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);
@@ -394,8 +403,8 @@ struct limo_ba_batch : Executor {
             for (size_t i = 0; i < ev_used; ++i) {
                 float ms = 0.f;
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, ev_pool[i].a, ev_pool[i].b));
-                lin_ms_acc += ms;
-                lin_launches += 1;
+                k_ms_acc[ev_pool[i].kernel] += ms;
+                k_launches[ev_pool[i].kernel] += 1;
             }
             ev_used = 0;
         }
@@ -593,14 +602,25 @@ int limo_ba_batch_kernel_stats(limo_ba_batch* b, int reset, double* linearize_ms
     if (!b) return LIMO_ERR_INVALID;
     int rc = b->collect_linearize_events();
     if (rc != LIMO_OK) return rc;
-    if (linearize_ms) *linearize_ms = b->lin_ms_acc;
-    if (linearize_launches) *linearize_launches = b->lin_launches;
+    if (linearize_ms) *linearize_ms = b->k_ms_acc[LIMO_KERNEL_LINEARIZE];
+    if (linearize_launches) *linearize_launches = b->k_launches[LIMO_KERNEL_LINEARIZE];
     if (total_ms) *total_ms = b->total_ms_acc;
     if (reset) {
-        b->lin_ms_acc = 0.0;
-        b->lin_launches = 0;
+        for (int k = 0; k < 2; ++k) {
+            b->k_ms_acc[k] = 0.0;
+            b->k_launches[k] = 0;
+        }
         b->total_ms_acc = 0.0;
     }
+    return LIMO_OK;
+}
+
+int limo_ba_batch_kernel_time(limo_ba_batch* b, int kernel, double* ms, int64_t* launches) {
+    if (!b || kernel < 0 || kernel > LIMO_KERNEL_SCHUR) return LIMO_ERR_INVALID;
+    int rc = b->collect_linearize_events();
+    if (rc != LIMO_OK) return rc;
+    if (ms) *ms = b->k_ms_acc[kernel];
+    if (launches) *launches = b->k_launches[kernel];
     return LIMO_OK;
 }
 
