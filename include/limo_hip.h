@@ -187,6 +187,26 @@ int limo_ba_batch_kernel_stats(limo_ba_batch* batch, int reset, double* lineariz
 int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int64_t* launches);
 
 /*
+ * Landmark-sharded solve of ONE (large) window, SURVEY §8e / BASELINE.json configs[3]: shard s owns the landmarks
+ * whose index in the window satisfies  index mod n_shards == s  together with all their observations and
+ * ground-plane rows; camera-side parameters are replicated.  Per LM iteration the shards exchange their partial
+ * camera blocks (U_k, g_k, cost), Schur-complement slabs and step-norm parts by all-reduce (3 exchanges), then every
+ * shard factors the reduced camera system redundantly and back-substitutes its own landmarks.  Every partial entry
+ * has exactly one owner, so the sum is exact and the result does not depend on the reduction order.
+ *   - with a communicator (limo_ctx_comm_init): one process per GPU, shard s lives on rank s mod world (n_shards a
+ *     multiple of world, normally == world); every rank calls with the same window; the exchange is a local sum
+ *     over the rank's shards followed by an RCCL all-reduce; all ranks return the full result;
+ *   - without: n_shards (<= 8) VIRTUAL shards on this GPU - the same kernels, the exchange is the local sum only
+ *     (the single-GPU mode SURVEY §8e asks for to check the sharding arithmetic).
+ * Replaces the same reference call as limo_ba_solve (bundle_adjuster_keyframes.cpp:629-767).
+ */
+#define LIMO_COMM_ID_BYTES 128
+int limo_comm_unique_id(unsigned char id[LIMO_COMM_ID_BYTES]);            /* rank 0; broadcast the bytes to all ranks */
+int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES], int rank, int world);
+int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
+                          limo_ba_report* report);
+
+/*
  * Evaluate the reprojection / depth residual blocks of a window at its current parameters
  * (Problem::Evaluate semantics).  Outputs are per observation in the caller's observation order; rows
  * 0,1 = reprojection (u,v), row 2 = depth (zero when the observation has no depth):

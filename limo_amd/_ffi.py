@@ -163,6 +163,9 @@ ABI_SYMBOLS = [
     "limo_ba_batch_destroy",
     "limo_ba_batch_kernel_stats",
     "limo_ba_batch_kernel_time",
+    "limo_comm_unique_id",
+    "limo_ctx_comm_init",
+    "limo_ba_solve_sharded",
     "limo_ba_evaluate",
     "limo_ba_adjust_pose_only",
     "limo_landmark_init",
@@ -204,6 +207,9 @@ def load():
     lib.limo_ba_batch_destroy.restype = None
     lib.limo_ba_batch_kernel_stats.argtypes = [vp, C.c_int, c_double_p, c_int64_p, c_double_p]
     lib.limo_ba_batch_kernel_time.argtypes = [vp, C.c_int, c_double_p, c_int64_p]
+    lib.limo_comm_unique_id.argtypes = [C.c_char_p]
+    lib.limo_ctx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.limo_ba_solve_sharded.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int, C.POINTER(BaReport)]
     lib.limo_ba_evaluate.argtypes = [
         vp,
         C.POINTER(BaWindow),

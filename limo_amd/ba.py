@@ -61,6 +61,22 @@ class Context:
         _check(self.lib.limo_ba_solve(self.ptr, C.byref(s), C.byref(opts), C.byref(rep)), self.ptr, "limo_ba_solve")
         return rep.as_dict()
 
+    def solve_sharded(self, window, opts, n_shards):
+        """Landmark-sharded solve of one window: ranks of the communicator set by comm_init(), or
+        n_shards virtual shards on this GPU when there is none."""
+        s = window.as_struct()
+        rep = _ffi.BaReport()
+        _check(self.lib.limo_ba_solve_sharded(self.ptr, C.byref(s), C.byref(opts), int(n_shards), C.byref(rep)), self.ptr, "limo_ba_solve_sharded")
+        return rep.as_dict()
+
+    def comm_init(self, unique_id, rank, world):
+        _check(self.lib.limo_ctx_comm_init(self.ptr, unique_id, int(rank), int(world)), self.ptr, "limo_ctx_comm_init")
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        _check(self.lib.limo_comm_unique_id(buf), self.ptr, "limo_comm_unique_id")
+        return buf.raw
+
     def adjust_pose_only(self, window, prior, opts):
         s = window.as_struct()
         rep = _ffi.BaReport()

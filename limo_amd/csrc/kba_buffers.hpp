@@ -1,7 +1,9 @@
 // kba_buffers.hpp — the list of buffers behind a BatchView, written once so the HIP library (hipMalloc /
 // hipMemcpy) and the test emulator (malloc / memcpy) allocate exactly the same layout.
 #pragma once
+#include <algorithm>
 #include <cstddef>
+#include <vector>
 
 #include "kba_pack.hpp"
 
@@ -103,6 +105,34 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(trim_dep, TL * D, nullptr);
     KBA_BUF(n_active, 4 * I, nullptr);
 #undef KBA_BUF
+}
+
+// Per-workgroup partial arrays that cross from the landmark-side kernels (owned by ONE shard of a landmark-sharded
+// solve) to the window-level kernels (replicated on every shard): the exchange set of SURVEY §8e.  `point` bits:
+// 1 = before k_cam_assemble, 2 = before k_cam_solve, 4 = before k_step_decide, 8 = before k_trim_select.
+struct PartialArray {
+    size_t member;  // offset of the pointer inside BatchView
+    size_t count;   // elements
+    bool is_int;    // int32 (else double)
+    int point;
+};
+inline std::vector<PartialArray> partial_arrays(const PackedBatch& P) {
+    const size_t NB = (size_t)std::max(1, P.n_blk), NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG),
+                 TL = (size_t)std::max(1, P.TL);
+    return {
+        {offsetof(BatchView, blk_part), NB * kLinPartial, false, 1},
+        {offsetof(BatchView, blk_fail), NB, true, 1},
+        {offsetof(BatchView, gp_r), (size_t)P.SG, false, 1},
+        {offsetof(BatchView, gp_F), (size_t)P.SG * 10, false, 1},
+        {offsetof(BatchView, gp_cost), TG, false, 1},
+        {offsetof(BatchView, lblk_part), NL * 8, false, 1 | 2 | 4},
+        {offsetof(BatchView, S_part), (size_t)std::max<int64_t>(1, P.spart_total), false, 2},
+        {offsetof(BatchView, blk_cost_c), NB, false, 4},
+        {offsetof(BatchView, blk_fail_c), NB, true, 4},
+        {offsetof(BatchView, gp_cost_c), TG, false, 4},
+        {offsetof(BatchView, trim_rep), TL, false, 8},
+        {offsetof(BatchView, trim_dep), TL, false, 8},
+    };
 }
 
 }  // namespace kba

@@ -134,9 +134,11 @@ __global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, co
     if (threadIdx.x == 0) bv.blk_fail_c[b] = any_fail;
 }
 
-__global__ void k_gp(BatchView bv, int candidate) {
+// shard / n_shards: landmark sharding - a shard evaluates only the rows of its own landmarks.
+__global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= bv.TG) return;
+    if (n_shards > 1 && bv.lm_id[bv.gp_lm[g]] % n_shards != shard) return;
     const int w = bv.lm_win[bv.gp_lm[g]];
     const WinState& st = bv.st[w];
     if (!st.active) return;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         fetch_data(gl0, st0, slot0, nxt);
     }
 
-    for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
+    for (int l0 = 0; l0 < (dbg == 38 ? 0 : n_lm_blk); l0 += kSchurLm) {
         const int nl = min(kSchurLm, n_lm_blk - l0);
         const bool tile_gp = lm_first + l0 + nl > wd.lm_gp0;  // wave-uniform
         const int Tt = tile_gp ? T : Tq;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
                 for (int a = 0; a < kCamSlots; ++a) {
                     if (a < 6 || tile_gp) {
                         const int zc = zc_s[my_kl * kCamSlots + a];
-                        if (zc >= 0) {
+                        if (zc >= 0 && dbg != 36) {
                             Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
                             Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
                             Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         for (int ks = 0; ks < ksteps; ++ks) {
             double pan[TM];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) pan[t] = t < Tt ? zp[ks * 4 * ld + 16 * t] : 0.0;
+            for (int t = 0; t < TM; ++t) pan[t] = (t < Tt && dbg != 37) ? zp[ks * 4 * ld + 16 * t] : 1.0;
             int idx = 0;
 #pragma unroll
             for (int tr = 0; tr < TM; ++tr)
@@ -482,16 +484,17 @@ __global__ void k_accept(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ trimming
-__global__ __launch_bounds__(kBlock) void k_trim_residual(BatchView bv, double* plane_rep, double* plane_dep) {
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(kBlock) void k_trim_residual(BatchView bv, double* plane_rep, double* plane_dep, const int32_t* wl) {
+    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.win[w].do_trim) return;
     for (int q = 0; q < kObsPerLane; ++q) trim_residual_lane(bv, b, threadIdx.x + q * kBlock, plane_rep, plane_dep);
 }
 
-__global__ void k_trim_max(BatchView bv, const double* plane_rep, const double* plane_dep) {
+__global__ void k_trim_max(BatchView bv, const double* plane_rep, const double* plane_dep, int shard, int n_shards) {
     const int gl = blockIdx.x * blockDim.x + threadIdx.x;
     if (gl >= bv.TL) return;
+    if (n_shards > 1 && bv.lm_id[gl] % n_shards != shard) return;
     if (!bv.win[bv.lm_win[gl]].do_trim) return;
     trim_max_lane(bv, gl, plane_rep, plane_dep);
 }
@@ -580,6 +583,31 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
         }
     }
     if (removed) atomicAdd(&bv.st[w].n_trimmed, removed);
+}
+
+// ------------------------------------------------------------------------------------------ landmark sharding
+// Exchange step of the landmark-sharded solve when the shards live on ONE GPU ("virtual shards"): the
+// same sum an RCCL all-reduce forms, in shard order.  Every entry has exactly one owner (the other shards hold
+// zero), so the result is exact for any order.
+struct ShardPtrs {
+    const void* p[8];
+};
+template <typename T>
+__global__ void k_sum_shards(T* dst, ShardPtrs src, int n_shards, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T acc = static_cast<const T*>(src.p[0])[i];
+    for (int r = 1; r < n_shards; ++r) acc += static_cast<const T*>(src.p[r])[i];
+    dst[i] = acc;
+}
+
+// out = landmark positions of the landmarks this shard owns, zero elsewhere (input of the final all-reduce that
+// gives every rank every landmark).
+__global__ void k_lm_owned(BatchView bv, double* out, int rank, int n_shards, int world) {
+    const int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gl >= bv.TL) return;
+    const bool mine = (bv.lm_id[gl] % n_shards) % world == rank;  // shard s lives on rank s mod world
+    for (int i = 0; i < 3; ++i) out[3 * (int64_t)gl + i] = mine ? bv.lm[3 * (int64_t)gl + i] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------ evaluate (Problem::Evaluate)

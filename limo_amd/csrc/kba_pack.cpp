@@ -51,6 +51,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     }
     P = PackedBatch();
     P.n_win = n;
+    P.n_shards = std::max(1, po.shards);
     P.evaluate_only = po.evaluate_only;
     P.win.resize(n);
     // ---- pass 1: sizes, views
@@ -195,15 +196,27 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 }
             }
         }
-        // packed landmark order: plain landmarks (input order), then ground-plane landmarks (input order)
-        std::vector<int> perm(W.n_lm);
+        // packed landmark order: plain landmarks, then ground-plane landmarks; inside each class by owning shard
+        // (landmark id mod n_shards), then input order.  seg[] = start of every run of one (class, shard):
+        // with n_shards > 1 no workgroup straddles a run, so every workgroup has exactly one owner.
+        const int NS = std::max(1, po.shards);
+        std::vector<int> perm(W.n_lm), seg;
         {
             int nxt = 0;
             for (int pass = 0; pass < 2; ++pass)
-                for (int l = 0; l < W.n_lm; ++l)
-                    if (has_gp[l] == pass) perm[l] = nxt++;
+                for (int r = 0; r < NS; ++r) {
+                    const int before = nxt;
+                    for (int l = 0; l < W.n_lm; ++l)
+                        if (has_gp[l] == pass && l % NS == r) perm[l] = nxt++;
+                    if (NS > 1 && nxt > before) seg.push_back(before);
+                }
+            if (seg.empty()) seg.push_back(0);
+            seg.push_back(W.n_lm);
             d.lm_gp0 = d.lm0 + W.n_lm - (int)gp_tmp.size();
         }
+        std::vector<int> seg_of(W.n_lm, 0);  // run index of a packed landmark
+        for (size_t si = 0; si + 1 < seg.size(); ++si)
+            for (int l = seg[si]; l < seg[si + 1]; ++l) seg_of[l] = (int)si;
         for (int l = 0; l < W.n_lm; ++l) {
             const int g = d.lm0 + perm[l];
             P.lm_win[g] = w;
@@ -239,13 +252,22 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         for (int v = 0; v < d.n_view; ++v) {
             const int start = pos;
             while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
-            for (int b0 = start; b0 < pos; b0 += kObsBlock) {
+            for (int b0 = start; b0 < pos;) {
+                int b1 = std::min(pos, b0 + kObsBlock);
+                const int s0 = seg_of[perm[W.obs_lm[order[b0]]]];
+                for (int i = b0 + 1; i < b1; ++i)
+                    if (seg_of[perm[W.obs_lm[order[i]]]] != s0) {
+                        b1 = i;
+                        break;
+                    }
                 const int gkf = d.kf0 + views[w][v].kf;
                 if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
                 P.kf_nblk[gkf]++;
                 P.blk_view.push_back(d.view0 + v);
                 P.blk_obs0.push_back(d.obs0 + b0);
-                P.blk_n.push_back(std::min(kObsBlock, pos - b0));
+                P.blk_n.push_back(b1 - b0);
+                P.blk_owner.push_back(W.obs_lm[order[b0]] % NS);
+                b0 = b1;
             }
             for (int i = start; i < pos; ++i) {
                 const int src = order[i];
@@ -286,6 +308,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 P.gp_lm.push_back(d.lm0 + perm[g.lm]);
                 P.gp_kf.push_back(d.kf0 + g.kf);
                 P.gp_w.push_back(g.w);
+                P.gp_owner.push_back(g.lm % NS);
             }
         }
         d.n_gp = (int)P.gp_lm.size() - d.gp0;
@@ -354,20 +377,24 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
 
         // ---- workgroup tables
         d.lblk0 = (int)P.lblk_win.size();
-        for (int l0 = 0; l0 < W.n_lm; l0 += kBlock) {
-            P.lblk_win.push_back(w);
-            P.lblk_lm0.push_back(d.lm0 + l0);
-            P.lblk_n.push_back(std::min(kBlock, W.n_lm - l0));
-        }
+        for (size_t si = 0; si + 1 < seg.size(); ++si)
+            for (int l0 = seg[si]; l0 < seg[si + 1]; l0 += kBlock) {
+                P.lblk_win.push_back(w);
+                P.lblk_lm0.push_back(d.lm0 + l0);
+                P.lblk_n.push_back(std::min(kBlock, seg[si + 1] - l0));
+                P.lblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
+            }
         d.n_lblk = (int)P.lblk_win.size() - d.lblk0;
         d.sblk0 = (int)P.sblk_win.size();
         if (!po.pose_only && !po.evaluate_only && d.nf > 0) {
             const int per = kSchurLmPerBlock;
-            for (int l0 = 0; l0 < W.n_lm; l0 += per) {
-                P.sblk_win.push_back(w);
-                P.sblk_lm0.push_back(d.lm0 + l0);
-                P.sblk_n.push_back(std::min(per, W.n_lm - l0));
-            }
+            for (size_t si = 0; si + 1 < seg.size(); ++si)
+                for (int l0 = seg[si]; l0 < seg[si + 1]; l0 += per) {
+                    P.sblk_win.push_back(w);
+                    P.sblk_lm0.push_back(d.lm0 + l0);
+                    P.sblk_n.push_back(std::min(per, seg[si + 1] - l0));
+                    P.sblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
+                }
         }
         d.n_sblk = (int)P.sblk_win.size() - d.sblk0;
         d.hcc_off = P.hcc_total;

@@ -18,6 +18,8 @@ struct PackedBatch {
     int64_t SO = 0, SL = 0, SG = 0;
     int64_t hcc_total = 0, spart_total = 0;
     bool evaluate_only = false;  // planes hold the full Jacobians instead of the factored form
+    int32_t n_shards = 1;        // landmark shards; owner of landmark l = (caller's index of l) mod n_shards
+    std::vector<int32_t> blk_owner, lblk_owner, sblk_owner, gp_owner;  // owning shard of every workgroup / gp row
     std::vector<WinDesc> win;
     std::vector<double> pose, pdir, pdist, lm;  // initial parameters
     std::vector<int32_t> kf_win, kf_blk0, kf_nblk, kf_gp0, kf_ngp;
@@ -42,6 +44,7 @@ struct PackOptions {
     bool pose_only = false;
     bool evaluate_only = false;  // no problem-build logic (no ground plane / regularisers), every parameter free
     const limo_speed_prior* prior = nullptr;
+    int shards = 1;  // > 1: lay the batch out for landmark sharding (no workgroup straddles two shards)
 };
 
 // Returns LIMO_OK or a negative limo_status; err receives a message.

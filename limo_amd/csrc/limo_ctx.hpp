@@ -12,4 +12,6 @@ struct limo_ctx {
     std::string err;
     void* depth_ws = nullptr;               // workspace of limo_depth_estimate (depth.hip), grown on demand
     void (*depth_ws_free)(void*) = nullptr;
+    void* comm = nullptr;                   // ncclComm_t of a landmark-sharded solve (limo_ctx_comm_init), else null
+    int comm_rank = 0, comm_world = 1;
 };

@@ -2,6 +2,7 @@
 // Host side: packing (kba_pack.cpp), device allocation, launch sequencing, result download.
 // There is NO CPU fallback here: without a HIP device limo_ctx_create fails with LIMO_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -79,6 +80,25 @@ struct limo_ba_batch : Executor {
              : T <= 4 ? (const void*)k_schur<4, false> : T <= 6 ? (const void*)k_schur<6, false> : (const void*)k_schur<8, false>;
     }
     int rc = LIMO_OK;
+    // ---- landmark sharding.  shard_P == 1: everything below is inert (pv = {bv}).
+    // Every shard holds the same global layout and owns the observation / landmark / Schur workgroups of its
+    // landmarks (rank lists); the per-workgroup partial arrays it produces live in its own "producer view" pv[i] and
+    // are summed into the consumer view bv before each window-level kernel: by RCCL all-reduce when the shards are
+    // ranks (one local shard), by k_sum_shards when all shards are virtual on this GPU.
+    int shard_P = 1, shard_rank = 0;
+    bool shard_virtual = true;
+    std::vector<int> local_shards;
+    std::vector<BatchView> pv;
+    std::vector<PartialArray> parts;
+    struct RankLists {
+        int32_t *full_blk = nullptr, *full_lblk = nullptr, *full_sblk = nullptr;  // every window listed
+        int32_t *act_blk = nullptr, *act_lblk = nullptr, *act_sblk = nullptr;     // re-batched active set
+        int n_full_blk = 0, n_full_lblk = 0, n_full_sblk = 0;
+        const int32_t *blk = nullptr, *lblk = nullptr, *sblk = nullptr;           // lists in use
+        int n_blk = 0, n_lblk = 0, n_sblk = 0;
+    };
+    std::vector<RankLists> rl;
+    double* d_lm_tmp = nullptr;
     // kernel timing (linearize) via HIP events on the batch's stream
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
@@ -127,6 +147,36 @@ struct limo_ba_batch : Executor {
             *slot = p;
         });
         if (status != LIMO_OK) return status;
+        pv.assign(1, bv);
+        if (shard_P > 1) {
+            parts = partial_arrays(P);
+            pv.assign(local_shards.size(), bv);
+            rl.assign(local_shards.size(), RankLists());
+            for (size_t i = 0; i < local_shards.size(); ++i) {
+                for (const PartialArray& pa : parts) {  // private, zero-initialised partial arrays of this shard
+                    void* q = nullptr;
+                    const size_t bytes = pa.count * (pa.is_int ? sizeof(int32_t) : sizeof(double));
+                    if (dmalloc(&q, bytes)) return LIMO_ERR_RUNTIME;
+                    HIP_TRY(ctx, hipMemsetAsync(q, 0, bytes, ctx->stream));
+                    *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member) = q;
+                }
+                const int r = local_shards[i];
+                auto make = [&](const std::vector<int32_t>& owner, int32_t** full, int32_t** act, int* n) -> int {
+                    std::vector<int32_t> v;
+                    for (size_t k = 0; k < owner.size(); ++k)
+                        if (owner[k] == r) v.push_back((int32_t)k);
+                    *n = (int)v.size();
+                    if (dmalloc((void**)full, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
+                    if (dmalloc((void**)act, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
+                    if (!v.empty()) HIP_TRY(ctx, hipMemcpy(*full, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+                    return LIMO_OK;
+                };
+                if (make(P.blk_owner, &rl[i].full_blk, &rl[i].act_blk, &rl[i].n_full_blk)) return LIMO_ERR_RUNTIME;
+                if (make(P.lblk_owner, &rl[i].full_lblk, &rl[i].act_lblk, &rl[i].n_full_lblk)) return LIMO_ERR_RUNTIME;
+                if (make(P.sblk_owner, &rl[i].full_sblk, &rl[i].act_sblk, &rl[i].n_full_sblk)) return LIMO_ERR_RUNTIME;
+            }
+            if (!shard_virtual && dmalloc((void**)&d_lm_tmp, sizeof(double) * 3 * std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
+        }
         if (dmalloc((void**)&d_plane_rep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_plane_dep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_pose0, sizeof(double) * 7 * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
@@ -221,6 +271,44 @@ struct limo_ba_batch : Executor {
     void set_span(int n_windows_listed) {
         const int64_t coarse_waves = (int64_t)n_windows_listed * std::max(1, avg_sblk) / 4;
         c.schur_span = coarse_waves >= 2048 ? 4 : coarse_waves >= 1024 ? 2 : 1;
+        if (shard_P > 1) c.schur_span = 1;  // Schur blocks are cut at shard boundaries
+    }
+
+    // ---- sharding helpers
+    const int32_t* list_blk(size_t i) const { return shard_P > 1 ? rl[i].blk : (use_wl ? d_wl_blk : nullptr); }
+    const int32_t* list_lblk(size_t i) const { return shard_P > 1 ? rl[i].lblk : (use_wl ? d_wl_lblk : nullptr); }
+    const int32_t* list_sblk(size_t i) const { return shard_P > 1 ? rl[i].sblk : d_wl_sblk; }
+    int count_blk(size_t i) const { return shard_P > 1 ? rl[i].n_blk : n_wl_blk; }
+    int count_lblk(size_t i) const { return shard_P > 1 ? rl[i].n_lblk : n_wl_lblk; }
+    int count_sblk(size_t i) const { return shard_P > 1 ? rl[i].n_sblk : n_wl_sblk; }
+    int shard_of(size_t i) const { return shard_P > 1 ? local_shards[i] : 0; }
+
+    // Exchange step: sum the shards' partial arrays of `point` into the consumer view.
+    void allreduce(int point) {
+        if (shard_P == 1) return;
+        hipStream_t s = ctx->stream;
+        for (const PartialArray& pa : parts) {
+            if (!(pa.point & point)) continue;
+            void* dst = *reinterpret_cast<void**>(reinterpret_cast<char*>(&bv) + pa.member);
+            {   // sum of the local shards, in shard order
+                ShardPtrs sp;
+                for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member);
+                const int nb = cdiv((int64_t)pa.count, 256);
+                const int nl = (int)pv.size();
+                if (pa.is_int)
+                    hipLaunchKernelGGL(k_sum_shards<int32_t>, dim3(nb), dim3(256), 0, s, (int32_t*)dst, sp, nl, (int64_t)pa.count);
+                else
+                    hipLaunchKernelGGL(k_sum_shards<double>, dim3(nb), dim3(256), 0, s, (double*)dst, sp, nl, (int64_t)pa.count);
+                LAUNCH_CHECK("k_sum_shards");
+            }
+            if (!shard_virtual) {  // ... then over the ranks (in place)
+                ncclResult_t r = ncclAllReduce(dst, dst, pa.count, pa.is_int ? ncclInt32 : ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+                if (r != ncclSuccess && rc == LIMO_OK) {
+                    rc = LIMO_ERR_RUNTIME;
+                    ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
+                }
+            }
+        }
     }
 
     void full_lists() {
@@ -233,6 +321,14 @@ struct limo_ba_batch : Executor {
         const int k = c.schur_span == 4 ? 2 : c.schur_span == 2 ? 1 : 0;
         d_wl_sblk = d_wl_sblk_full[k];
         n_wl_sblk = n_wl_sblk_full[k];
+        for (RankLists& r : rl) {
+            r.blk = r.full_blk;
+            r.lblk = r.full_lblk;
+            r.sblk = r.full_sblk;
+            r.n_blk = r.n_full_blk;
+            r.n_lblk = r.n_full_lblk;
+            r.n_sblk = r.n_full_sblk;
+        }
     }
 
     // Rebuild the worklists from the windows that are active right now (synchronises the stream).
@@ -263,6 +359,32 @@ struct limo_ba_batch : Executor {
         d_wl_sblk = d_wl_sblk_part;
         up(d_wl_sblk, wsb);
         up(d_wl_win, ww);
+        std::vector<std::vector<int32_t>> keep;  // host lists of the shards, alive until the sync below
+        for (size_t i = 0; i < rl.size(); ++i) {
+            const int r = local_shards[i];
+            std::vector<int32_t> b1, b2, b3;
+            for (int w : ww) {
+                const WinDesc& d = P.win[w];
+                for (int k = d.blk0; k < d.blk0 + d.n_blk; ++k)
+                    if (P.blk_owner[k] == r) b1.push_back(k);
+                for (int k = d.lblk0; k < d.lblk0 + d.n_lblk; ++k)
+                    if (P.lblk_owner[k] == r) b2.push_back(k);
+                for (int k = d.sblk0; k < d.sblk0 + d.n_sblk; ++k)
+                    if (P.sblk_owner[k] == r) b3.push_back(k);
+            }
+            up(rl[i].act_blk, b1);
+            up(rl[i].act_lblk, b2);
+            up(rl[i].act_sblk, b3);
+            rl[i].blk = rl[i].act_blk;
+            rl[i].lblk = rl[i].act_lblk;
+            rl[i].sblk = rl[i].act_sblk;
+            rl[i].n_blk = (int)b1.size();
+            rl[i].n_lblk = (int)b2.size();
+            rl[i].n_sblk = (int)b3.size();
+            keep.push_back(std::move(b1));
+            keep.push_back(std::move(b2));
+            keep.push_back(std::move(b3));
+        }
         note(hipStreamSynchronize(s), "sync worklists");  // the host vectors go out of scope
         use_wl = true;
         n_wl_blk = (int)wb.size();
@@ -297,20 +419,26 @@ struct limo_ba_batch : Executor {
 
     void linearize() override {
         hipStream_t s = ctx->stream;
-        if (n_wl_blk) {
+        {
             EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
-            hipLaunchKernelGGL(k_linearize, dim3(n_wl_blk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_blk : nullptr);
-            LAUNCH_CHECK("k_linearize");
+            for (size_t i = 0; i < pv.size(); ++i)
+                if (count_blk(i)) {
+                    hipLaunchKernelGGL(k_linearize, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
+                    LAUNCH_CHECK("k_linearize");
+                }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
-        if (P.TG) {
-            hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 0);
-            LAUNCH_CHECK("k_gp");
+        for (size_t i = 0; i < pv.size(); ++i) {
+            if (P.TG) {
+                hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 0, shard_of(i), shard_P);
+                LAUNCH_CHECK("k_gp");
+            }
+            if (count_lblk(i)) {
+                hipLaunchKernelGGL(k_lm_accum, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], c, list_lblk(i));
+                LAUNCH_CHECK("k_lm_accum");
+            }
         }
-        if (n_wl_lblk) {
-            hipLaunchKernelGGL(k_lm_accum, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_lblk : nullptr);
-            LAUNCH_CHECK("k_lm_accum");
-        }
+        allreduce(1);
         // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
         const int slot = it_no & 3;
         note(hipMemsetAsync(bv.n_active + slot, 0, sizeof(int32_t), s), "memset n_active");
@@ -346,33 +474,41 @@ struct limo_ba_batch : Executor {
 
     void step() override {
         hipStream_t s = ctx->stream;
-        if (n_wl_lblk) {
-            hipLaunchKernelGGL(k_lm_damp, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_lblk : nullptr);
-            LAUNCH_CHECK("k_lm_damp");
-        }
-        if (n_wl_sblk) {
-            const int32_t* wlp = d_wl_sblk;
-            int span = c.schur_span, dbg = c.pad;
-            void* args[] = {(void*)&bv, (void*)&wlp, (void*)&span, (void*)&dbg};
+        for (size_t i = 0; i < pv.size(); ++i)
+            if (count_lblk(i)) {
+                hipLaunchKernelGGL(k_lm_damp, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], c, list_lblk(i));
+                LAUNCH_CHECK("k_lm_damp");
+            }
+        {
             EventPair* ep = timed(LIMO_KERNEL_SCHUR);
-            note(hipLaunchKernel(schur_fn, dim3(n_wl_sblk), dim3(64), args, max_ld_bytes, s), "launch k_schur");
+            for (size_t i = 0; i < pv.size(); ++i)
+                if (count_sblk(i)) {
+                    const int32_t* wlp = list_sblk(i);
+                    int span = c.schur_span, dbg = c.pad;
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
+                    note(hipLaunchKernel(schur_fn, dim3(count_sblk(i)), dim3(64), args, max_ld_bytes, s), "launch k_schur");
+                    LAUNCH_CHECK("k_schur");
+                }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
-            LAUNCH_CHECK("k_schur");
         }
+        allreduce(2);
         if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_cam_solve");
-        if (n_wl_lblk) {
-            hipLaunchKernelGGL(k_backsub, dim3(n_wl_lblk), dim3(kBlock), 0, s, bv, use_wl ? d_wl_lblk : nullptr);
-            LAUNCH_CHECK("k_backsub");
+        for (size_t i = 0; i < pv.size(); ++i) {
+            if (count_lblk(i)) {
+                hipLaunchKernelGGL(k_backsub, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], list_lblk(i));
+                LAUNCH_CHECK("k_backsub");
+            }
+            if (count_blk(i)) {
+                hipLaunchKernelGGL(k_cost, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
+                LAUNCH_CHECK("k_cost");
+            }
+            if (P.TG) {
+                hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 1, shard_of(i), shard_P);
+                LAUNCH_CHECK("k_gp(cand)");
+            }
         }
-        if (n_wl_blk) {
-            hipLaunchKernelGGL(k_cost, dim3(n_wl_blk), dim3(kBlock), 0, s, bv, c, use_wl ? d_wl_blk : nullptr);
-            LAUNCH_CHECK("k_cost");
-        }
-        if (P.TG) {
-            hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, bv, 1);
-            LAUNCH_CHECK("k_gp(cand)");
-        }
+        allreduce(4);
         if (n_wl_win) hipLaunchKernelGGL(k_step_decide, dim3(n_wl_win), dim3(64), 0, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_step_decide");
         hipLaunchKernelGGL(k_accept, dim3(cdiv((int64_t)P.TK + P.TL, 256)), dim3(256), 0, s, bv);
@@ -384,15 +520,22 @@ struct limo_ba_batch : Executor {
         bool any = false;
         for (const WinDesc& d : P.win) any = any || d.do_trim;
         if (!any) return;
-        if (P.n_blk) {
-            hipLaunchKernelGGL(k_trim_residual, dim3(P.n_blk), dim3(kBlock), 0, s, bv, d_plane_rep, d_plane_dep);
-            LAUNCH_CHECK("k_trim_residual");
+        for (size_t i = 0; i < pv.size(); ++i) {
+            const int nb = shard_P > 1 ? rl[i].n_full_blk : P.n_blk;
+            if (nb) {
+                hipLaunchKernelGGL(k_trim_residual, dim3(nb), dim3(kBlock), 0, s, pv[i], d_plane_rep, d_plane_dep,
+                                   shard_P > 1 ? (const int32_t*)rl[i].full_blk : (const int32_t*)nullptr);
+                LAUNCH_CHECK("k_trim_residual");
+            }
         }
         if (P.TL) {
-            hipLaunchKernelGGL(k_trim_max, dim3(cdiv(P.TL, 256)), dim3(256), 0, s, bv, (const double*)d_plane_rep,
-                               (const double*)d_plane_dep);
-            LAUNCH_CHECK("k_trim_max");
+            for (size_t i = 0; i < pv.size(); ++i) {
+                hipLaunchKernelGGL(k_trim_max, dim3(cdiv(P.TL, 256)), dim3(256), 0, s, pv[i], (const double*)d_plane_rep,
+                                   (const double*)d_plane_dep, shard_of(i), shard_P);
+                LAUNCH_CHECK("k_trim_max");
+            }
         }
+        allreduce(8);
         hipLaunchKernelGGL(k_trim_select, dim3(P.n_win), dim3(kBlock), trim_bytes, s, bv, c);
         LAUNCH_CHECK("k_trim_select");
     }
@@ -439,6 +582,7 @@ int limo_ctx_create(int device, limo_ctx** out) {
 void limo_ctx_destroy(limo_ctx* ctx) {
     if (!ctx) return;
     if (ctx->depth_ws && ctx->depth_ws_free) ctx->depth_ws_free(ctx->depth_ws);
+    if (ctx->comm) (void)ncclCommDestroy((ncclComm_t)ctx->comm);
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
 }
@@ -479,7 +623,7 @@ void limo_ba_default_options(limo_ba_options* o) {
 }
 
 static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* windows, const limo_ba_options* opts,
-                             const PackOptions& po, limo_ba_batch** out) {
+                             const PackOptions& po, limo_ba_batch** out, bool shards_are_ranks = false) {
     if (!ctx || !out) return LIMO_ERR_INVALID;
     *out = nullptr;
     limo_ba_options o;
@@ -494,6 +638,19 @@ static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* win
     int rc = pack_windows(n, windows, o, po, b->P, ctx->err);
     if (rc == LIMO_OK) {
         if (hipSetDevice(ctx->device) != hipSuccess) rc = LIMO_ERR_NO_DEVICE;
+    }
+    b->shard_P = b->P.n_shards;
+    b->shard_virtual = !shards_are_ranks;
+    b->shard_rank = shards_are_ranks ? ctx->comm_rank : 0;
+    if (b->shard_P > 1) {  // shard s lives on rank s mod world (all of them here when there is no communicator)
+        const int world = shards_are_ranks ? ctx->comm_world : 1, me = shards_are_ranks ? ctx->comm_rank : 0;
+        for (int r = 0; r < b->shard_P; ++r)
+            if (r % world == me) b->local_shards.push_back(r);
+        if (b->local_shards.size() > 8) {
+            ctx->err = "at most 8 shards per GPU";
+            delete b;
+            return LIMO_ERR_INVALID;
+        }
     }
     if (rc == LIMO_OK) rc = b->upload();
     if (rc != LIMO_OK) {
@@ -527,6 +684,15 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(b->ev_total_a, ctx->stream));
     run_schedule(*b, b->opts);
+    if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
+        hipLaunchKernelGGL(k_lm_owned, dim3(cdiv(b->P.TL, 256)), dim3(256), 0, ctx->stream, b->bv, b->d_lm_tmp, b->shard_rank, b->shard_P,
+                           ctx->comm_world);
+        ncclResult_t r = ncclAllReduce(b->d_lm_tmp, b->bv.lm, (size_t)3 * b->P.TL, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+        if (r != ncclSuccess) {
+            ctx->err = std::string("ncclAllReduce(landmarks): ") + ncclGetErrorString(r);
+            return LIMO_ERR_RUNTIME;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(b->ev_total_b, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -622,6 +788,56 @@ int limo_ba_batch_kernel_time(limo_ba_batch* b, int kernel, double* ms, int64_t*
     if (ms) *ms = b->k_ms_acc[kernel];
     if (launches) *launches = b->k_launches[kernel];
     return LIMO_OK;
+}
+
+int limo_comm_unique_id(unsigned char id[LIMO_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) <= LIMO_COMM_ID_BYTES, "ncclUniqueId does not fit");
+    if (!id) return LIMO_ERR_INVALID;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return LIMO_ERR_RUNTIME;
+    std::memset(id, 0, LIMO_COMM_ID_BYTES);
+    std::memcpy(id, &u, sizeof(u));
+    return LIMO_OK;
+}
+
+int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES], int rank, int world) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return LIMO_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    if (ctx->comm) {
+        (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclCommInitRank(&comm, world, u, rank);
+    if (r != ncclSuccess) {
+        ctx->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
+        return LIMO_ERR_RUNTIME;
+    }
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return LIMO_OK;
+}
+
+int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
+                          limo_ba_report* report) {
+    if (!ctx || !window) return LIMO_ERR_INVALID;
+    const bool ranks = ctx->comm != nullptr;
+    if (n_shards < 1 || (ranks && n_shards % ctx->comm_world != 0) || n_shards > 8 * (ranks ? ctx->comm_world : 1)) {
+        ctx->err = "limo_ba_solve_sharded: n_shards must be a multiple of the communicator size, at most 8 shards per GPU";
+        return LIMO_ERR_INVALID;
+    }
+    PackOptions po;
+    po.shards = n_shards;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, po, &b, ranks);
+    if (rc != LIMO_OK) return rc;
+    rc = limo_ba_batch_solve(b, opts);
+    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
+    limo_ba_batch_destroy(b);
+    return rc;
 }
 
 int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report) {

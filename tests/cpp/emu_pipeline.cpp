@@ -18,12 +18,23 @@ using namespace kba;
 
 namespace {
 
+// Exchange callback of a landmark-sharded run whose shards are separate processes (tests: torch.distributed / gloo):
+// recv = element-wise sum over all ranks of send.
+typedef void (*emu_allreduce_fn)(const void* send, void* recv, int64_t count, int is_int, void* user);
+
 struct EmuBatch : Executor {
     PackedBatch P;
-    BatchView bv;
+    BatchView bv;  // consumer view (window-level items); == the only view when not sharded
     SolveConsts c;
     std::vector<void*> allocs;
     std::vector<double> plane_rep, plane_dep;
+    // landmark sharding (mirrors limo_ba_batch): producer views of the local shards, partial arrays private to each
+    int shard_P = 1;
+    std::vector<int> local_shards;
+    std::vector<BatchView> pv;
+    std::vector<PartialArray> parts;
+    emu_allreduce_fn cb = nullptr;
+    void* cb_user = nullptr;
 
     ~EmuBatch() override {
         for (void* p : allocs) std::free(p);
@@ -41,6 +52,49 @@ struct EmuBatch : Executor {
         }
         plane_rep.assign(bv.SO, -1.0);
         plane_dep.assign(bv.SO, -1.0);
+        shard_P = P.n_shards;
+        pv.assign(1, bv);
+        if (shard_P > 1) {
+            if (local_shards.empty())
+                for (int r = 0; r < shard_P; ++r) local_shards.push_back(r);
+            parts = partial_arrays(P);
+            pv.assign(local_shards.size(), bv);
+            for (BatchView& v : pv)
+                for (const PartialArray& pa : parts) {
+                    void* q = std::calloc(pa.count, pa.is_int ? sizeof(int32_t) : sizeof(double));
+                    allocs.push_back(q);
+                    *reinterpret_cast<void**>(reinterpret_cast<char*>(&v) + pa.member) = q;
+                }
+        }
+    }
+    bool owns(size_t i, int owner) const { return shard_P == 1 || owner == local_shards[i]; }
+    bool owns_lm(size_t i, int gl) const { return shard_P == 1 || bv.lm_id[gl] % shard_P == local_shards[i]; }
+    bool owned_here(int gl) const {
+        for (size_t i = 0; i < pv.size(); ++i)
+            if (owns_lm(i, gl)) return true;
+        return false;
+    }
+    void exchange(int point) {
+        if (shard_P == 1) return;
+        for (const PartialArray& pa : parts) {
+            if (!(pa.point & point)) continue;
+            void* dst = *reinterpret_cast<void**>(reinterpret_cast<char*>(&bv) + pa.member);
+            auto src = [&](size_t i) { return *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member); };
+            if (pa.is_int) {  // sum of the local shards, in shard order ...
+                for (size_t k = 0; k < pa.count; ++k) {
+                    int32_t a = 0;
+                    for (size_t i = 0; i < pv.size(); ++i) a += static_cast<int32_t*>(src(i))[k];
+                    static_cast<int32_t*>(dst)[k] = a;
+                }
+            } else {
+                for (size_t k = 0; k < pa.count; ++k) {
+                    double a = static_cast<double*>(src(0))[k];
+                    for (size_t i = 1; i < pv.size(); ++i) a += static_cast<double*>(src(i))[k];
+                    static_cast<double*>(dst)[k] = a;
+                }
+            }
+            if (cb) cb(dst, dst, (int64_t)pa.count, pa.is_int ? 1 : 0, cb_user);  // ... then over the ranks, in place
+        }
     }
 
     void solve_init(int max_iter, int select) override {
@@ -54,44 +108,51 @@ struct EmuBatch : Executor {
     }
 
     void linearize() override {
-        // K1: observations
-        for (int b = 0; b < bv.n_blk; ++b) {
-            const int w = bv.view_win[bv.blk_view[b]];
-            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
-            double part[kLinPartial];
-            for (int i = 0; i < kLinPartial; ++i) part[i] = 0.0;
-            int fail = 0;
-            for (int t = 0; t < kObsBlock; ++t) {
-                LinLane l;
-                linearize_lane(bv, c, b, t, l, bv.st[w].first != 0);
-                part[0] += l.cost;
-                for (int i = 0; i < 21; ++i) part[1 + i] += l.U[i];
-                for (int i = 0; i < 6; ++i) part[22 + i] += l.g[i];
-                fail |= l.fail;
+        for (size_t si = 0; si < pv.size(); ++si) {
+            BatchView& v = pv[si];
+            // K1: observations
+            for (int b = 0; b < v.n_blk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.blk_owner[b] : 0)) continue;
+                const int w = v.view_win[v.blk_view[b]];
+                if (!v.st[w].active || !v.st[w].need_lin) continue;
+                double part[kLinPartial];
+                for (int i = 0; i < kLinPartial; ++i) part[i] = 0.0;
+                int fail = 0;
+                for (int t = 0; t < kObsBlock; ++t) {
+                    LinLane l;
+                    linearize_lane(v, c, b, t, l, v.st[w].first != 0);
+                    part[0] += l.cost;
+                    for (int i = 0; i < 21; ++i) part[1 + i] += l.U[i];
+                    for (int i = 0; i < 6; ++i) part[22 + i] += l.g[i];
+                    fail |= l.fail;
+                }
+                for (int i = 0; i < kLinPartial; ++i) v.blk_part[(int64_t)b * kLinPartial + i] = part[i];
+                v.blk_fail[b] = fail;
             }
-            for (int i = 0; i < kLinPartial; ++i) bv.blk_part[(int64_t)b * kLinPartial + i] = part[i];
-            bv.blk_fail[b] = fail;
-        }
-        // ground-plane rows
-        for (int w = 0; w < bv.n_win; ++w) {
-            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
-            const WinDesc& wd = bv.win[w];
-            for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(bv, g, false, bv.gp_cost);
-        }
-        // landmarks
-        for (int b = 0; b < bv.n_lblk; ++b) {
-            const int w = bv.lblk_win[b];
-            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
-            double gmax = 0.0, xn2 = 0.0;
-            for (int t = 0; t < bv.lblk_n[b]; ++t) {
-                double part[8];
-                lm_accum_lane(bv, c, bv.lblk_lm0[b] + t, part);
-                gmax = std::fmax(gmax, part[0]);
-                xn2 += part[1];
+            // ground-plane rows
+            for (int w = 0; w < v.n_win; ++w) {
+                if (!v.st[w].active || !v.st[w].need_lin) continue;
+                const WinDesc& wd = v.win[w];
+                for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g)
+                    if (owns_lm(si, v.gp_lm[g])) gp_lane(v, g, false, v.gp_cost);
             }
-            bv.lblk_part[(int64_t)b * 8 + 0] = gmax;
-            bv.lblk_part[(int64_t)b * 8 + 1] = xn2;
+            // landmarks
+            for (int b = 0; b < v.n_lblk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
+                const int w = v.lblk_win[b];
+                if (!v.st[w].active || !v.st[w].need_lin) continue;
+                double gmax = 0.0, xn2 = 0.0;
+                for (int t = 0; t < v.lblk_n[b]; ++t) {
+                    double part[8];
+                    lm_accum_lane(v, c, v.lblk_lm0[b] + t, part);
+                    gmax = std::fmax(gmax, part[0]);
+                    xn2 += part[1];
+                }
+                v.lblk_part[(int64_t)b * 8 + 0] = gmax;
+                v.lblk_part[(int64_t)b * 8 + 1] = xn2;
+            }
         }
+        exchange(1);
         // camera assemble + LM decision
         std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1));
         for (int w = 0; w < bv.n_win; ++w) {
@@ -113,50 +174,56 @@ struct EmuBatch : Executor {
     }
 
     void step() override {
-        // landmark damping
-        for (int b = 0; b < bv.n_lblk; ++b) {
-            const int w = bv.lblk_win[b];
-            if (!bv.st[w].active) continue;
-            int fail = 0;
-            for (int t = 0; t < bv.lblk_n[b]; ++t) fail |= lm_damp_lane(bv, c, bv.lblk_lm0[b] + t);
-            bv.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
-        }
-        // Schur slabs: upper triangle of Z^T Z per Schur workgroup (rhs = column nfq, see kba_items.hpp)
         std::vector<double> z;
-        for (int sb = 0; sb < bv.n_sblk; ++sb) {
-            const int w = bv.sblk_win[sb];
-            if (!bv.st[w].active) continue;
-            const WinDesc& wd = bv.win[w];
-            const int nfp = wd.nf_pad, nfq = wd.nfq;
-            const int slab = nfp * nfp;
-            std::vector<int> vkl(wd.n_view);
-            for (int j = 0; j < wd.n_view; ++j) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
-            double* out = bv.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
-            for (int i = 0; i < slab; ++i) out[i] = 0.0;
-            for (int li = 0; li < bv.sblk_n[sb]; ++li) {
-                const int gl = bv.sblk_lm0[sb] + li;
-                if (bv.lm_state[gl] != 1) continue;
-                double lmk[9], Y[3 * kCamSlots];
-                schur_load_lm(bv, gl, lmk);
-                z.assign((size_t)3 * nfp, 0.0);
-                for (int kl = 0; kl < wd.n_kf; ++kl) {
-                    schur_pair_block(bv, wd, gl, kl, lmk, bv.scale_c + wd.cam0, vkl.data(), gl >= wd.lm_gp0, Y);
-                    for (int a = 0; a < kCamSlots; ++a) {
-                        const int ci = bv.cslot[wd.cam0 + kl * kCamSlots + a];
-                        if (ci < 0) continue;
-                        for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + schur_col(ci, nfq)] = Y[a * 3 + cc];
+        for (size_t si = 0; si < pv.size(); ++si) {
+            BatchView& v = pv[si];
+            // landmark damping
+            for (int b = 0; b < v.n_lblk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
+                const int w = v.lblk_win[b];
+                if (!v.st[w].active) continue;
+                int fail = 0;
+                for (int t = 0; t < v.lblk_n[b]; ++t) fail |= lm_damp_lane(v, c, v.lblk_lm0[b] + t);
+                v.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
+            }
+            // Schur slabs: upper triangle of Z^T Z per Schur workgroup (rhs = column nfq, see kba_items.hpp)
+            for (int sb = 0; sb < v.n_sblk; ++sb) {
+                if (!owns(si, shard_P > 1 ? P.sblk_owner[sb] : 0)) continue;
+                const int w = v.sblk_win[sb];
+                if (!v.st[w].active) continue;
+                const WinDesc& wd = v.win[w];
+                const int nfp = wd.nf_pad, nfq = wd.nfq;
+                const int slab = nfp * nfp;
+                std::vector<int> vkl(wd.n_view);
+                for (int j = 0; j < wd.n_view; ++j) vkl[j] = v.view_kf[wd.view0 + j] - wd.kf0;
+                double* out = v.S_part + wd.spart_off + (int64_t)(sb - wd.sblk0) * slab;
+                for (int i = 0; i < slab; ++i) out[i] = 0.0;
+                for (int li = 0; li < v.sblk_n[sb]; ++li) {
+                    const int gl = v.sblk_lm0[sb] + li;
+                    if (v.lm_state[gl] != 1) continue;
+                    double lmk[9], Y[3 * kCamSlots];
+                    schur_load_lm(v, gl, lmk);
+                    z.assign((size_t)3 * nfp, 0.0);
+                    for (int kl = 0; kl < wd.n_kf; ++kl) {
+                        schur_pair_block(v, wd, gl, kl, lmk, v.scale_c + wd.cam0, vkl.data(), gl >= wd.lm_gp0, Y);
+                        for (int a = 0; a < kCamSlots; ++a) {
+                            const int ci = v.cslot[wd.cam0 + kl * kCamSlots + a];
+                            if (ci < 0) continue;
+                            for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + schur_col(ci, nfq)] = Y[a * 3 + cc];
+                        }
                     }
-                }
-                for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + nfq] = bv.lm_t[cc * bv.SL + gl];
-                for (int cc = 0; cc < 3; ++cc) {
-                    const double* zr = z.data() + (size_t)cc * nfp;
-                    for (int a = 0; a <= wd.nf; ++a) {
-                        if (zr[a] == 0.0) continue;
-                        for (int bcol = a; bcol <= wd.nf; ++bcol) out[a * nfp + bcol] += zr[a] * zr[bcol];
+                    for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + nfq] = v.lm_t[cc * v.SL + gl];
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const double* zr = z.data() + (size_t)cc * nfp;
+                        for (int a = 0; a <= wd.nf; ++a) {
+                            if (zr[a] == 0.0) continue;
+                            for (int bcol = a; bcol <= wd.nf; ++bcol) out[a * nfp + bcol] += zr[a] * zr[bcol];
+                        }
                     }
                 }
             }
         }
+        exchange(2);
         // camera solve
         std::vector<double> S((size_t)cam_solve_scratch(kMaxNc, 1));
         for (int w = 0; w < bv.n_win; ++w) {
@@ -164,42 +231,52 @@ struct EmuBatch : Executor {
             int flag = 0;
             cam_solve(bv, c, w, 0, 1, S.data(), &flag);
         }
-        // back-substitution
-        for (int b = 0; b < bv.n_lblk; ++b) {
-            const int w = bv.lblk_win[b];
-            if (!bv.st[w].active) continue;
-            double mcc = 0.0, s2 = 0.0, c2 = 0.0;
-            for (int t = 0; t < bv.lblk_n[b]; ++t) {
-                double part[8];
-                backsub_lane(bv, bv.lblk_lm0[b] + t, part);
-                mcc += part[2];
-                s2 += part[3];
-                c2 += part[4];
+        for (size_t si = 0; si < pv.size(); ++si) {
+            BatchView& v = pv[si];
+            // back-substitution
+            for (int b = 0; b < v.n_lblk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
+                const int w = v.lblk_win[b];
+                if (!v.st[w].active) continue;
+                double mcc = 0.0, s2 = 0.0, c2 = 0.0;
+                for (int t = 0; t < v.lblk_n[b]; ++t) {
+                    double part[8];
+                    backsub_lane(v, v.lblk_lm0[b] + t, part);
+                    mcc += part[2];
+                    s2 += part[3];
+                    c2 += part[4];
+                }
+                v.lblk_part[(int64_t)b * 8 + 2] = mcc;
+                v.lblk_part[(int64_t)b * 8 + 3] = s2;
+                v.lblk_part[(int64_t)b * 8 + 4] = c2;
             }
-            bv.lblk_part[(int64_t)b * 8 + 2] = mcc;
-            bv.lblk_part[(int64_t)b * 8 + 3] = s2;
-            bv.lblk_part[(int64_t)b * 8 + 4] = c2;
-        }
-        // candidate cost
-        for (int b = 0; b < bv.n_blk; ++b) {
-            const int w = bv.view_win[bv.blk_view[b]];
-            if (!bv.st[w].active) continue;
-            double cost = 0.0;
-            int fail = 0;
-            for (int t = 0; t < kObsBlock; ++t) {
-                double cst;
-                int f;
-                cost_lane(bv, c, b, t, cst, f);
-                cost += cst;
-                fail |= f;
+            // candidate cost
+            for (int b = 0; b < v.n_blk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.blk_owner[b] : 0)) continue;
+                const int w = v.view_win[v.blk_view[b]];
+                if (!v.st[w].active) continue;
+                double cost = 0.0;
+                int fail = 0;
+                for (int t = 0; t < kObsBlock; ++t) {
+                    double cst;
+                    int f;
+                    cost_lane(v, c, b, t, cst, f);
+                    cost += cst;
+                    fail |= f;
+                }
+                v.blk_cost_c[b] = cost;
+                v.blk_fail_c[b] = fail;
             }
-            bv.blk_cost_c[b] = cost;
-            bv.blk_fail_c[b] = fail;
+            for (int w = 0; w < v.n_win; ++w) {
+                if (!v.st[w].active) continue;
+                const WinDesc& wd = v.win[w];
+                for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g)
+                    if (owns_lm(si, v.gp_lm[g])) gp_lane(v, g, true, v.gp_cost_c);
+            }
         }
+        exchange(4);
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active) continue;
-            const WinDesc& wd = bv.win[w];
-            for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(bv, g, true, bv.gp_cost_c);
             double red1[1];
             reduce_step(bv, w, 0, 1, red1);
             lm_decide_step(bv.st[w], bv.red[w], c);
@@ -216,15 +293,25 @@ struct EmuBatch : Executor {
     }
 
     void trim() override {
-        for (int b = 0; b < bv.n_blk; ++b) {
-            const int w = bv.view_win[bv.blk_view[b]];
-            if (!bv.win[w].do_trim) continue;
-            for (int t = 0; t < kObsBlock; ++t) trim_residual_lane(bv, b, t, plane_rep.data(), plane_dep.data());
+        for (size_t si = 0; si < pv.size(); ++si) {
+            BatchView& v = pv[si];
+            for (int b = 0; b < v.n_blk; ++b) {
+                if (!owns(si, shard_P > 1 ? P.blk_owner[b] : 0)) continue;
+                const int w = v.view_win[v.blk_view[b]];
+                if (!v.win[w].do_trim) continue;
+                for (int t = 0; t < kObsBlock; ++t) trim_residual_lane(v, b, t, plane_rep.data(), plane_dep.data());
+            }
+            for (int w = 0; w < v.n_win; ++w) {
+                const WinDesc& wd = v.win[w];
+                if (!wd.do_trim) continue;
+                for (int l = 0; l < wd.n_lm; ++l)
+                    if (owns_lm(si, wd.lm0 + l)) trim_max_lane(v, wd.lm0 + l, plane_rep.data(), plane_dep.data());
+            }
         }
+        exchange(8);
         for (int w = 0; w < bv.n_win; ++w) {
             const WinDesc& wd = bv.win[w];
             if (!wd.do_trim) continue;
-            for (int l = 0; l < wd.n_lm; ++l) trim_max_lane(bv, wd.lm0 + l, plane_rep.data(), plane_dep.data());
             std::vector<uint8_t> out(wd.n_lm, 0);
             for (int l = 0; l < wd.n_lm; ++l) {
                 out[l] = trim_is_outlier(bv.trim_dep + wd.lm0, bv.lm_id + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
@@ -236,6 +323,17 @@ struct EmuBatch : Executor {
                     bv.st[w].n_trimmed++;
                 }
         }
+    }
+
+    // rank mode: make every rank hold every landmark (sum of "owned, else zero")
+    void gather_landmarks() {
+        if (shard_P == 1 || !cb) return;
+        std::vector<double> send((size_t)3 * bv.TL, 0.0), recv((size_t)3 * bv.TL, 0.0);
+        for (int gl = 0; gl < bv.TL; ++gl)
+            if (owned_here(gl))
+                for (int i = 0; i < 3; ++i) send[3 * (size_t)gl + i] = bv.lm[3 * (size_t)gl + i];
+        cb(send.data(), recv.data(), (int64_t)send.size(), 0, cb_user);
+        std::memcpy(bv.lm, recv.data(), sizeof(double) * recv.size());
     }
 };
 
@@ -287,6 +385,31 @@ int emu_ba_solve_batch(int32_t n, limo_ba_window* windows, const limo_ba_options
     write_back(B, windows);
     if (reports)
         for (int w = 0; w < n; ++w) fill_report(B, w, reports + w);
+    return LIMO_OK;
+}
+
+// Landmark-sharded solve of one window.  cb == NULL: n_shards virtual shards in this process (the
+// exchange is a plain sum); else this process is shard `rank` of n_shards and cb is the all-reduce.
+int emu_ba_solve_sharded(limo_ba_window* window, const limo_ba_options* o, int n_shards, int rank, int world,
+                         emu_allreduce_fn cb, void* user, limo_ba_report* report) {
+    EmuBatch B;
+    std::string err;
+    PackOptions po;
+    po.shards = n_shards;
+    int rc = pack_windows(1, window, *o, po, B.P, err);
+    if (rc != LIMO_OK) return rc;
+    B.c = make_consts(*o);
+    if (cb) {  // shard s lives on rank s mod world
+        for (int r = 0; r < n_shards; ++r)
+            if (r % world == rank) B.local_shards.push_back(r);
+        B.cb = cb;
+        B.cb_user = user;
+    }
+    B.alloc();
+    run_schedule(B, *o);
+    B.gather_landmarks();
+    write_back(B, window);
+    if (report) fill_report(B, 0, report);
     return LIMO_OK;
 }
 

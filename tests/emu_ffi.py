@@ -41,6 +41,31 @@ def build_shim_tests(gpu=False):
     return SHIM_TEST_GPU
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
+
+def solve_sharded(window, opts, n_shards, rank=0, world=1, allreduce=None):
+    """Landmark-sharded emulation.  allreduce = None: n_shards virtual shards in this process; else this process is
+    shard `rank` and allreduce(send_ndarray, recv_ndarray) must leave the element-wise sum over all ranks in recv."""
+    lib = load()
+    s = window.as_struct()
+    rep = _ffi.BaReport()
+    if allreduce is None:
+        cb = C.cast(None, ALLREDUCE_FN)
+    else:
+        def _cb(send, recv, count, is_int, _user):
+            ct = C.c_int32 if is_int else C.c_double
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(ct)), shape=(count,))
+            b = np.ctypeslib.as_array(C.cast(recv, C.POINTER(ct)), shape=(count,))
+            allreduce(a, b)  # send and recv may alias (in-place exchange)
+
+        cb = ALLREDUCE_FN(_cb)
+    rc = lib.emu_ba_solve_sharded(C.byref(s), C.byref(opts), int(n_shards), int(rank), int(world), cb, None, C.byref(rep))
+    if rc != 0:
+        raise RuntimeError("emu_ba_solve_sharded rc=%d" % rc)
+    return rep.as_dict()
+
+
 def load():
     global _lib
     if _lib is None:
@@ -49,6 +74,7 @@ def load():
         dp, u8p = _ffi.c_double_p, _ffi.c_uint8_p
         lib.emu_ba_solve_batch.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.POINTER(_ffi.SpeedPrior)]
         lib.emu_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+        lib.emu_ba_solve_sharded.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, C.POINTER(_ffi.BaReport)]
         _lib = lib
     return _lib
 
