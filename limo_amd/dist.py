@@ -56,3 +56,15 @@ def gather_objects(dist, obj):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
     return out
+
+
+def init_shard_comm(dist, ctx):
+    """Give `ctx` the RCCL communicator of a landmark-sharded solve (limo_ctx_comm_init): rank 0 creates the unique id,
+    torch.distributed broadcasts its bytes, every rank joins.  Single process: a one-rank communicator."""
+    rank, _, world = env_rank_world()
+    if dist is None:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        return
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], rank, world)
