@@ -100,6 +100,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(yc, TK * kCamSlots * D, nullptr);
     KBA_BUF(delta_c, TK * kCamSlots * D, nullptr);
     KBA_BUF(S_part, (size_t)(P.spart_total > 0 ? P.spart_total : 1) * D, nullptr);
+    KBA_BUF(S_red, (size_t)(P.sred_total > 0 ? P.sred_total : 1) * D, nullptr);
     KBA_BUF(reg_cost, NW * 2 * D, nullptr);
     KBA_BUF(trim_rep, TL * D, nullptr);
     KBA_BUF(trim_dep, TL * D, nullptr);
@@ -126,7 +127,8 @@ inline std::vector<PartialArray> partial_arrays(const PackedBatch& P) {
         {offsetof(BatchView, gp_F), (size_t)P.SG * 10, false, 1},
         {offsetof(BatchView, gp_cost), TG, false, 1},
         {offsetof(BatchView, lblk_part), NL * 8, false, 1 | 2 | 4},
-        {offsetof(BatchView, S_part), (size_t)std::max<int64_t>(1, P.spart_total), false, 2},
+        {offsetof(BatchView, S_part), (size_t)std::max<int64_t>(1, P.spart_total), false, 0},  // private per shard, never exchanged
+        {offsetof(BatchView, S_red), (size_t)std::max<int64_t>(1, P.sred_total), false, 2},
         {offsetof(BatchView, blk_cost_c), NB, false, 4},
         {offsetof(BatchView, blk_fail_c), NB, true, 4},
         {offsetof(BatchView, gp_cost_c), TG, false, 4},

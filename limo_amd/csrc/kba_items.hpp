@@ -340,6 +340,17 @@ KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
     for (int i = 0; i < 6; ++i) lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
 }
 
+// Landmark-sharded solve: entry e of slab `shard` of S_red = sum over ALL partial slabs of the window in this shard's
+// private S_part (slabs of other shards' workgroups are never written there and stay zero).
+KBA_HD void slab_reduce_entry(const BatchView& bv, int w, int shard, int e) {
+    const WinDesc& wd = bv.win[w];
+    const int64_t slab = (int64_t)wd.nf_pad * wd.nf_pad;
+    const double* sp = bv.S_part + wd.spart_off + e;
+    double a = 0.0;
+    for (int q = 0; q < wd.n_sblk; ++q) a += sp[q * slab];
+    bv.S_red[wd.sred_off + shard * slab + e] = a;
+}
+
 // column of compact slot i in the Schur tile / slab (the rhs sits at column nfq)
 KBA_HD int schur_col(int i, int nfq) {
     return i + (i >= nfq ? 1 : 0);
@@ -875,7 +886,8 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         if (cs[a] >= 0) fl[cs[a]] = a;
     KBA_SYNC();
     // ---- assemble [S | rhs]: S = S_c H S_c + D^2 - sum slabs (upper triangle), rhs = S_c g_c - sum slabs
-    const double* sp = bv.S_part + wd.spart_off;
+    // partial slabs of the Schur workgroups, or (landmark-sharded solve) the per-shard sums of them
+    const double* sp = c.schur_nslab > 0 ? bv.S_red + wd.sred_off : bv.S_part + wd.spart_off;
     for (int i = tid; i < nf * lda; i += nt) {
         const int ca = i / lda, cb = i % lda;
         if (cb < ca) continue;  // lower triangle unused
@@ -894,7 +906,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int q = 0;
-        const int n_slab = (wd.n_sblk + c.schur_span - 1) / c.schur_span;
+        const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : (wd.n_sblk + c.schur_span - 1) / c.schur_span;
         for (; q + 4 <= n_slab; q += 4) {  // independent loads in flight
             s0 += sp[(int64_t)q * slab + off];
             s1 += sp[(int64_t)(q + 1) * slab + off];

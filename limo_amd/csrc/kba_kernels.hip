@@ -601,6 +601,14 @@ __global__ void k_sum_shards(T* dst, ShardPtrs src, int n_shards, int64_t n) {
     dst[i] = acc;
 }
 
+// One slab per (window, shard) before the exchange: 74 KB instead of 9 MB on the wire for a C4 window.
+__global__ __launch_bounds__(kBlock) void k_slab_reduce(BatchView bv, const int32_t* wl, int shard) {
+    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
+    if (!bv.st[w].active) return;
+    const int n = bv.win[w].nf_pad * bv.win[w].nf_pad;
+    for (int e = blockIdx.y * kBlock + threadIdx.x; e < n; e += gridDim.y * kBlock) slab_reduce_entry(bv, w, shard, e);
+}
+
 // out = landmark positions of the landmarks this shard owns, zero elsewhere (input of the final all-reduce that
 // gives every rank every landmark).
 __global__ void k_lm_owned(BatchView bv, double* out, int rank, int n_shards, int world) {

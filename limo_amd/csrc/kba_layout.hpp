@@ -56,6 +56,7 @@ struct WinDesc {
     double speed_w, speed_dt, speed_vel[3], speed_Rb[9], speed_tb[3];  // SpeedRegularizationVector2 (pose-only)
     int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer
     int64_t spart_off;        // offset of this window's Schur partial slabs
+    int64_t sred_off;         // offset of this window's per-shard slabs (n_shards x nf_pad^2) in S_red
 };
 
 // Per-window Levenberg-Marquardt state (device resident; see kba_lm.hpp).
@@ -94,7 +95,8 @@ struct SolveConsts {  // subset of limo_ba_options the kernels need
     int32_t max_invalid, jacobi_scaling;
     double depth_quantile, reprojection_quantile;
     int32_t min_groups, pad;
-    int32_t schur_span, pad2;  // Schur blocks per wave in this iteration (slab q of a window covers blocks [q*span, ..))
+    int32_t schur_span;   // Schur blocks per wave in this iteration (slab q of a window covers blocks [q*span, ..))
+    int32_t schur_nslab;  // > 0: landmark-sharded solve - k_cam_solve sums this many per-shard slabs from S_red instead
 };
 
 // Raw pointers to every buffer of a batch (device pointers in the library, host pointers in the emulator).
@@ -163,6 +165,7 @@ struct BatchView {
     double *Hcc, *gc;           // per window nc*nc (hcc_off) ; [TK*10]
     double *scale_c, *yc, *delta_c;  // [TK*10]
     double *S_part;             // Schur partial slabs
+    double *S_red;              // landmark-sharded solve: one slab per (window, shard) = sum of the shard's partial slabs
     double* reg_cost;           // [n_win*2]: free / fixed regulariser cost at the linearisation point
     // --- trimming
     double *trim_rep, *trim_dep;   // [TL] max un-robustified residual norm per landmark, <0 = no block

@@ -401,6 +401,8 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.hcc_total += (int64_t)d.nc * d.nc;
         d.spart_off = P.spart_total;
         P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
+        d.sred_off = P.sred_total;
+        if (NS > 1) P.sred_total += (int64_t)NS * d.nf_pad * d.nf_pad;
     }
     P.TG = (int)P.gp_lm.size();
     P.SG = pad64(std::max(1, P.TG));

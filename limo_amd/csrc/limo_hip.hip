@@ -272,6 +272,7 @@ struct limo_ba_batch : Executor {
         const int64_t coarse_waves = (int64_t)n_windows_listed * std::max(1, avg_sblk) / 4;
         c.schur_span = coarse_waves >= 2048 ? 4 : coarse_waves >= 1024 ? 2 : 1;
         if (shard_P > 1) c.schur_span = 1;  // Schur blocks are cut at shard boundaries
+        c.schur_nslab = shard_P > 1 ? shard_P : 0;
     }
 
     // ---- sharding helpers
@@ -490,6 +491,12 @@ struct limo_ba_batch : Executor {
                     LAUNCH_CHECK("k_schur");
                 }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+        }
+        if (shard_P > 1 && n_wl_win) {
+            for (size_t i = 0; i < pv.size(); ++i) {
+                hipLaunchKernelGGL(k_slab_reduce, dim3(n_wl_win, 8), dim3(kBlock), 0, s, pv[i], use_wl ? d_wl_win : nullptr, shard_of(i));
+                LAUNCH_CHECK("k_slab_reduce");
+            }
         }
         allreduce(2);
         if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);

@@ -223,6 +223,15 @@ struct EmuBatch : Executor {
                 }
             }
         }
+        if (shard_P > 1) {
+            for (size_t si = 0; si < pv.size(); ++si)
+                for (int w = 0; w < bv.n_win; ++w) {
+                    if (!bv.st[w].active) continue;
+                    const int n = bv.win[w].nf_pad * bv.win[w].nf_pad;
+                    for (int e = 0; e < n; ++e) slab_reduce_entry(pv[si], w, local_shards[si], e);
+                }
+            c.schur_nslab = shard_P;
+        }
         exchange(2);
         // camera solve
         std::vector<double> S((size_t)cam_solve_scratch(kMaxNc, 1));
