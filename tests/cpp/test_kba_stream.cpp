@@ -1,0 +1,169 @@
+// Streaming visual-odometry scenario on a synthetic sequence, through the keyframe_bundle_adjustment API of the shim
+// (limo_amd/kba): the per-frame call order of the reference's ROS node, restated without ROS
+//   keyframe_bundle_adjustment_ros_tool/src/mono_lidar/mono_lidar.cpp:186-260
+//   build the frame with a motion prior -> adjustPoseOnly -> push -> deactivateKeyframes -> solve -> dump the pose
+// (every frame is taken as a keyframe; SURVEY §8f-3's keyframe selection stays on the host and is not the subject).
+// Checks the trajectory against the synthetic ground truth (absolute trajectory error) and the window bookkeeping.
+// Linked against the emulated C-ABI in the CPU test tier and against liblimo_hip.so in the GPU tier.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../limo_amd/kba/bundle_adjuster_keyframes.hpp"
+
+using namespace keyframe_bundle_adjustment;
+using matches_msg_types::FeaturePoint;
+using matches_msg_types::Tracklets;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        ++g_checks;                                                                  \
+        if (!(cond)) {                                                               \
+            ++g_fail;                                                                \
+            std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+        }                                                                            \
+    } while (0)
+
+static std::mt19937_64 rng(7);
+static double gauss(double s) {
+    return s > 0 ? std::normal_distribution<double>(0., s)(rng) : 0.;
+}
+static double uni(double a, double b) {
+    return std::uniform_real_distribution<double>(a, b)(rng);
+}
+
+int main(int argc, char** argv) {
+    const int n_frames = argc > 1 ? std::atoi(argv[1]) : 24;
+    const int n_lm = argc > 2 ? std::atoi(argv[2]) : 1500;
+    const int window = 5, history = 10;
+    // camera <- vehicle (vehicle x forward, y left, z up; camera z forward, x right, y down), KITTI-like intrinsics
+    EigenPose cam_veh = EigenPose::Identity();
+    {
+        const double R[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
+        for (int i = 0; i < 9; ++i) cam_veh.R[i] = R[i];
+        const Vector3d t_veh_cam(1.08, 0., 1.35);  // camera position in the vehicle frame
+        const Vector3d t = cam_veh * Vector3d(-t_veh_cam[0], -t_veh_cam[1], -t_veh_cam[2]);
+        cam_veh.t[0] = t[0] - cam_veh.t[0];
+        cam_veh.t[1] = t[1] - cam_veh.t[1];
+        cam_veh.t[2] = t[2] - cam_veh.t[2];
+    }
+    const double f = 718.856, cx = 607.1928, cy = 185.2157, W = 1241., H = 376.;
+    Camera::Ptr cam = std::make_shared<Camera>(f, Vector2d(cx, cy), cam_veh);
+
+    // ground truth: origin <- vehicle_t, forward motion with a slow turn; keyframe <- origin = inverse
+    std::vector<EigenPose> origin_veh(n_frames);
+    {
+        EigenPose p = EigenPose::Identity();
+        for (int t = 0; t < n_frames; ++t) {
+            origin_veh[t] = p;
+            p.translate(Vector3d(1.1, 0., 0.));
+            p.rotate(0.012, Vector3d(0., 0., 1.));
+        }
+    }
+    // landmarks in the origin frame along the route; 20 % on the ground plane (z = -0.31 under the vehicle origin)
+    std::vector<Vector3d> lms(n_lm);
+    std::vector<char> on_ground(n_lm);
+    for (int i = 0; i < n_lm; ++i) {
+        const int anchor = (int)uni(0, n_frames - 1);
+        on_ground[i] = uni(0, 1) < 0.2;
+        const Vector3d local(uni(4., 45.), uni(-12., 12.), on_ground[i] ? -0.31 : uni(-0.2, 4.0));
+        lms[i] = origin_veh[anchor] * local;
+    }
+    auto project = [&](int t, int i, double& u, double& v, double& z) {
+        const Vector3d pc = cam_veh * (origin_veh[t].inverse() * lms[i]);
+        z = pc[2];
+        if (z < 1.0 || z > 60.) return false;
+        u = f * pc[0] / z + cx;
+        v = f * pc[1] / z + cy;
+        return u >= 0 && u < W && v >= 0 && v < H;
+    };
+    std::vector<char> has_depth(n_lm);
+    for (int i = 0; i < n_lm; ++i) has_depth[i] = uni(0, 1) < 0.45;
+
+    BundleAdjusterKeyframes ba;
+    ba.set_solver_time(20.);
+    std::map<uint64_t, int> frame_of_stamp;
+    std::vector<EigenPose> est(n_frames);  // keyframe <- origin estimates as dumped right after each solve
+    EigenPose last_motion = EigenPose::Identity();
+    double t_solve = 0.;
+    int n_solves = 0;
+    for (int t = 0; t < n_frames; ++t) {
+        // tracklets of this frame: every landmark visible now, with its history over the consecutive frames it was seen
+        Tracklets ts;
+        for (int k = 0; k < history && t - k >= 0; ++k) ts.stamps.push_back((uint64_t)(t - k) * 100000000ull + 1000ull);
+        frame_of_stamp[ts.stamps[0]] = t;
+        for (int i = 0; i < n_lm; ++i) {
+            matches_msg_types::Tracklet tr;
+            tr.id = i;
+            for (int k = 0; k < (int)ts.stamps.size(); ++k) {
+                double u, v, z;
+                if (!project(t - k, i, u, v, z)) break;
+                // deterministic per (frame, landmark) noise so that a measurement is the same in every tracklet message
+                std::mt19937_64 r2((uint64_t)(t - k) * 1000003ull + i);
+                std::normal_distribution<double> n01(0., 1.);
+                u += 0.3 * n01(r2);
+                v += 0.3 * n01(r2);
+                const double d = z + 0.03 * n01(r2);
+                tr.feature_points.push_back(has_depth[i] ? FeaturePoint((float)u, (float)v, (float)d) : FeaturePoint((float)u, (float)v));
+            }
+            if (tr.feature_points.size() >= 1) {
+                tr.age = tr.feature_points.size();
+                tr.label = on_ground[i] ? 7 : 11;  // cityscapes: road / building (labels_ of the adjuster)
+                ts.tracks.push_back(tr);
+            }
+        }
+        // motion prior: constant velocity from the last two estimates, perturbed (mono_lidar.cpp:150-185)
+        EigenPose prior = EigenPose::Identity();
+        if (t == 1) prior = origin_veh[1].inverse();
+        if (t >= 2) prior = last_motion * est[t - 1];
+        if (t >= 1) {
+            prior.translate(Vector3d(gauss(0.05), gauss(0.03), gauss(0.02)));
+            prior.rotate(gauss(0.004), Vector3d(0., 0., 1.));
+        }
+        Plane gp;
+        gp.distance = 0.31;  // height over ground (launch file), normal +z in the vehicle frame
+        gp.direction = {{0., 0., 1.}};
+        Keyframe kf(ts.stamps[0], ts, cam, prior, t == 0 ? Keyframe::FixationStatus::Pose : Keyframe::FixationStatus::None, gp);
+        if (ba.keyframes_.size() >= 3) {
+            ba.adjustPoseOnly(kf);
+            CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
+        }
+        ba.push(kf);
+        if (ba.keyframes_.size() > 2) {
+            ba.deactivateKeyframes(3, 3, window);
+            ba.updateLabels(ts, 0.9);
+            CHECK((int)ba.active_keyframe_ids_.size() <= window);
+            const auto t0 = std::chrono::steady_clock::now();
+            const std::string summary = ba.solve();
+            t_solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ++n_solves;
+            CHECK(!summary.empty());
+            CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
+            CHECK(ba.last_report_.final_cost <= ba.last_report_.initial_cost || ba.last_report_.initial_cost < 0);
+        }
+        est[t] = ba.getKeyframe().getEigenPose();  // newest keyframe, as the node dumps it (:281-294)
+        if (t >= 1) last_motion = est[t] * est[t - 1].inverse();
+    }
+    // absolute trajectory error of the dumped poses (vehicle positions in the origin frame; first pose is fixed = GT)
+    double se = 0., worst = 0.;
+    for (int t = 0; t < n_frames; ++t) {
+        const Vector3d e = est[t].inverse().translation() - origin_veh[t].translation();
+        se += e.norm() * e.norm();
+        worst = std::max(worst, e.norm());
+    }
+    const double ate = std::sqrt(se / n_frames);
+    const double path = 1.1 * (n_frames - 1);
+    std::printf("stream: %d keyframes, %d landmarks, window %d: ATE rmse %.4f m (max %.4f m) over %.1f m; %d solves, %.1f ms per solve()\n",
+                n_frames, n_lm, window, ate, worst, path, n_solves, n_solves ? 1e3 * t_solve / n_solves : 0.);
+    CHECK(ate < 0.05);
+    CHECK(worst < 0.12);
+    CHECK((int)ba.keyframes_.size() == n_frames);
+    std::printf("%d checks, %d failed\n", g_checks, g_fail);
+    return g_fail ? 1 : 0;
+}

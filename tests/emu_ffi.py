@@ -27,6 +27,21 @@ SHIM_TEST_EMU = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_emu")
 SHIM_TEST_GPU = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_gpu")
 
 
+def build_stream_test(gpu=False):
+    """tests/cpp/test_kba_stream.cpp (streaming sequence through the shim) against the emulated C-ABI or liblimo_hip.so."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
+    test_src = os.path.join(_HERE, "cpp", "test_kba_stream.cpp")
+    out = os.path.join(_HERE, "cpp", "_build", "test_kba_stream_gpu" if gpu else "test_kba_stream_emu")
+    if not gpu:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
+        return out
+    libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    return out
+
+
 def build_shim_tests(gpu=False):
     """tests/cpp/test_kba_shim.cpp + the kba shim, linked against the emulated C-ABI (CPU tier) or liblimo_hip.so."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)

@@ -22,3 +22,22 @@ def test_reference_scenarios_with_emulated_backend():
 @pytest.mark.gpu
 def test_reference_scenarios_on_gpu():
     run(emu_ffi.build_shim_tests(gpu=True))
+
+
+def run_stream(exe, n_frames, n_lm):
+    r = subprocess.run([exe, str(n_frames), str(n_lm)], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:])
+    print(r.stderr[-1000:])
+    assert r.returncode == 0, "streaming scenario failed:\n" + r.stdout[-2000:]
+    assert " 0 failed" in r.stdout
+
+
+def test_streaming_sequence_with_emulated_backend():
+    """BASELINE.json configs[4] in miniature: sliding 5-keyframe window over a synthetic drive, the per-frame call
+    order of the reference's node (adjustPoseOnly -> push -> deactivateKeyframes -> solve), ATE against ground truth."""
+    run_stream(emu_ffi.build_stream_test(gpu=False), 16, 800)
+
+
+@pytest.mark.gpu
+def test_streaming_sequence_on_gpu():
+    run_stream(emu_ffi.build_stream_test(gpu=True), 40, 2500)
