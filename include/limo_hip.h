@@ -237,6 +237,8 @@ int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_s
 
 /* --- landmark initialisation ----------------------------------------------------------------------- */
 /*
+ * Runs on the device (one lane per landmark, limo_amd/csrc/landmark_init.hip): hand over ALL new landmarks of a
+ * keyframe in one call.  ctx is required.
  * For each of n landmarks: rays are given as n_rays_off CSR over (pose_cam_origin [7], u, v, d, f, cx, cy).
  * If the FIRST listed measurement with d >= 0 exists in the landmark's own (newest) keyframe the caller
  * should pass it as mode 0 (depth back-projection, :332-355); else mode 1 = midpoint triangulation over all

@@ -77,6 +77,18 @@ class Context:
         _check(self.lib.limo_comm_unique_id(buf), self.ptr, "limo_comm_unique_id")
         return buf.raw
 
+    def landmark_init(self, ray_off, rays, use_depth):
+        """limo_landmark_init: rays = ctypes array of _ffi.Ray (CSR by ray_off); returns (positions [n,3], ok [n])."""
+        ray_off = np.ascontiguousarray(ray_off, np.int32)
+        use_depth = np.ascontiguousarray(use_depth, np.uint8)
+        n = len(use_depth)
+        pos = np.zeros((n, 3))
+        ok = np.zeros(n, np.uint8)
+        rc = self.lib.limo_landmark_init(self.ptr, n, ray_off.ctypes.data_as(_ffi.c_int32_p), rays, use_depth.ctypes.data_as(_ffi.c_uint8_p),
+                                         pos.ctypes.data_as(_ffi.c_double_p), ok.ctypes.data_as(_ffi.c_uint8_p))
+        _check(rc, self.ptr, "limo_landmark_init")
+        return pos, ok
+
     def adjust_pose_only(self, window, prior, opts):
         s = window.as_struct()
         rep = _ffi.BaReport()

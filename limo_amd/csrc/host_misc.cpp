@@ -1,5 +1,6 @@
-// host_misc.cpp — C-ABI entry points that run on the host in this round: landmark initialisation (B10) and the
-// quantile trimmer exposed for callers / tests (the batched solve trims on the device, kba_kernels.hip).
+// host_misc.cpp — C-ABI entry points that run on the host: the quantile trimmer exposed for callers / tests (the
+// batched solve trims on the device, kba_kernels.hip) and, ONLY inside the emulated ABI of the CPU test tier, the host
+// loop of the landmark initialisation (the product's limo_landmark_init is the device kernel of landmark_init.hip).
 //
 //   limo_landmark_init   BundleAdjusterKeyframes::calculateLandmark (both overloads),
 //                        keyframe_bundle_adjustment/src/bundle_adjuster_keyframes.cpp:332-382,
@@ -14,109 +15,25 @@
 #include <vector>
 
 #include "../../include/limo_hip.h"
-#include "kba_math.hpp"
-
-namespace {
-
-// camera<-origin pose (7) -> origin<-camera rotation (row-major) and camera centre in the origin frame
-void invert_pose(const double* pose_cam_origin, double* R_oc, double* c_o) {
-    double R[9];
-    kba::quat_R(pose_cam_origin, R);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R_oc[i * 3 + j] = R[j * 3 + i];
-    const double* t = pose_cam_origin + 4;
-    for (int i = 0; i < 3; ++i) c_o[i] = -(R_oc[i * 3] * t[0] + R_oc[i * 3 + 1] * t[1] + R_oc[i * 3 + 2] * t[2]);
-}
-
-// Minimum-norm least-squares solution of the symmetric PSD 3x3 system A p = b (what JacobiSVD::solve returns),
-// via a cyclic-Jacobi eigen-decomposition; eigenvalues below eps * 3 * max are treated as zero.
-void solve_sym3_pinv(const double* A, const double* b, double* p) {
-    double a[3][3] = {{A[0], A[1], A[2]}, {A[3], A[4], A[5]}, {A[6], A[7], A[8]}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 50; ++sweep) {
-        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off == 0.0) break;
-        for (int i = 0; i < 2; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                if (a[i][j] == 0.0) continue;
-                const double tau = (a[j][j] - a[i][i]) / (2.0 * a[i][j]);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
-                for (int k = 0; k < 3; ++k) {  // A <- A G
-                    const double x = a[k][i], y = a[k][j];
-                    a[k][i] = cs * x - sn * y;
-                    a[k][j] = sn * x + cs * y;
-                }
-                for (int k = 0; k < 3; ++k) {  // A <- G^T A
-                    const double x = a[i][k], y = a[j][k];
-                    a[i][k] = cs * x - sn * y;
-                    a[j][k] = sn * x + cs * y;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double x = V[k][i], y = V[k][j];
-                    V[k][i] = cs * x - sn * y;
-                    V[k][j] = sn * x + cs * y;
-                }
-            }
-    }
-    const double mx = std::max(std::fabs(a[0][0]), std::max(std::fabs(a[1][1]), std::fabs(a[2][2])));
-    const double thr = std::numeric_limits<double>::epsilon() * 3.0 * mx;
-    p[0] = p[1] = p[2] = 0.0;
-    for (int j = 0; j < 3; ++j) {
-        if (std::fabs(a[j][j]) <= thr) continue;
-        const double dot = (V[0][j] * b[0] + V[1][j] * b[1] + V[2][j] * b[2]) / a[j][j];
-        for (int k = 0; k < 3; ++k) p[k] += V[k][j] * dot;
-    }
-}
-
-}  // namespace
+#include "landmark_init.hpp"
 
 extern "C" {
 
+#ifdef KBA_EMU_EXPORT_ABI
+// Host loop over the SAME per-landmark statements the device kernel runs (landmark_init.hpp) - only inside the
+// emulated C-ABI of the CPU test tier; the product's limo_landmark_init is landmark_init.hip.
 int limo_landmark_init(limo_ctx* /*ctx*/, int32_t n, const int32_t* ray_off, const limo_ray* rays,
                        const uint8_t* use_depth, double* pos_out, uint8_t* ok) {
     if (n < 0 || (n > 0 && (!ray_off || !rays || !use_depth || !pos_out || !ok))) return LIMO_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
-        const int b = ray_off[i], e = ray_off[i + 1];
-        ok[i] = 0;
-        if (e < b) return LIMO_ERR_INVALID;
-        if (use_depth[i]) {
-            // first measurement with d >= 0 is back-projected (:336-351)
-            for (int r = b; r < e; ++r) {
-                const limo_ray& m = rays[r];
-                if (m.d < 0) continue;
-                const double z = static_cast<double>(m.d);
-                const double pc[3] = {(static_cast<double>(m.u) - m.cx) * z / m.f, (static_cast<double>(m.v) - m.cy) * z / m.f, z};
-                double R_oc[9], c_o[3];
-                invert_pose(m.pose_cam_origin, R_oc, c_o);
-                for (int k = 0; k < 3; ++k)
-                    pos_out[3 * (size_t)i + k] = R_oc[k * 3] * pc[0] + R_oc[k * 3 + 1] * pc[1] + R_oc[k * 3 + 2] * pc[2] + c_o[k];
-                ok[i] = 1;
-                break;
-            }
-            continue;
-        }
-        if (e - b < 2) continue;  // :363-365
-        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0};
-        for (int r = b; r < e; ++r) {
-            const limo_ray& m = rays[r];
-            double ray[3] = {(static_cast<double>(m.u) - m.cx) / m.f, (static_cast<double>(m.v) - m.cy) / m.f, 1.0};
-            const double nn = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-            double R_oc[9], c_o[3], ro[3];
-            invert_pose(m.pose_cam_origin, R_oc, c_o);
-            for (int k = 0; k < 3; ++k) ro[k] = (R_oc[k * 3] * ray[0] + R_oc[k * 3 + 1] * ray[1] + R_oc[k * 3 + 2] * ray[2]) / nn;
-            // (I - r r^T) accumulated, rhs += (I - r r^T) c
-            const double rc = ro[0] * c_o[0] + ro[1] * c_o[1] + ro[2] * c_o[2];
-            for (int a = 0; a < 3; ++a) {
-                for (int c = 0; c < 3; ++c) A[a * 3 + c] += (a == c ? 1.0 : 0.0) - ro[a] * ro[c];
-                rhs[a] += c_o[a] - ro[a] * rc;
-            }
-        }
-        solve_sym3_pinv(A, rhs, pos_out + 3 * (size_t)i);
-        ok[i] = 1;
+        if (ray_off[i + 1] < ray_off[i]) return LIMO_ERR_INVALID;
+        double p[3] = {0.0, 0.0, 0.0};
+        ok[i] = kba::lminit_one(ray_off, rays, use_depth, i, p) ? 1 : 0;
+        for (int k = 0; k < 3; ++k) pos_out[3 * (size_t)i + k] = p[k];
     }
     return LIMO_OK;
 }
+#endif
 
 int limo_trim_quantile(int32_t n, const int64_t* ids, const double* values, double quantile, int64_t* outliers_out) {
     if (n < 0 || (n > 0 && (!ids || !values || !outliers_out))) return LIMO_ERR_INVALID;

@@ -142,43 +142,75 @@ void BundleAdjusterKeyframes::push(const std::vector<Keyframe>& kfs) {
 void BundleAdjusterKeyframes::push(const Keyframe& kf) {
     keyframes_[kf.timestamp_] = std::make_shared<Keyframe>(kf);
     active_keyframe_ids_.insert(kf.timestamp_);
-    for (const auto& m : kf.measurements_) {
-        if (landmarks_.find(m.first) == landmarks_.cend()) {
-            Vector3d p;
-            const bool has_depth = containsDepth(kf, m.first);
-            const bool success = has_depth ? calculateLandmark(kf, m.first, p) : calculateLandmark(m.first, p);
-            if (!success) continue;
-            landmarks_[m.first] = std::make_shared<Landmark>(p, has_depth);
-        }
-        active_landmark_ids_.insert(m.first);
-    }
-}
-
-bool BundleAdjusterKeyframes::calculateLandmark(const Keyframe& kf, const LandmarkId& lId, Vector3d& posAbs) {
+    // Every landmark this keyframe introduces is initialised in ONE device call (the reference does it one by one,
+    // :289-330): depth back-projection where the keyframe measures a depth, N-view triangulation otherwise.
+    std::vector<LandmarkId> ids;
+    std::vector<int32_t> off{0};
     std::vector<limo_ray> rays;
-    for (const auto& m : kf.measurements_.at(lId)) rays.push_back(make_ray(*kf.cameras_.at(m.first), kf, m.second));
-    const int32_t off[2] = {0, (int32_t)rays.size()};
-    const uint8_t use_depth = 1;
-    uint8_t ok = 0;
-    double pos[3];
-    if (limo_landmark_init(nullptr, 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
-    posAbs = Vector3d(pos);
-    return true;
+    std::vector<uint8_t> use_depth;
+    for (const auto& m : kf.measurements_) {
+        if (landmarks_.find(m.first) != landmarks_.cend()) continue;
+        const bool has_depth = containsDepth(kf, m.first);
+        const size_t before = rays.size();
+        if (has_depth) {
+            collectRays(kf, m.first, rays);
+        } else {
+            collectRays(m.first, rays);
+            if (rays.size() - before < 2) {  // not enough views to triangulate (:363-365)
+                rays.resize(before);
+                continue;
+            }
+        }
+        ids.push_back(m.first);
+        use_depth.push_back(has_depth ? 1 : 0);
+        off.push_back((int32_t)rays.size());
+    }
+    if (!ids.empty()) {
+        std::vector<double> pos(3 * ids.size());
+        std::vector<uint8_t> ok(ids.size(), 0);
+        const int rc = limo_landmark_init(context(), (int32_t)ids.size(), off.data(), rays.data(), use_depth.data(), pos.data(), ok.data());
+        if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_landmark_init: ") + limo_last_error(ctx_));
+        for (size_t i = 0; i < ids.size(); ++i)
+            if (ok[i]) landmarks_[ids[i]] = std::make_shared<Landmark>(Vector3d(pos.data() + 3 * i), use_depth[i] != 0);
+    }
+    for (const auto& m : kf.measurements_)
+        if (landmarks_.find(m.first) != landmarks_.cend()) active_landmark_ids_.insert(m.first);
 }
 
-bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d& posAbs) {
-    std::vector<limo_ray> rays;  // getMeasurementsAndPoses (:125-159): every active keyframe / camera that sees it
+void BundleAdjusterKeyframes::collectRays(const Keyframe& kf, const LandmarkId& lId, std::vector<limo_ray>& rays) const {
+    for (const auto& m : kf.measurements_.at(lId)) rays.push_back(make_ray(*kf.cameras_.at(m.first), kf, m.second));
+}
+
+void BundleAdjusterKeyframes::collectRays(const LandmarkId& lId, std::vector<limo_ray>& rays) const {
+    // getMeasurementsAndPoses (:125-159): every active keyframe / camera that sees the landmark
     for (const auto& id : active_keyframe_ids_) {
         const Keyframe& kf = *keyframes_.at(id);
         for (const auto& id_cam : kf.cameras_)
             if (kf.hasMeasurement(lId, id_cam.first)) rays.push_back(make_ray(*id_cam.second, kf, kf.getMeasurement(lId, id_cam.first)));
     }
+}
+
+bool BundleAdjusterKeyframes::calculateLandmark(const Keyframe& kf, const LandmarkId& lId, Vector3d& posAbs) {
+    std::vector<limo_ray> rays;
+    collectRays(kf, lId, rays);
+    const int32_t off[2] = {0, (int32_t)rays.size()};
+    const uint8_t use_depth = 1;
+    uint8_t ok = 0;
+    double pos[3];
+    if (limo_landmark_init(context(), 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
+    posAbs = Vector3d(pos);
+    return true;
+}
+
+bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d& posAbs) {
+    std::vector<limo_ray> rays;
+    collectRays(lId, rays);
     if (rays.size() < 2) return false;
     const int32_t off[2] = {0, (int32_t)rays.size()};
     const uint8_t use_depth = 0;
     uint8_t ok = 0;
     double pos[3];
-    if (limo_landmark_init(nullptr, 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
+    if (limo_landmark_init(context(), 1, off, rays.data(), &use_depth, pos, &ok) != LIMO_OK || !ok) return false;
     posAbs = Vector3d(pos);
     return true;
 }

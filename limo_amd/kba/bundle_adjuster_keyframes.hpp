@@ -13,6 +13,7 @@
 #include "landmark_selector.hpp"
 
 struct limo_ctx;
+struct limo_ray;
 
 namespace keyframe_bundle_adjustment {
 
@@ -87,6 +88,8 @@ public:
 
 private:
     std::map<LandmarkId, Landmark::ConstPtr> filterLandmarksById(const std::set<LandmarkId>& ids) const;
+    void collectRays(const Keyframe& kf, const LandmarkId& lId, std::vector<limo_ray>& rays) const;  // this keyframe's views
+    void collectRays(const LandmarkId& lId, std::vector<limo_ray>& rays) const;                      // every active keyframe
     limo_ctx* context();
     limo_ctx* ctx_ = nullptr;
     double solver_time_sec;
