@@ -2,12 +2,15 @@
 #include "kba_pack.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "kba_items.hpp"
 
@@ -60,37 +63,45 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     };
     std::vector<std::vector<View>> views(n);
     std::vector<std::vector<int>> obs_view(n);
-    for (int w = 0; w < n; ++w) {
+    // host threads over the windows (used by both passes)
+    auto for_windows = [&](auto&& f) {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = std::max(1u, std::min({nt, 16u, (unsigned)((n + 7) / 8)}));
+        if (const char* e = std::getenv("KBA_PACK_THREADS")) nt = std::max(1, std::atoi(e));
+        if (nt == 1) {
+            for (int w = 0; w < n; ++w) f(w);
+            return;
+        }
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&] {
+                for (int w = next.fetch_add(1); w < n; w = next.fetch_add(1)) f(w);
+            });
+        for (auto& th : pool) th.join();
+    };
+    std::vector<int> rc1(n, LIMO_OK);
+    std::vector<const char*> err1(n, nullptr);
+    for_windows([&](int w) {  // validation + the views (keyframe, camera) that carry observations
         const limo_ba_window& W = windows[w];
-        if (W.n_kf < 0 || W.n_lm < 0 || W.n_obs < 0 || W.n_cam < 0) {
-            err = "negative size";
-            return LIMO_ERR_INVALID;
-        }
-        if (!po.pose_only && !po.evaluate_only && W.n_kf < 3) {
-            err = "Not enough keyframes available in bundle_adjuster_keyframes. Should be 3";
-            return LIMO_ERR_NOT_ENOUGH_KF;
-        }
-        if (po.pose_only && W.n_kf != 1) {
-            err = "pose-only window must hold exactly one keyframe";
-            return LIMO_ERR_INVALID;
-        }
-        if (W.n_kf > kMaxKf) {
-            err = "window has more keyframes than kMaxKf (12)";
-            return LIMO_ERR_INVALID;
-        }
+        auto fail = [&](int code, const char* msg) {
+            rc1[w] = code;
+            err1[w] = msg;
+        };
+        if (W.n_kf < 0 || W.n_lm < 0 || W.n_obs < 0 || W.n_cam < 0) return fail(LIMO_ERR_INVALID, "negative size");
+        if (!po.pose_only && !po.evaluate_only && W.n_kf < 3)
+            return fail(LIMO_ERR_NOT_ENOUGH_KF, "Not enough keyframes available in bundle_adjuster_keyframes. Should be 3");
+        if (po.pose_only && W.n_kf != 1) return fail(LIMO_ERR_INVALID, "pose-only window must hold exactly one keyframe");
+        if (W.n_kf > kMaxKf) return fail(LIMO_ERR_INVALID, "window has more keyframes than kMaxKf (12)");
         if ((W.n_kf && (!W.kf_pose || !W.kf_plane_dir || !W.kf_plane_dist || !W.kf_fixation)) ||
             (W.n_lm && (!W.lm_pos || !W.lm_weight || !W.lm_is_ground)) || (W.n_cam && !W.cam) ||
-            (W.n_obs && (!W.obs_kf || !W.obs_lm || !W.obs_cam || !W.obs_u || !W.obs_v || !W.obs_d))) {
-            err = "null pointer in window";
-            return LIMO_ERR_INVALID;
-        }
+            (W.n_obs && (!W.obs_kf || !W.obs_lm || !W.obs_cam || !W.obs_u || !W.obs_v || !W.obs_d)))
+            return fail(LIMO_ERR_INVALID, "null pointer in window");
         std::vector<int> vid((size_t)W.n_kf * std::max(1, W.n_cam), -1);
         for (int i = 0; i < W.n_obs; ++i) {
             const int k = W.obs_kf[i], l = W.obs_lm[i], c = W.obs_cam[i];
-            if (k < 0 || k >= W.n_kf || l < 0 || l >= W.n_lm || c < 0 || c >= W.n_cam) {
-                err = "observation index out of range";
-                return LIMO_ERR_INVALID;
-            }
+            if (k < 0 || k >= W.n_kf || l < 0 || l >= W.n_lm || c < 0 || c >= W.n_cam)
+                return fail(LIMO_ERR_INVALID, "observation index out of range");
             vid[(size_t)k * W.n_cam + c] = 0;
         }
         int nv = 0;
@@ -102,6 +113,14 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 }
         obs_view[w].resize(W.n_obs);
         for (int i = 0; i < W.n_obs; ++i) obs_view[w][i] = vid[(size_t)W.obs_kf[i] * W.n_cam + W.obs_cam[i]];
+    });
+    for (int w = 0; w < n; ++w) {
+        if (rc1[w] != LIMO_OK) {
+            err = err1[w];
+            return rc1[w];
+        }
+        const limo_ba_window& W = windows[w];
+        const int nv = (int)views[w].size();
         P.Vmax = std::max(P.Vmax, nv);
         WinDesc& d = P.win[w];
         std::memset(&d, 0, sizeof(d));
@@ -141,17 +160,34 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.lm_gp.assign(P.TL, -1);
     P.lm_weight.resize(P.TL);
     P.lm_state.assign(P.TL, 0);
-    P.lm_slot.assign((size_t)std::max(1, P.Vmax) * P.SL, -1);
+    P.lm_slot.resize((size_t)std::max(1, P.Vmax) * P.SL);  // filled with -1 per window in pass 2, padding here
+    for (int v = 0; v < std::max(1, P.Vmax); ++v)
+        for (int64_t l = P.TL; l < P.SL; ++l) P.lm_slot[(size_t)v * P.SL + l] = -1;
     P.view_kf.resize(P.TV);
     P.view_win.resize(P.TV);
     P.view_cam.assign((size_t)P.TV * 16, 0.0);
     P.obs_pk.resize(P.TO);
     P.obs_src.resize(P.TO);
 
-    // ---- pass 2: fill
-    for (int w = 0; w < n; ++w) {
+    // ---- pass 2: fill.  Windows are independent: every window writes its own ranges of the fixed-size arrays and
+    //      collects its variable-size lists (workgroup tables, ground-plane rows) locally with LOCAL indices; a serial
+    //      merge concatenates them.  Host threads share the windows (the packing of a 1024-window batch is otherwise
+    //      the longest step of limo_ba_batch_create).
+    struct Local {
+        std::vector<int32_t> blk_view, blk_obs0, blk_n, blk_owner, lblk_win, lblk_lm0, lblk_n, lblk_owner, sblk_win, sblk_lm0,
+            sblk_n, sblk_owner, gp_lm, gp_kf, gp_owner;
+        std::vector<double> gp_w;
+        std::string err;
+        int rc = LIMO_OK;
+    };
+    const auto t_p1 = std::chrono::steady_clock::now();
+    std::vector<Local> locals(n);
+    auto pack_one = [&](int w) {
+        Local& L = locals[w];
         const limo_ba_window& W = windows[w];
         WinDesc& d = P.win[w];
+        for (int v = 0; v < std::max(1, P.Vmax); ++v)
+            std::fill_n(P.lm_slot.data() + (size_t)v * P.SL + d.lm0, W.n_lm, -1);
         std::memcpy(P.pose.data() + (size_t)d.kf0 * 7, W.kf_pose, sizeof(double) * 7 * W.n_kf);
         std::memcpy(P.pdir.data() + (size_t)d.kf0 * 3, W.kf_plane_dir, sizeof(double) * 3 * W.n_kf);
         std::memcpy(P.pdist.data() + d.kf0, W.kf_plane_dist, sizeof(double) * W.n_kf);
@@ -242,7 +278,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
             return perm[W.obs_lm[a]] < perm[W.obs_lm[b]];
         });
-        d.blk0 = (int)P.blk_view.size();
+        d.blk0 = (int)L.blk_view.size();
         std::vector<int> lm_nobs(W.n_lm, 0);
         int depth_blocks = 0;
         int pos = 0;
@@ -258,12 +294,12 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                         break;
                     }
                 const int gkf = d.kf0 + views[w][v].kf;
-                if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)P.blk_view.size();
+                if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)L.blk_view.size();
                 P.kf_nblk[gkf]++;
-                P.blk_view.push_back(d.view0 + v);
-                P.blk_obs0.push_back(d.obs0 + b0);
-                P.blk_n.push_back(b1 - b0);
-                P.blk_owner.push_back(W.obs_lm[order[b0]] % NS);
+                L.blk_view.push_back(d.view0 + v);
+                L.blk_obs0.push_back(d.obs0 + b0);
+                L.blk_n.push_back(b1 - b0);
+                L.blk_owner.push_back(W.obs_lm[order[b0]] % NS);
                 b0 = b1;
             }
             for (int i = start; i < pos; ++i) {
@@ -277,38 +313,39 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 P.obs_src[o] = src;
                 int32_t& slot = P.lm_slot[(size_t)v * P.SL + d.lm0 + l];
                 if (slot != -1) {
-                    err = "duplicate (keyframe, landmark, camera) observation";
-                    return LIMO_ERR_INVALID;
+                    L.err = "duplicate (keyframe, landmark, camera) observation";
+                    L.rc = LIMO_ERR_INVALID;
+                    return;
                 }
                 slot = o;
                 lm_nobs[l]++;
                 if (W.obs_d[src] > 0.0f) depth_blocks++;
             }
         }
-        d.n_blk = (int)P.blk_view.size() - d.blk0;
+        d.n_blk = (int)L.blk_view.size() - d.blk0;
         d.n_depth = depth_blocks;
         d.n_repr = W.n_obs;
         for (int l = 0; l < W.n_lm; ++l) P.lm_state[d.lm0 + l] = lm_nobs[l] > 0 ? (po.pose_only ? 2 : 1) : 0;
 
         // ---- ground-plane rows
-        d.gp0 = (int)P.gp_lm.size();
+        d.gp0 = (int)L.gp_lm.size();
         {
             for (const GpTmp& g : gp_tmp)
                 if (P.lm_state[d.lm0 + perm[g.lm]] == 0) P.lm_state[d.lm0 + perm[g.lm]] = 1;  // constrained by its gp block only
             // rows sorted by keyframe (stable in landmark order) so each keyframe owns a contiguous range
             std::stable_sort(gp_tmp.begin(), gp_tmp.end(), [](const GpTmp& a, const GpTmp& b) { return a.kf < b.kf; });
             for (const GpTmp& g : gp_tmp) {
-                const int gi = (int)P.gp_lm.size();
+                const int gi = (int)L.gp_lm.size();
                 if (P.kf_ngp[d.kf0 + g.kf] == 0) P.kf_gp0[d.kf0 + g.kf] = gi;
                 P.kf_ngp[d.kf0 + g.kf]++;
                 P.lm_gp[d.lm0 + perm[g.lm]] = gi;
-                P.gp_lm.push_back(d.lm0 + perm[g.lm]);
-                P.gp_kf.push_back(d.kf0 + g.kf);
-                P.gp_w.push_back(g.w);
-                P.gp_owner.push_back(g.lm % NS);
+                L.gp_lm.push_back(d.lm0 + perm[g.lm]);
+                L.gp_kf.push_back(d.kf0 + g.kf);
+                L.gp_w.push_back(g.w);
+                L.gp_owner.push_back(g.lm % NS);
             }
         }
-        d.n_gp = (int)P.gp_lm.size() - d.gp0;
+        d.n_gp = (int)L.gp_lm.size() - d.gp0;
 
         // ---- which parameter blocks exist / are free (B9)
         uint8_t* present = P.cpresent.data() + (size_t)d.cam0;
@@ -350,7 +387,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             d.has_gp_reg = (n_gp > 0 && W.n_kf > 1) ? 1 : 0;  // :717-719, :771
             std::vector<int> kf_obs(W.n_kf, 0), kf_gp(W.n_kf, 0);
             for (int i = 0; i < W.n_obs; ++i) kf_obs[W.obs_kf[i]]++;
-            for (int g = d.gp0; g < d.gp0 + d.n_gp; ++g) kf_gp[P.gp_kf[g] - d.kf0]++;
+            for (int g = d.gp0; g < d.gp0 + d.n_gp; ++g) kf_gp[L.gp_kf[g] - d.kf0]++;
             for (int k = 0; k < W.n_kf; ++k) {
                 const bool pose_in = kf_obs[k] > 0 || kf_gp[k] > 0 || d.has_gp_reg || (d.has_scale_reg && k < 2);
                 const bool plane_in = kf_gp[k] > 0 || d.has_gp_reg;
@@ -373,34 +410,78 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.do_trim = (W.n_lm > opts.min_landmarks_for_trimming) ? 1 : 0;  // :741 / :865
 
         // ---- workgroup tables
-        d.lblk0 = (int)P.lblk_win.size();
+        d.lblk0 = (int)L.lblk_win.size();
         for (size_t si = 0; si + 1 < seg.size(); ++si)
             for (int l0 = seg[si]; l0 < seg[si + 1]; l0 += kBlock) {
-                P.lblk_win.push_back(w);
-                P.lblk_lm0.push_back(d.lm0 + l0);
-                P.lblk_n.push_back(std::min(kBlock, seg[si + 1] - l0));
-                P.lblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
+                L.lblk_win.push_back(w);
+                L.lblk_lm0.push_back(d.lm0 + l0);
+                L.lblk_n.push_back(std::min(kBlock, seg[si + 1] - l0));
+                L.lblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
             }
-        d.n_lblk = (int)P.lblk_win.size() - d.lblk0;
-        d.sblk0 = (int)P.sblk_win.size();
+        d.n_lblk = (int)L.lblk_win.size() - d.lblk0;
+        d.sblk0 = (int)L.sblk_win.size();
         if (!po.pose_only && !po.evaluate_only && d.nf > 0) {
             const int per = kSchurLmPerBlock;
             for (size_t si = 0; si + 1 < seg.size(); ++si)
                 for (int l0 = seg[si]; l0 < seg[si + 1]; l0 += per) {
-                    P.sblk_win.push_back(w);
-                    P.sblk_lm0.push_back(d.lm0 + l0);
-                    P.sblk_n.push_back(std::min(per, seg[si + 1] - l0));
-                    P.sblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
+                    L.sblk_win.push_back(w);
+                    L.sblk_lm0.push_back(d.lm0 + l0);
+                    L.sblk_n.push_back(std::min(per, seg[si + 1] - l0));
+                    L.sblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
                 }
         }
-        d.n_sblk = (int)P.sblk_win.size() - d.sblk0;
+        d.n_sblk = (int)L.sblk_win.size() - d.sblk0;
+        };
+    for_windows(pack_one);
+    const auto t_p2 = std::chrono::steady_clock::now();
+    // ---- merge: local lists -> global lists, local indices -> global indices
+    for (int w = 0; w < n; ++w) {
+        Local& L = locals[w];
+        if (L.rc != LIMO_OK) {
+            err = L.err;
+            return L.rc;
+        }
+        WinDesc& d = P.win[w];
+        const int blk_base = (int)P.blk_view.size(), lblk_base = (int)P.lblk_win.size(), sblk_base = (int)P.sblk_win.size(),
+                  gp_base = (int)P.gp_lm.size();
+        d.blk0 += blk_base;
+        d.lblk0 += lblk_base;
+        d.sblk0 += sblk_base;
+        d.gp0 += gp_base;
+        for (int k = d.kf0; k < d.kf0 + d.n_kf; ++k) {
+            if (P.kf_nblk[k]) P.kf_blk0[k] += blk_base;
+            if (P.kf_ngp[k]) P.kf_gp0[k] += gp_base;
+        }
+        for (int l = d.lm0; l < d.lm0 + d.n_lm; ++l)
+            if (P.lm_gp[l] >= 0) P.lm_gp[l] += gp_base;
+        auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+        app(P.blk_view, L.blk_view);
+        app(P.blk_obs0, L.blk_obs0);
+        app(P.blk_n, L.blk_n);
+        app(P.blk_owner, L.blk_owner);
+        app(P.lblk_win, L.lblk_win);
+        app(P.lblk_lm0, L.lblk_lm0);
+        app(P.lblk_n, L.lblk_n);
+        app(P.lblk_owner, L.lblk_owner);
+        app(P.sblk_win, L.sblk_win);
+        app(P.sblk_lm0, L.sblk_lm0);
+        app(P.sblk_n, L.sblk_n);
+        app(P.sblk_owner, L.sblk_owner);
+        app(P.gp_lm, L.gp_lm);
+        app(P.gp_kf, L.gp_kf);
+        app(P.gp_w, L.gp_w);
+        app(P.gp_owner, L.gp_owner);
         d.hcc_off = P.hcc_total;
         P.hcc_total += (int64_t)d.nc * d.nc;
         d.spart_off = P.spart_total;
         P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
         d.sred_off = P.sred_total;
-        if (NS > 1) P.sred_total += (int64_t)NS * d.nf_pad * d.nf_pad;
+        if (P.n_shards > 1) P.sred_total += (int64_t)P.n_shards * d.nf_pad * d.nf_pad;
+        L = Local();
     }
+    if (std::getenv("KBA_PACK_TRACE"))
+        std::fprintf(stderr, "[kba] pack: fill %.1f ms, merge %.1f ms\n", std::chrono::duration<double, std::milli>(t_p2 - t_p1).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
     P.TG = (int)P.gp_lm.size();
     P.SG = pad64(std::max(1, P.TG));
     P.n_blk = (int)P.blk_view.size();

@@ -6,12 +6,36 @@
 // wiring, :704-736 scale / ground-plane regularisation and constness rules, :740-758 trimming schedule) and the
 // outer loop of robust_optimization::solveTrimmed (robust_optimization/src/robust_solving.cpp:140-248).
 #pragma once
+#include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "kba_layout.hpp"
 
 namespace kba {
+
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the big per-observation /
+// per-landmark arrays are written exactly once by the (threaded) packing, zero-filling them first only costs a
+// serial pass of page faults.
+template <typename T>
+struct default_init_allocator : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = default_init_allocator<U>;
+    };
+    template <typename U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <typename U, typename... Args>
+    void construct(U* p, Args&&... args) {
+        ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <typename T>
+using uvec = std::vector<T, default_init_allocator<T>>;
 
 struct PackedBatch {
     int32_t n_win = 0, TK = 0, TL = 0, TO = 0, TV = 0, TG = 0, n_blk = 0, n_lblk = 0, n_sblk = 0, Vmax = 0;
@@ -21,19 +45,21 @@ struct PackedBatch {
     int32_t n_shards = 1;        // landmark shards; owner of landmark l = (caller's index of l) mod n_shards
     std::vector<int32_t> blk_owner, lblk_owner, sblk_owner, gp_owner;  // owning shard of every workgroup / gp row
     std::vector<WinDesc> win;
-    std::vector<double> pose, pdir, pdist, lm;  // initial parameters
+    std::vector<double> pose, pdir, pdist;  // initial parameters
+    uvec<double> lm;
     std::vector<int32_t> kf_win, kf_blk0, kf_nblk, kf_gp0, kf_ngp;
     std::vector<uint8_t> cmask, cpresent;
     std::vector<int32_t> cslot;
-    std::vector<int32_t> lm_win, lm_gp, lm_slot;
-    std::vector<int32_t> lm_id;  // packed landmark -> index in the caller's window
-    std::vector<double> lm_weight;
+    std::vector<int32_t> lm_gp;
+    uvec<int32_t> lm_win, lm_slot;
+    uvec<int32_t> lm_id;  // packed landmark -> index in the caller's window
+    uvec<double> lm_weight;
     std::vector<uint8_t> lm_state;
     std::vector<int32_t> view_kf, view_win;
     std::vector<double> view_cam;
     std::vector<int32_t> blk_view, blk_obs0, blk_n;
-    std::vector<ObsPk> obs_pk;
-    std::vector<int32_t> obs_src;  // packed observation -> index in the caller's window
+    uvec<ObsPk> obs_pk;
+    uvec<int32_t> obs_src;  // packed observation -> index in the caller's window
     std::vector<int32_t> lblk_win, lblk_lm0, lblk_n, sblk_win, sblk_lm0, sblk_n;
     std::vector<int32_t> gp_lm, gp_kf;
     std::vector<double> gp_w;

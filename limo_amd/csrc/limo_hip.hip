@@ -642,7 +642,9 @@ static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* win
     b->ctx = ctx;
     b->opts = o;
     b->c = make_consts(o);
+    const auto t_c0 = std::chrono::steady_clock::now();
     int rc = pack_windows(n, windows, o, po, b->P, ctx->err);
+    const auto t_c1 = std::chrono::steady_clock::now();
     if (rc == LIMO_OK) {
         if (hipSetDevice(ctx->device) != hipSuccess) rc = LIMO_ERR_NO_DEVICE;
     }
@@ -660,6 +662,9 @@ static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* win
         }
     }
     if (rc == LIMO_OK) rc = b->upload();
+    if (std::getenv("KBA_PACK_TRACE"))
+        std::fprintf(stderr, "[kba] create: pack %.1f ms, upload %.1f ms\n", std::chrono::duration<double, std::milli>(t_c1 - t_c0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c1).count());
     if (rc != LIMO_OK) {
         delete b;
         return rc;

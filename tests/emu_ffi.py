@@ -18,7 +18,7 @@ def build(force=False):
     deps = _SRC + [os.path.join(_HERE, "..", "limo_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "limo_amd", "csrc")) if f.endswith(".hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + _SRC)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-o", LIB_PATH] + _SRC)
 
 
 SHIM_SRC = [os.path.join(_HERE, "..", "limo_amd", "kba", "bundle_adjuster_keyframes.cpp")]
@@ -34,11 +34,11 @@ def build_stream_test(gpu=False):
     test_src = os.path.join(_HERE, "cpp", "test_kba_stream.cpp")
     out = os.path.join(_HERE, "cpp", "_build", "test_kba_stream_gpu" if gpu else "test_kba_stream_emu")
     if not gpu:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
         return out
     libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
     return out
 
 
@@ -48,11 +48,11 @@ def build_shim_tests(gpu=False):
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
     test_src = os.path.join(_HERE, "cpp", "test_kba_shim.cpp")
     if not gpu:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SHIM_TEST_EMU, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_EMU, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
         return SHIM_TEST_EMU
     libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SHIM_TEST_GPU, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_GPU, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
     return SHIM_TEST_GPU
 
 
