@@ -71,7 +71,7 @@ def main():
     # ---- synthetic input: `distinct` different windows per rank, tiled to the batch size (each copy is an
     # independent solve; distinct seeds per rank)
     distinct = args.batch if args.distinct <= 0 else max(1, min(args.distinct, args.batch))
-    base = [synth.make_window(1000 * (rank + 1) + i, n_kf=args.n_kf, n_lm=args.n_lm) for i in range(distinct)]
+    base = [synth.make_window(1000 + 100000 * rank + i, n_kf=args.n_kf, n_lm=args.n_lm) for i in range(distinct)]
     windows = [base[i % distinct].copy() for i in range(args.batch)]
     batch = ba.Batch(ctx, windows)
     n_obs = sum(w.n_obs for w in windows)
@@ -183,7 +183,7 @@ def main():
             "algorithmic_flops_per_launch": schur_flops / max(1, stats["schur_launches"]),
             "kernel_share_of_device_time": schur_ms / stats["total_ms"] if stats["total_ms"] > 0 else None,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(base, opts, args.cpu_windows)
         print(json.dumps(out))
     batch.close()

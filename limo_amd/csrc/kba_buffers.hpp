@@ -62,7 +62,10 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(blk_view, NB * I, P.blk_view.data());
     KBA_BUF(blk_obs0, NB * I, P.blk_obs0.data());
     KBA_BUF(blk_n, NB * I, P.blk_n.data());
-    KBA_BUF(obs_pk, TO * sizeof(ObsPk), P.obs_pk.data());
+    KBA_BUF(obs_lm, TO * I, P.obs_lm.data());
+    KBA_BUF(obs_u, TO * sizeof(float), P.obs_u.data());
+    KBA_BUF(obs_v, TO * sizeof(float), P.obs_v.data());
+    KBA_BUF(obs_d, TO * sizeof(float), P.obs_d.data());
     KBA_BUF(lblk_win, NL * I, P.lblk_win.data());
     KBA_BUF(lblk_lm0, NL * I, P.lblk_lm0.data());
     KBA_BUF(lblk_n, NL * I, P.lblk_n.data());
@@ -77,8 +80,8 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(gp_E, (size_t)P.SG * 3 * D, nullptr);
     KBA_BUF(gp_cost, TG * D, nullptr);
     KBA_BUF(gp_cost_c, TG * D, nullptr);
-    KBA_BUF(obs_lin, (size_t)(P.evaluate_only ? 1 : P.SO * 12) * D, nullptr);
-    KBA_BUF(obs_r, (size_t)(P.evaluate_only ? P.SO * 3 : 1) * D, nullptr);
+    KBA_BUF(obs_r, (size_t)P.SO * 3 * D, nullptr);
+    KBA_BUF(obs_Ft, (size_t)(P.evaluate_only ? 1 : P.SO * 9) * D, nullptr);
     KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
     KBA_BUF(blk_part, NB * kLinPartial * D, nullptr);

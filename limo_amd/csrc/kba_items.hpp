@@ -23,51 +23,6 @@
 namespace kba {
 
 // ======================================================================================= observations
-// Factored linearisation of observation o: v12 = (Ft0..Ft8, r0, r1, r2), see BatchView::obs_lin.
-KBA_HD void lin_store(const BatchView& bv, int64_t o, const double* v12) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double2* p = reinterpret_cast<double2*>(bv.obs_lin);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) p[k * bv.SO + o] = make_double2(v12[2 * k], v12[2 * k + 1]);
-#else
-    for (int k = 0; k < 6; ++k) {
-        bv.obs_lin[(k * bv.SO + o) * 2] = v12[2 * k];
-        bv.obs_lin[(k * bv.SO + o) * 2 + 1] = v12[2 * k + 1];
-    }
-#endif
-}
-// first 2*npairs elements (npairs = 5: Ft and r0; 6: everything)
-template <int NPAIRS>
-KBA_HD void lin_load(const BatchView& bv, int64_t o, double* out) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double2* p = reinterpret_cast<const double2*>(bv.obs_lin);
-#pragma unroll
-    for (int k = 0; k < NPAIRS; ++k) {
-        const double2 t = p[k * bv.SO + o];
-        out[2 * k] = t.x;
-        out[2 * k + 1] = t.y;
-    }
-#else
-    for (int k = 0; k < NPAIRS; ++k) {
-        out[2 * k] = bv.obs_lin[(k * bv.SO + o) * 2];
-        out[2 * k + 1] = bv.obs_lin[(k * bv.SO + o) * 2 + 1];
-    }
-#endif
-}
-KBA_HD ObsPk obs_load(const BatchView& bv, int64_t o) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int4 t = reinterpret_cast<const int4*>(bv.obs_pk)[o];
-    ObsPk k;
-    k.u = __int_as_float(t.x);
-    k.v = __int_as_float(t.y);
-    k.d = __int_as_float(t.z);
-    k.lm = t.w;
-    return k;
-#else
-    return bv.obs_pk[o];
-#endif
-}
-
 struct LinLane {
     double cost;
     int fail;
@@ -81,16 +36,15 @@ KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b,
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
-    const ObsPk m = obs_load(bv, o);
-    const int gl = m.lm;
+    const int gl = bv.obs_lm[o];
     ObsOut oo;
     bool live = bv.lm_state[gl] != 0;
     bool ok = true;
     if (live) {
         const double* cam = bv.view_cam + 16 * (int64_t)view;
         ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                                   bv.lm + 3 * (int64_t)gl, m.u, m.v, m.d, bv.lm_weight[gl], c.a_rep, c.a_dep, true, &oo,
-                                   want_cost);
+                                   bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
+                                   c.a_rep, c.a_dep, true, &oo, want_cost);
     }
     if (!live || !ok) {
         for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
@@ -100,13 +54,11 @@ KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b,
         if (live) out.fail = 1;
     }
     if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
-        double v12[12];
-        for (int row = 0; row < 3; ++row)  // Ft = translation columns of Jp (see BatchView::obs_lin)
-            for (int j = 0; j < 3; ++j) v12[row * 3 + j] = oo.Jp[row * 6 + 3 + j];
-        for (int i = 0; i < 3; ++i) v12[9 + i] = oo.r[i];
-        lin_store(bv, o, v12);
+        for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
+        for (int row = 0; row < 3; ++row)  // Ft = translation columns of Jp (see BatchView::obs_Ft)
+            for (int j = 0; j < 3; ++j) bv.obs_Ft[(row * 3 + j) * bv.SO + o] = oo.Jp[row * 6 + 3 + j];
     } else if (oo.cost == 1.2345) {
-        bv.obs_lin[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
+        bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
     }
     out.cost += oo.cost;
     int k = 0;
@@ -132,13 +84,12 @@ KBA_HD void cost_lane(const BatchView& bv, const SolveConsts& c, int b, int t, d
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
-    const ObsPk m = obs_load(bv, o);
-    const int gl = m.lm;
+    const int gl = bv.obs_lm[o];
     if (!bv.lm_state[gl]) return;
     const double* cam = bv.view_cam + 16 * (int64_t)view;
     double cst;
     if (!obs_cost(bv.pose_c + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                  bv.lm_c + 3 * (int64_t)gl, m.u, m.v, m.d, bv.lm_weight[gl], c.a_rep, c.a_dep,
+                  bv.lm_c + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl], c.a_rep, c.a_dep,
                   &cst)) {
         fail = 1;
         return;
@@ -151,8 +102,7 @@ KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
-    const ObsPk m = obs_load(bv, o);
-    const int gl = m.lm;
+    const int gl = bv.obs_lm[o];
     double nr = -1.0, nd = -1.0;
     if (bv.lm_state[gl]) {
         const double* cam = bv.view_cam + 16 * (int64_t)view;
@@ -160,12 +110,12 @@ KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_
         // the reprojection functor fails for |z| < 0.01 (its block then counts as an infinite residual); the
         // depth functor has no failure mode (cost_functors_ceres.hpp:193-212)
         if (obs_residual(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                         bv.lm + 3 * (int64_t)gl, m.u, m.v, m.d, ruv, &rd, zc)) {
+                         bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], ruv, &rd, zc)) {
             nr = sqrt(ruv[0] * ruv[0] + ruv[1] * ruv[1]);
         } else {
             nr = INFINITY;
         }
-        if (m.d > 0.0f) nd = fabs(zc[2] - static_cast<double>(m.d));
+        if (bv.obs_d[o] > 0.0f) nd = fabs(zc[2] - static_cast<double>(bv.obs_d[o]));
     }
     plane_rep[o] = nr;
     plane_dep[o] = nd;
@@ -213,10 +163,8 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
         const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
         if (s < 0) continue;
         double E[9], Ft[9], R[9], r[3];
-        double v12[12];
-        lin_load<6>(bv, s, v12);
-        for (int i = 0; i < 9; ++i) Ft[i] = v12[i];
-        for (int i = 0; i < 3; ++i) r[i] = v12[9 + i];
+        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+        for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
         quat_R(bv.pose + 7 * (int64_t)bv.view_kf[wd.view0 + j], R);
         mat3_mul(Ft, R, E);
         for (int row = 0; row < 3; ++row) {
@@ -373,8 +321,9 @@ KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int
                 rot_tangent_jac(pose, bv.lm + 3 * (int64_t)gl, M);
                 have = true;
             }
-            double Ft[10];
-            lin_load<5>(bv, s, Ft);
+            double Ft[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
             schur_pose_block(Ft, R, M, lmk, sc + row0, Y);
         }
     }
@@ -430,8 +379,8 @@ KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
         const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
         // F dc = Ft (M d_rot + d_trans);  E^T (F dc) = R^T Ft^T (F dc)
         const double* pose = bv.pose + 7 * (int64_t)gk;
-        double Ft[10], R[9], M[9], m[3], q[3], v[3];
-        lin_load<5>(bv, s, Ft);
+        double Ft[9], R[9], M[9], m[3], q[3], v[3];
+        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
         quat_R(pose, R);
         rot_tangent_jac(pose, x, M);
         mat3_vec(M, dc, m);

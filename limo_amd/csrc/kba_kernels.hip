@@ -218,7 +218,7 @@ __host__ __device__ inline int schur_lds_bytes(int nfp) {
 
 // What a lane of the fast path holds one tile ahead (its landmark of the next tile, its keyframe is fixed).
 struct SchurPre {
-    double Ft[10];  // factored Jacobian of the (landmark, keyframe) observation (+ r0: loaded as five pairs)
+    double Ft[9];   // factored Jacobian of the (landmark, keyframe) observation
     double lmk[9];  // landmark scale (3) | L^-1 (6)
     double p[3];    // landmark position
     double t[3];    // L^-1 S g (lanes kq == 0 only)
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         if (P.seen && dbg != 35) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) P.p[i] = bv.lm[3 * (int64_t)gl + i];
-            lin_load<5>(bv, slot, P.Ft);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) P.Ft[i] = bv.obs_Ft[i * bv.SO + slot];
         }
     };
     SchurPre nxt;
@@ -625,12 +626,11 @@ __device__ __forceinline__ void evaluate_lane(const BatchView& bv, const SolveCo
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
-    const ObsPk m = obs_load(bv, o);
-    const int gl = m.lm;
+    const int gl = bv.obs_lm[o];
     const double* cam = bv.view_cam + 16 * (int64_t)view;
     ObsOut oo;
     const bool ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                                          bv.lm + 3 * (int64_t)gl, m.u, m.v, m.d, bv.lm_weight[gl],
+                                          bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
                                           c.a_rep, c.a_dep, apply_loss != 0, &oo);
     if (!ok) {
         for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;

@@ -32,12 +32,6 @@ constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per p
 // number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
 constexpr int kLinPartial = 28;
 
-// One observation as the view-major kernels read it.
-struct ObsPk {
-    float u, v, d;
-    int32_t lm;  // global landmark index
-};
-
 struct WinDesc {
     int32_t kf0, n_kf;
     int32_t lm0, n_lm;
@@ -136,7 +130,8 @@ struct BatchView {
     const int32_t* blk_view;    // [n_blk]
     const int32_t* blk_obs0;    // [n_blk]
     const int32_t* blk_n;       // [n_blk]
-    const ObsPk* obs_pk;        // [TO] measurement (u, v, d) + global landmark: one 16-byte load per observation
+    const int32_t* obs_lm;      // [TO] global landmark
+    const float *obs_u, *obs_v, *obs_d;  // [TO]
     const int32_t* lblk_win;    // [n_lblk]
     const int32_t* lblk_lm0;
     const int32_t* lblk_n;
@@ -155,10 +150,7 @@ struct BatchView {
     // pose and  c_row^T Rc R(q)  towards its landmark, so only  Ft = c^T Rc  (3x3, loss-scaled) is stored and the
     // landmark-parallel kernels rebuild  F = Ft [M | I],  E = Ft R  from the pose / landmark they hold anyway
     // (96 B per observation instead of 240 B).  Evaluate-only batches (Problem::Evaluate) materialise Jp / Jl in full.
-    // Stored as 6 planes of double PAIRS, obs_lin[(k*SO + obs)*2 + {0,1}] = element 2k, 2k+1 of (Ft0..Ft8, r0, r1, r2):
-    // 16-byte loads / stores per lane (half the memory instructions of 8-byte planes).
-    double *obs_lin;                  // [6][SO][2]
-    double *obs_r;                    // [3][SO], evaluate-only batches
+    double *obs_r, *obs_Ft;           // [3|9][SO]
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* blk_part;           // [n_blk*kLinPartial]
     int32_t* blk_fail;          // [n_blk]

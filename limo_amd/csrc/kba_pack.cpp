@@ -166,7 +166,10 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.view_kf.resize(P.TV);
     P.view_win.resize(P.TV);
     P.view_cam.assign((size_t)P.TV * 16, 0.0);
-    P.obs_pk.resize(P.TO);
+    P.obs_lm.resize(P.TO);
+    P.obs_u.resize(P.TO);
+    P.obs_v.resize(P.TO);
+    P.obs_d.resize(P.TO);
     P.obs_src.resize(P.TO);
 
     // ---- pass 2: fill.  Windows are independent: every window writes its own ranges of the fixed-size arrays and
@@ -306,10 +309,10 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 const int src = order[i];
                 const int o = d.obs0 + i;
                 const int l = perm[W.obs_lm[src]];
-                P.obs_pk[o].lm = d.lm0 + l;
-                P.obs_pk[o].u = W.obs_u[src];
-                P.obs_pk[o].v = W.obs_v[src];
-                P.obs_pk[o].d = W.obs_d[src];
+                P.obs_lm[o] = d.lm0 + l;
+                P.obs_u[o] = W.obs_u[src];
+                P.obs_v[o] = W.obs_v[src];
+                P.obs_d[o] = W.obs_d[src];
                 P.obs_src[o] = src;
                 int32_t& slot = P.lm_slot[(size_t)v * P.SL + d.lm0 + l];
                 if (slot != -1) {

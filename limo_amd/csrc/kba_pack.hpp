@@ -58,7 +58,8 @@ struct PackedBatch {
     std::vector<int32_t> view_kf, view_win;
     std::vector<double> view_cam;
     std::vector<int32_t> blk_view, blk_obs0, blk_n;
-    uvec<ObsPk> obs_pk;
+    uvec<int32_t> obs_lm;
+    uvec<float> obs_u, obs_v, obs_d;
     uvec<int32_t> obs_src;  // packed observation -> index in the caller's window
     std::vector<int32_t> lblk_win, lblk_lm0, lblk_n, sblk_win, sblk_lm0, sblk_n;
     std::vector<int32_t> gp_lm, gp_kf;

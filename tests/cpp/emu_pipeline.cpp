@@ -439,12 +439,11 @@ int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int 
         const double* cam = B.bv.view_cam + 16 * (int64_t)view;
         for (int t = 0; t < B.bv.blk_n[b]; ++t) {
             const int64_t o_ = B.bv.blk_obs0[b] + t;
-            const ObsPk m_ = B.bv.obs_pk[o_];
-            const int gl = m_.lm;
+            const int gl = B.bv.obs_lm[o_];
             ObsOut oo;
             bool ok = obs_residual_jacobian(B.bv.pose + 7 * (int64_t)B.bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1],
-                                            cam[2], B.bv.lm + 3 * (int64_t)gl, m_.u, m_.v, m_.d, B.bv.lm_weight[gl],
-                                            B.c.a_rep, B.c.a_dep, apply_loss != 0, &oo);
+                                            cam[2], B.bv.lm + 3 * (int64_t)gl, B.bv.obs_u[o_], B.bv.obs_v[o_],
+                                            B.bv.obs_d[o_], B.bv.lm_weight[gl], B.c.a_rep, B.c.a_dep, apply_loss != 0, &oo);
             const int src = B.P.obs_src[o_];
             if (!ok) {
                 std::memset(&oo, 0, sizeof(oo));
