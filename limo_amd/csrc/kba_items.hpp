@@ -50,13 +50,13 @@ KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b,
         for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
         for (int i = 0; i < 18; ++i) oo.Jp[i] = 0.0;
         for (int i = 0; i < 9; ++i) oo.Jl[i] = 0.0;
+        for (int i = 0; i < 4; ++i) oo.c[i] = 0.0;
         oo.cost = 0.0;
         if (live) out.fail = 1;
     }
     if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
         for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
-        for (int row = 0; row < 3; ++row)  // Ft = translation columns of Jp (see BatchView::obs_Ft)
-            for (int j = 0; j < 3; ++j) bv.obs_Ft[(row * 3 + j) * bv.SO + o] = oo.Jp[row * 6 + 3 + j];
+        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = oo.c[i];  // see BatchView::obs_c
     } else if (oo.cost == 1.2345) {
         bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
     }
@@ -163,8 +163,10 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
         const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
         if (s < 0) continue;
         double E[9], Ft[9], R[9], r[3];
-        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+        double c4[4];
+        for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
         for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
+        ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
         quat_R(bv.pose + 7 * (int64_t)bv.view_kf[wd.view0 + j], R);
         mat3_mul(Ft, R, E);
         for (int row = 0; row < 3; ++row) {
@@ -241,7 +243,7 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
 // sum Y' t  in one symmetric rank-k update.  Landmarks without a ground-plane row only fill pose columns.
 //
 // schur_pair_block: the 3 x 10 block of Y' that landmark gl contributes to keyframe kl (local index): all of the
-// keyframe's views of the landmark (F = Ft [M | I], E = Ft R rebuilt from the factored planes) plus its ground-plane
+// keyframe's views of the landmark (Ft = c^T Rc, F = Ft [M | I], E = Ft R rebuilt from the factored planes) plus its ground-plane
 // row when that row is attached to kl.  Y[a*3 + c'] for local slot a; masked slots are left zero.
 //   lmk = landmark scale (3) | L^-1 (6, lower, row-major);  sc = Jacobi scale of the window's slots (local index);
 //   vkl[j] = local keyframe of view j.
@@ -321,9 +323,10 @@ KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int
                 rot_tangent_jac(pose, bv.lm + 3 * (int64_t)gl, M);
                 have = true;
             }
-            double Ft[9];
+            double Ft[9], c4[4];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
+            ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
             schur_pose_block(Ft, R, M, lmk, sc + row0, Y);
         }
     }
@@ -379,8 +382,9 @@ KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
         const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
         // F dc = Ft (M d_rot + d_trans);  E^T (F dc) = R^T Ft^T (F dc)
         const double* pose = bv.pose + 7 * (int64_t)gk;
-        double Ft[9], R[9], M[9], m[3], q[3], v[3];
-        for (int i = 0; i < 9; ++i) Ft[i] = bv.obs_Ft[i * bv.SO + s];
+        double Ft[9], c4[4], R[9], M[9], m[3], q[3], v[3];
+        for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
+        ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
         quat_R(pose, R);
         rot_tangent_jac(pose, x, M);
         mat3_vec(M, dc, m);

@@ -213,12 +213,12 @@ __host__ __device__ inline int schur_ld(int nfp) {
 constexpr int kSchurMaxViews = 64;
 
 __host__ __device__ inline int schur_lds_bytes(int nfp) {
-    return (3 * kSchurLm * schur_ld(nfp) + kMaxNc) * (int)sizeof(double) + (kMaxNc + kSchurMaxViews + kMaxKf + 4) * (int)sizeof(int);
+    return (3 * kSchurLm * schur_ld(nfp) + kMaxNc + 9 * kMaxKf) * (int)sizeof(double) + (kMaxNc + kSchurMaxViews + kMaxKf + 4) * (int)sizeof(int);
 }
 
 // What a lane of the fast path holds one tile ahead (its landmark of the next tile, its keyframe is fixed).
 struct SchurPre {
-    double Ft[9];   // factored Jacobian of the (landmark, keyframe) observation
+    double c[4];    // factored Jacobian of the (landmark, keyframe) observation: (au, xn, yn, sd)
     double lmk[9];  // landmark scale (3) | L^-1 (6)
     double p[3];    // landmark position
     double t[3];    // L^-1 S g (lanes kq == 0 only)
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Z = smem;                                    // [3*kSchurLm][ld]
     double* sc_s = Z + 3 * kSchurLm * ld;                // [kMaxNc] Jacobi scale by local slot
-    int* zc_s = reinterpret_cast<int*>(sc_s + kMaxNc);   // [kMaxNc] tile column of a local slot or -1
+    double* rc_s = sc_s + kMaxNc;                        // [kMaxKf][9] camera extrinsic rotation of the keyframe's view
+    int* zc_s = reinterpret_cast<int*>(rc_s + 9 * kMaxKf);  // [kMaxNc] tile column of a local slot or -1
     int* vkl = zc_s + kMaxNc;                            // [kSchurMaxViews] local keyframe of each view
     int* fk = vkl + kSchurMaxViews;                      // [kMaxKf] local keyframes with a free slot; [kMaxKf] count,
                                                          // [kMaxKf+1] fast-path flag
@@ -252,6 +253,10 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
     for (int j = lane; j < wd.n_view; j += 64) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
     for (int i = lane; i < 3 * kSchurLm * ld; i += 64) Z[i] = 0.0;
     __syncthreads();
+    for (int i = lane; i < 9 * wd.n_view; i += 64) {  // (one view per keyframe on the fast path; the last one wins otherwise)
+        const int j = i / 9;
+        rc_s[9 * vkl[j] + i % 9] = bv.view_cam[16 * (int64_t)(wd.view0 + j) + 4 + i % 9];
+    }
     if (lane == 0) {
         int n = 0, mono = 1;
         for (int k = 0; k < wd.n_kf; ++k) {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
     const int my_kl = (fast && kq < nfk) ? fk[kq] : -1;
     int my_view = -1;
     bool pose_free = false;
-    double Rk[9], qk[4];
+    double Rk[9], qk[4];  // keyframe rotation, quaternion
     if (my_kl >= 0) {
         for (int j = 0; j < wd.n_view; ++j)
             if (vkl[j] == my_kl) my_view = j;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
 #pragma unroll
             for (int i = 0; i < 3; ++i) P.p[i] = bv.lm[3 * (int64_t)gl + i];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) P.Ft[i] = bv.obs_Ft[i * bv.SO + slot];
+            for (int i = 0; i < 4; ++i) P.c[i] = bv.obs_c[i * bv.SO + slot];
         }
     };
     SchurPre nxt;
@@ -349,7 +354,9 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
                 if (cur.seen && dbg != 31) {
                     double M[9];
                     rot_tangent_jac(qk, cur.p, M);
-                    schur_pose_block(cur.Ft, Rk, M, cur.lmk, sc_s + my_kl * kCamSlots, Y);
+                    double Ft[9];
+                    ft_build(cur.c, rc_s + 9 * my_kl, Ft);
+                    schur_pose_block(Ft, Rk, M, cur.lmk, sc_s + my_kl * kCamSlots, Y);
                 }
                 if (tile_gp && cur.live) {
                     const int gg = bv.lm_gp[cur.gl];

@@ -147,10 +147,12 @@ struct BatchView {
     double* gp_cost_c;          // [TG] cost at the candidate
     // --- materialised linearisation (planes over observations)
     // Solver batches keep the FACTORED Jacobian: every row of an observation is  c_row^T Rc [ M(q,p) | I ]  towards its
-    // pose and  c_row^T Rc R(q)  towards its landmark, so only  Ft = c^T Rc  (3x3, loss-scaled) is stored and the
-    // landmark-parallel kernels rebuild  F = Ft [M | I],  E = Ft R  from the pose / landmark they hold anyway
-    // (96 B per observation instead of 240 B).  Evaluate-only batches (Problem::Evaluate) materialise Jp / Jl in full.
-    double *obs_r, *obs_Ft;           // [3|9][SO]
+    // pose and  c_row^T Rc R(q)  towards its landmark, and the three c_row are spanned by FOUR scalars
+    // (au, xn, yn, sd; kba_math.hpp:ft_build).  Only those and the residual are stored - 56 B per observation instead
+    // of 240 B for J_pose 3x6 + J_point 3x3; the landmark-parallel kernels rebuild Ft = c^T Rc, F = Ft [M | I],
+    // E = Ft R from the view / pose / landmark they hold anyway.  Evaluate-only batches (Problem::Evaluate)
+    // materialise Jp / Jl in full.
+    double *obs_r, *obs_c;            // [3|4][SO]
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* blk_part;           // [n_blk*kLinPartial]
     int32_t* blk_fail;          // [n_blk]

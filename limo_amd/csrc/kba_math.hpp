@@ -134,7 +134,20 @@ struct ObsOut {
     double Jp[18];
     double Jl[9];
     double cost;
+    double c[4];  // (au, xn, yn, sd): the translation columns of Jp are ft_build(c, Rc), see below
 };
+
+// Every row of an observation's Jacobian is  c_row^T Rc [ M(q,p) | I ]  (pose) /  c_row^T Rc R(q)  (landmark) with
+//   c_u = au (1, 0, -xn),  c_v = au (0, 1, -yn),  c_d = sd (0, 0, 1),   au = sqrt(rho'_uv) f / z,  sd = sqrt(rho'_d).
+// Ft = c^T Rc (3x3, = the translation columns of Jp) is rebuilt from the FOUR scalars and the view's Rc.
+KBA_HD void ft_build(const double* c, const double* Rc, double* Ft) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Ft[0 + j] = c[0] * (Rc[0 + j] - c[1] * Rc[6 + j]);
+        Ft[3 + j] = c[0] * (Rc[3 + j] - c[2] * Rc[6 + j]);
+        Ft[6 + j] = c[3] * Rc[6 + j];
+    }
+}
 
 KBA_HD bool obs_residual(const double* pose, const double* Rc, const double* tc, double f, double cx, double cy,
                          const double* lm, float u, float v, float d, double* r_uv, double* r_d, double* zc_out) {
@@ -220,6 +233,10 @@ KBA_HD bool obs_residual_jacobian(const double* pose, const double* Rc, const do
     o->r[1] = su * rv;
     o->r[2] = sd * rd;
     const double au = su * fz, ad = sd;
+    o->c[0] = au;
+    o->c[1] = xn;
+    o->c[2] = yn;
+    o->c[3] = ad;
     for (int j = 0; j < 3; ++j) {
         o->Jp[0 * 6 + j] = au * (G[0 + j] - xn * G[6 + j]);
         o->Jp[1 * 6 + j] = au * (G[3 + j] - yn * G[6 + j]);
