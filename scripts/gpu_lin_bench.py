@@ -12,7 +12,8 @@ ws = [synth.make_window(7000 + i) for i in range(B)]
 b = ba.Batch(ctx, ws)
 n_obs = sum(w.n_obs for w in ws)
 n_dep = int(sum((w.obs_d > 0).sum() for w in ws))
-alg = 148 * n_obs  # factored Jacobian: read 52 B + write r (24 B) + Ft (72 B) per observation
+alg = 212 * n_obs + 84 * n_dep  # SURVEY 8d work unit (materialised Jacobian); stored: 52 B read + 56 B written
+stored = 108 * n_obs
 for _ in range(3):
     b.reset(); b.solve(opts)
 b.kernel_stats(reset=True)
@@ -23,4 +24,4 @@ st = b.kernel_stats()
 # every solve launches k_linearize twice here (the second launch finds nothing to linearise and exits at once):
 # time per solve = the full-batch launch (+ ~5 us of the empty one)
 ms = st["linearize_ms"] / N
-print("B=%d obs=%d  k_linearize %.1f us/launch  algorithmic %.1f MB -> %.0f GB/s (%.2f of 8 TB/s)  [variant %s]" % (B, n_obs, ms * 1e3, alg / 1e6, alg / ms / 1e6, alg / ms / 1e6 / 8000, os.environ.get("KBA_DEBUG_STAGE", "0")))
+print("B=%d obs=%d  k_linearize %.1f us/launch  algorithmic (SURVEY 8d) %.1f MB -> %.0f GB/s (%.2f of 8 TB/s); stored bytes %.1f MB -> %.0f GB/s  [variant %s]" % (B, n_obs, ms * 1e3, alg / 1e6, alg / ms / 1e6, alg / ms / 1e6 / 8000, stored / 1e6, stored / ms / 1e6, os.environ.get("KBA_DEBUG_STAGE", "0")))
