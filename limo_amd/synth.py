@@ -115,8 +115,11 @@ def make_window(
     shrub_frac=0.1,
     with_ground_plane=True,
     dt=0.4,
+    stereo_baseline=0.0,
 ):
-    """One synthetic window.  Returns a Window whose .meta holds the ground truth (gt_pose, gt_lm)."""
+    """One synthetic window.  Returns a Window whose .meta holds the ground truth (gt_pose, gt_lm).
+    stereo_baseline > 0 adds a second camera that far to the right of the first one (two views per keyframe;
+    reprojection-only measurements), the multi-camera case of the reference (keyframe.cpp:5-17,43-59)."""
     rng = np.random.default_rng(int(seed))
     cam = kitti_camera()
     f, cx, cy = cam[0], cam[1], cam[2]
@@ -211,6 +214,31 @@ def make_window(
     kk, nn = np.nonzero(vis[:, idx])
     lm_ids = idx[nn]
     weight = np.where(rng.uniform(size=n_lm) < shrub_frac, 0.9, 1.0)
+    cams = cam[None, :]
+    o_kf, o_lm, o_cam = kk.astype(np.int32), nn.astype(np.int32), np.zeros(kk.size, np.int32)
+    o_u, o_v, o_d = mu[kk, lm_ids], mv[kk, lm_ids], md[kk, lm_ids]
+    if stereo_baseline > 0.0:
+        cam2 = cam.copy()
+        cam2[7] = cam[7] - stereo_baseline  # camera <- vehicle translation of a camera displaced along its own +x
+        t_cv2 = cam2[7:10]
+        t_co2 = np.einsum("ij,kj->ki", R_cv, t_ko) + t_cv2
+        pc2 = np.einsum("kij,nj->kni", R_co, gt_lm) + t_co2[:, None, :]
+        z2 = pc2[..., 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u2 = f * pc2[..., 0] / z2 + cx
+            v2 = f * pc2[..., 1] / z2 + cy
+        vis2 = (z2 > 0.1) & (u2 >= 0) & (u2 < KITTI_W) & (v2 >= 0) & (v2 < KITTI_H) & vis
+        u2 = (u2 + rng.normal(0, uv_sigma, u2.shape)).astype(np.float32)
+        v2 = (v2 + rng.normal(0, uv_sigma, v2.shape)).astype(np.float32)
+        k2, n2 = np.nonzero(vis2[:, idx])
+        l2 = idx[n2]
+        cams = np.stack([cam, cam2])
+        o_kf = np.concatenate([o_kf, k2.astype(np.int32)])
+        o_lm = np.concatenate([o_lm, n2.astype(np.int32)])
+        o_cam = np.concatenate([o_cam, np.ones(k2.size, np.int32)])
+        o_u = np.concatenate([o_u, u2[k2, l2]])
+        o_v = np.concatenate([o_v, v2[k2, l2]])
+        o_d = np.concatenate([o_d, np.full(k2.size, -1.0, np.float32)])
     w = Window(
         kf_pose=init_pose,
         kf_plane_dir=np.tile(np.array([0.0, 0.0, 1.0]), (n_kf, 1)),
@@ -218,16 +246,16 @@ def make_window(
         kf_fixation=np.array(
             [_ffi.LIMO_FIX_POSE, _ffi.LIMO_FIX_SCALE] + [_ffi.LIMO_FIX_NONE] * (n_kf - 2), np.int32
         )[:n_kf],
-        cam=cam[None, :],
+        cam=cams,
         lm_pos=lm_init[idx],
         lm_weight=weight[idx],
         lm_is_ground=is_ground[idx] if with_ground_plane else np.zeros(idx.size, np.uint8),
-        obs_kf=kk.astype(np.int32),
-        obs_lm=nn.astype(np.int32),
-        obs_cam=np.zeros(kk.size, np.int32),
-        obs_u=mu[kk, lm_ids],
-        obs_v=mv[kk, lm_ids],
-        obs_d=md[kk, lm_ids],
+        obs_kf=o_kf,
+        obs_lm=o_lm,
+        obs_cam=o_cam,
+        obs_u=o_u,
+        obs_v=o_v,
+        obs_d=o_d,
         meta={"gt_pose": gt_pose, "gt_lm": gt_lm[idx], "seed": int(seed)},
     )
     return w

@@ -33,6 +33,7 @@ CASES = [
     dict(seed=43, n_kf=6, n_lm=350, depth_prob=0.02),  # < 10 depth blocks per ... exercises plane-distance fixing
     dict(seed=44, n_kf=5, n_lm=250, ground_frac=0.0),  # depth but no ground landmarks
     dict(seed=45, n_kf=12, n_lm=200),  # largest supported window
+    dict(seed=46, n_kf=4, n_lm=400, stereo_baseline=0.54),  # two cameras per keyframe (generic Schur path)
     dict(seed=909, n_kf=5, n_lm=2000),  # first solve FAILS at x0 (a reprojection block with |z| < 0.01), trimming removes it
 ]
 
