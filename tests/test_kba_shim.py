@@ -35,9 +35,9 @@ def run_stream(exe, n_frames, n_lm):
 def test_streaming_sequence_with_emulated_backend():
     """BASELINE.json configs[4] in miniature: sliding 5-keyframe window over a synthetic drive, the per-frame call
     order of the reference's node (adjustPoseOnly -> push -> deactivateKeyframes -> solve), ATE against ground truth."""
-    run_stream(emu_ffi.build_stream_test(gpu=False), 16, 800)
+    run_stream(emu_ffi.build_stream_test(gpu=False), 24, 800)
 
 
 @pytest.mark.gpu
 def test_streaming_sequence_on_gpu():
-    run_stream(emu_ffi.build_stream_test(gpu=True), 40, 2500)
+    run_stream(emu_ffi.build_stream_test(gpu=True), 80, 2500)
