@@ -1,0 +1,260 @@
+// landmark_selection_voxel.hpp — the two landmark schemes the KITTI launch wires into the selector besides cheirality
+// (SURVEY §8f-2), restated without PCL / Boost.Geometry / Eigen:
+//
+//   LandmarkSparsificationSchemeVoxel   internal/landmark_selection_scheme_voxel.hpp:22-60,
+//                                       src/landmark_selection_scheme_voxel.cpp:116-233: landmarks in the frame of the
+//                                       newest keyframe -> plausibility cut in z -> split by distance to the driven
+//                                       path (far / middle / near "pipes") -> voxel-grid thinning of everything inside
+//                                       the far pipe -> per field a budget: near = largest image flow, middle = random,
+//                                       far = longest tracks.
+//   landmark_helpers::*                 src/landmark_selection_scheme_helpers.cpp:14-135
+//   LandmarkSelectionSchemeAddDepth     internal/landmark_selection_scheme_add_depth.hpp:24-64,
+//                                       src/landmark_selection_scheme_add_depth.cpp:16-76: per configured keyframe,
+//                                       force in the N landmarks that pass a predicate and sort lowest by a key
+//                                       (e.g. the 20 nearest landmarks with measured depth).
+//
+// Where this restatement decides something the reference leaves to its libraries (documented, not hidden):
+//   * voxel thinning: pcl::VoxelGrid emits one CENTROID per occupied voxel and averages the label field with it, so the
+//     id the reference maps back is the average of the ids in the voxel; here the representative of a voxel is the
+//     landmark closest to the voxel's centroid;
+//   * "random" middle-field choice: std::random_shuffle with the global C RNG there, a seeded std::mt19937 here;
+//   * ties in the flow / track-length rankings: unspecified by std::partial_sort_copy there, broken by id here;
+//   * keyframes are visited in time order (the reference sorts shared_ptr addresses, helpers.cpp:211).
+#pragma once
+#include <array>
+#include <functional>
+#include <limits>
+#include <random>
+#include <tuple>
+#include <unordered_map>
+
+#include "landmark_selector.hpp"
+
+namespace keyframe_bundle_adjustment {
+
+namespace landmark_helpers {
+
+// Per landmark: accumulated (or mean) pixel displacement between consecutive keyframes it is seen in, per camera;
+// the largest over its cameras.  Landmarks never seen twice by the same camera get no entry.
+inline std::map<LandmarkId, double> calcFlow(const std::vector<LandmarkId>& ids,
+                                             const std::vector<Keyframe::ConstPtr>& kfs_in_time_order, bool use_mean) {
+    std::map<LandmarkId, double> out;
+    for (const auto& id : ids) {
+        std::map<CameraId, Measurement> last;
+        std::map<CameraId, double> sum;
+        std::map<CameraId, int> cnt;
+        for (const auto& kf : kfs_in_time_order)
+            for (const auto& cm : kf->getMeasurements(id)) {
+                auto it = last.find(cm.first);
+                if (it != last.end()) {
+                    const double du = double(it->second.u) - double(cm.second.u), dv = double(it->second.v) - double(cm.second.v);
+                    sum[cm.first] += std::sqrt(du * du + dv * dv);
+                    cnt[cm.first] += 1;
+                }
+                last[cm.first] = cm.second;
+            }
+        if (sum.empty()) continue;
+        double best = -1.;
+        for (const auto& s : sum) best = std::max(best, use_mean ? s.second / cnt.at(s.first) : s.second);
+        out[id] = best;
+    }
+    return out;
+}
+inline std::map<LandmarkId, double> calcFlow(const std::vector<LandmarkId>& ids,
+                                             const std::map<KeyframeId, Keyframe::ConstPtr>& keyframes, bool use_mean) {
+    std::vector<Keyframe::ConstPtr> kfs;
+    for (const auto& k : keyframes) kfs.push_back(k.second);
+    std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
+    return calcFlow(ids, kfs, use_mean);
+}
+
+inline std::vector<LandmarkId> chooseNearLmIds(size_t max_num, const std::vector<LandmarkId>& near_ids,
+                                               const std::map<LandmarkId, double>& flow) {
+    std::vector<LandmarkId> ids;
+    for (const auto& id : near_ids)
+        if (flow.count(id)) ids.push_back(id);
+    std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) {
+        const double fa = flow.at(a), fb = flow.at(b);
+        return fa > fb || (fa == fb && a < b);
+    });
+    ids.resize(std::min(max_num, ids.size()));
+    return ids;
+}
+inline std::vector<LandmarkId> chooseMiddleLmIds(size_t max_num, const std::vector<LandmarkId>& middle_ids, uint64_t seed = 0) {
+    std::vector<LandmarkId> a(middle_ids);
+    std::sort(a.begin(), a.end());
+    std::mt19937_64 rng(seed);
+    std::shuffle(a.begin(), a.end(), rng);
+    a.resize(std::min(max_num, a.size()));
+    return a;
+}
+inline std::vector<LandmarkId> chooseFarLmIds(size_t max_num, const std::vector<LandmarkId>& far_ids,
+                                              const std::map<KeyframeId, Keyframe::ConstPtr>& keyframes) {
+    std::map<LandmarkId, unsigned> count;
+    for (const auto& id : far_ids) {
+        count[id] = 0;
+        for (const auto& kf : keyframes)
+            if (kf.second->hasMeasurement(id)) count[id] += 1;
+    }
+    std::vector<LandmarkId> ids(far_ids);
+    std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) {
+        return count.at(a) > count.at(b) || (count.at(a) == count.at(b) && a < b);
+    });
+    ids.resize(std::min(max_num, ids.size()));
+    return ids;
+}
+
+// distance of point p to the polyline through pts (a single point if there is only one)
+inline double distanceToPath(const Vector3d& p, const std::vector<Vector3d>& pts) {
+    if (pts.empty()) return std::numeric_limits<double>::max();
+    if (pts.size() == 1) return (p - pts[0]).norm();
+    double best = std::numeric_limits<double>::max();
+    for (size_t i = 0; i + 1 < pts.size(); ++i) {
+        const Vector3d ab = pts[i + 1] - pts[i], ap = p - pts[i];
+        const double l2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+        double t = l2 > 0. ? (ap[0] * ab[0] + ap[1] * ab[1] + ap[2] * ab[2]) / l2 : 0.;
+        t = std::min(1., std::max(0., t));
+        best = std::min(best, (p - (pts[i] + ab * t)).norm());
+    }
+    return best;
+}
+
+}  // namespace landmark_helpers
+
+class LandmarkSparsificationSchemeVoxel : public LandmarkSparsificationSchemeBase, public LandmarkCategorizatonInterface {
+public:
+    struct Parameters {
+        std::array<double, 3> voxel_size_xyz{{1.0, 1.0, 0.5}};
+        std::array<double, 3> roi_far_xyz{{50., 50., 50.}};     // [0] = radius of the far pipe around the driven path
+        std::array<double, 3> roi_middle_xyz{{25., 25., 25.}};  // [0] = radius of the near pipe
+        unsigned int max_num_landmarks_near{300};
+        unsigned int max_num_landmarks_middle{300};
+        unsigned int max_num_landmarks_far{300};
+    };
+    explicit LandmarkSparsificationSchemeVoxel(Parameters p) : params_(p) {}
+
+    std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        std::set<LandmarkId> out;
+        for (const auto& el : getCategorizedSelection(landmarks, keyframes)) out.insert(el.first);
+        return out;
+    }
+
+    std::map<LandmarkId, Category> getCategorizedSelection(const LandmarkMap& lms, const KeyframeMap& keyframes) const override {
+        std::map<LandmarkId, Category> out;
+        if (keyframes.empty()) return out;
+        const auto newest = std::max_element(keyframes.cbegin(), keyframes.cend(), [](const auto& a, const auto& b) {
+            return a.second->timestamp_ < b.second->timestamp_;
+        });
+        const EigenPose cur = newest->second->getEigenPose();  // newest keyframe <- origin
+        std::vector<Vector3d> path;                            // keyframe positions in the newest keyframe's frame
+        for (const auto& kf : keyframes) path.push_back(cur * kf.second->getEigenPose().inverse().translation());
+
+        struct P {
+            LandmarkId id;
+            Vector3d p;
+            double dist;
+        };
+        std::vector<P> pipe;
+        std::vector<LandmarkId> ids_far;
+        for (const auto& id_lm : lms) {
+            const Vector3d p = cur * Vector3d(id_lm.second->pos.data());
+            if (!(p[2] >= -20. && p[2] <= 100.)) continue;  // plausibility cut (voxel.cpp:150-155)
+            const double d = landmark_helpers::distanceToPath(p, path);
+            if (d < params_.roi_far_xyz[0])
+                pipe.push_back({id_lm.first, p, d});
+            else
+                ids_far.push_back(id_lm.first);
+        }
+        // voxel grid over the pipe: one representative per occupied voxel
+        struct Cell {
+            double sx = 0, sy = 0, sz = 0;
+            std::vector<size_t> members;
+        };
+        std::map<std::array<long, 3>, Cell> grid;
+        for (size_t i = 0; i < pipe.size(); ++i) {
+            const std::array<long, 3> key{{(long)std::floor(pipe[i].p[0] / params_.voxel_size_xyz[0]),
+                                           (long)std::floor(pipe[i].p[1] / params_.voxel_size_xyz[1]),
+                                           (long)std::floor(pipe[i].p[2] / params_.voxel_size_xyz[2])}};
+            Cell& c = grid[key];
+            c.sx += pipe[i].p[0];
+            c.sy += pipe[i].p[1];
+            c.sz += pipe[i].p[2];
+            c.members.push_back(i);
+        }
+        std::vector<LandmarkId> ids_near, ids_middle;
+        for (const auto& kc : grid) {
+            const Cell& c = kc.second;
+            const double n = (double)c.members.size();
+            const Vector3d centroid(c.sx / n, c.sy / n, c.sz / n);
+            size_t best = c.members[0];
+            double bd = std::numeric_limits<double>::max();
+            for (size_t i : c.members) {
+                const double d = (pipe[i].p - centroid).norm();
+                if (d < bd || (d == bd && pipe[i].id < pipe[best].id)) {
+                    bd = d;
+                    best = i;
+                }
+            }
+            (pipe[best].dist < params_.roi_middle_xyz[0] ? ids_near : ids_middle).push_back(pipe[best].id);
+        }
+        const auto flow = landmark_helpers::calcFlow(ids_near, keyframes, false);
+        for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, ids_near, flow)) out[id] = Category::NearField;
+        for (const auto& id : landmark_helpers::chooseMiddleLmIds(params_.max_num_landmarks_middle, ids_middle, newest->second->timestamp_))
+            out[id] = Category::MiddleField;
+        for (const auto& id : landmark_helpers::chooseFarLmIds(params_.max_num_landmarks_far, ids_far, keyframes)) out[id] = Category::FarField;
+        return out;
+    }
+
+    static LandmarkSparsificationSchemeBase::ConstPtr createConst(Parameters p) { return std::make_shared<const LandmarkSparsificationSchemeVoxel>(p); }
+    static LandmarkSparsificationSchemeBase::Ptr create(Parameters p) { return std::make_shared<LandmarkSparsificationSchemeVoxel>(p); }
+
+private:
+    Parameters params_;
+};
+
+class LandmarkSelectionSchemeAddDepth : public LandmarkSelectionSchemeBase {
+public:
+    using FrameIndex = int;       // 0 = oldest active keyframe
+    using NumberLandmarks = int;  // how many to force in
+    using Comparator = std::function<bool(const Landmark::ConstPtr&)>;               // which landmarks qualify
+    using Sorter = std::function<float(const Measurement&, const Vector3d& local_lm)>;  // key; the SMALLEST win
+    struct Parameters {
+        std::vector<std::tuple<FrameIndex, NumberLandmarks, Comparator, Sorter>> params_per_keyframe;
+    };
+    explicit LandmarkSelectionSchemeAddDepth(Parameters p) : params_(p) {}
+
+    std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        std::set<LandmarkId> out;
+        std::vector<Keyframe::ConstPtr> kfs;  // active keyframes, oldest first
+        for (const auto& kf : keyframes)
+            if (kf.second->is_active_) kfs.push_back(kf.second);
+        std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
+        for (const auto& el : params_.params_per_keyframe) {
+            const FrameIndex ind = std::get<0>(el);
+            if (ind < 0 || ind > (int)kfs.size() - 1) continue;
+            const Keyframe& kf = *kfs[ind];
+            std::vector<std::pair<LandmarkId, double>> keyed;
+            for (const auto& m : kf.measurements_) {
+                auto it = landmarks.find(m.first);
+                if (it == landmarks.cend() || !std::get<2>(el)(it->second)) continue;
+                const Vector3d local = kf.getEigenPose() * Vector3d(it->second->pos.data());
+                double worst = -std::numeric_limits<double>::max();  // largest key over the cameras that see it
+                for (const auto& cam_meas : m.second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
+                keyed.push_back({m.first, worst});
+            }
+            std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) {
+                return a.second < b.second || (a.second == b.second && a.first < b.first);
+            });
+            const int n = std::min(std::get<1>(el), (int)keyed.size());
+            for (int i = 0; i < n; ++i) out.insert(keyed[i].first);
+        }
+        return out;
+    }
+    static LandmarkSelectionSchemeBase::ConstPtr createConst(Parameters p) { return std::make_shared<const LandmarkSelectionSchemeAddDepth>(p); }
+    static LandmarkSelectionSchemeBase::Ptr create(Parameters p) { return std::make_shared<LandmarkSelectionSchemeAddDepth>(p); }
+
+private:
+    Parameters params_;
+};
+
+}  // namespace keyframe_bundle_adjustment

@@ -16,6 +16,7 @@
 
 #include "../../limo_amd/kba/bundle_adjuster_keyframes.hpp"
 #include "../../limo_amd/kba/keyframe_selector.hpp"
+#include "../../limo_amd/kba/landmark_selection_voxel.hpp"
 
 using namespace keyframe_bundle_adjustment;
 using matches_msg_types::FeaturePoint;
@@ -80,8 +81,69 @@ static void test_keyframe_schemes() {
     CHECK(sel.select({frame(1100000000ull, 0.f, 0.)}, none).size() == 1);   // very first frame
 }
 
+// Unit checks of the voxel / add-depth landmark schemes and their helpers on a hand-made scene.
+static void test_landmark_schemes() {
+    using Cat = LandmarkCategorizatonInterface::Category;
+    // two keyframes 2 m apart along x (identity rotations), one camera looking along +x of the vehicle frame
+    auto cam = std::make_shared<Camera>(500., Vector2d(320., 240.), EigenPose::Identity());
+    std::vector<Vector3d> pts;
+    for (int i = 0; i < 40; ++i) pts.push_back(Vector3d(5.0 + 0.01 * i, 0.5, 1.0));  // 40 points inside ONE 1 x 1 x 0.5 voxel, 5 m from the path
+    pts.push_back(Vector3d(3.0, 30.0, 1.0));    // id 40: 30 m from the path -> middle field (25 <= d < 50)
+    pts.push_back(Vector3d(3.0, 70.0, 1.0));    // id 41: 70 m -> far field
+    pts.push_back(Vector3d(3.0, 0.0, 150.0));   // id 42: z > 100 in the newest frame: implausible, dropped
+    Tracklets t0, t1;
+    t0.stamps = {100};
+    t1.stamps = {200};
+    for (size_t i = 0; i < pts.size(); ++i) {
+        matches_msg_types::Tracklet a, b;
+        a.id = b.id = i;
+        a.feature_points.push_back(FeaturePoint(100.f, 100.f));
+        b.feature_points.push_back(FeaturePoint(100.f + (float)i, 100.f));  // flow grows with the id
+        t0.tracks.push_back(a);
+        if (i != 41) t1.tracks.push_back(b);  // id 41 is seen once only
+    }
+    EigenPose p1 = EigenPose::Identity();
+    p1.translate(Vector3d(-2., 0., 0.));  // keyframe <- origin of a vehicle 2 m further along x
+    std::map<KeyframeId, Keyframe::ConstPtr> kfs{{100, std::make_shared<Keyframe>(100, t0, cam, EigenPose::Identity())},
+                                                 {200, std::make_shared<Keyframe>(200, t1, cam, p1)}};
+    std::map<LandmarkId, Landmark::ConstPtr> lms;
+    for (size_t i = 0; i < pts.size(); ++i) lms[i] = std::make_shared<Landmark>(pts[i], i % 2 == 0);
+    LandmarkSparsificationSchemeVoxel::Parameters vp;
+    LandmarkSparsificationSchemeVoxel voxel(vp);
+    const auto cat = voxel.getCategorizedSelection(lms, kfs);
+    int n_near = 0;
+    for (const auto& c : cat) n_near += c.second == Cat::NearField;
+    CHECK(n_near == 1);                                        // the 40 co-located points collapse to one representative
+    CHECK(cat.count(40) && cat.at(40) == Cat::MiddleField);
+    CHECK(cat.count(41) && cat.at(41) == Cat::FarField);
+    CHECK(!cat.count(42));
+    CHECK(voxel.getSelection(lms, kfs).size() == cat.size());
+    // helpers
+    std::vector<LandmarkId> ids{1, 2, 3, 41};
+    const auto flow = landmark_helpers::calcFlow(ids, kfs, false);
+    CHECK(flow.size() == 3 && !flow.count(41));                // seen once: no flow
+    CHECK(std::fabs(flow.at(3) - 3.0) < 1e-6);
+    const auto near2 = landmark_helpers::chooseNearLmIds(2, ids, flow);
+    CHECK(near2.size() == 2 && near2[0] == 3 && near2[1] == 2);  // largest flow first
+    const auto far1 = landmark_helpers::chooseFarLmIds(1, {41, 5}, kfs);
+    CHECK(far1.size() == 1 && far1[0] == 5);                   // two observations beat one
+    CHECK(landmark_helpers::chooseMiddleLmIds(3, {7, 8, 9, 10, 11}).size() == 3);
+    CHECK(std::fabs(landmark_helpers::distanceToPath(Vector3d(1., 3., 0.), {Vector3d(0., 0., 0.), Vector3d(2., 0., 0.)}) - 3.) < 1e-12);
+    CHECK(std::fabs(landmark_helpers::distanceToPath(Vector3d(5., 4., 0.), {Vector3d(0., 0., 0.), Vector3d(2., 0., 0.)}) - 5.) < 1e-12);
+    // add-depth: in the oldest keyframe force in the 3 landmarks with measured depth that have the smallest id-derived key
+    LandmarkSelectionSchemeAddDepth::Parameters ap;
+    ap.params_per_keyframe.push_back(std::make_tuple(0, 3, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
+                                                     [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
+    ap.params_per_keyframe.push_back(std::make_tuple(7, 3, [](const Landmark::ConstPtr&) { return true; },
+                                                     [](const Measurement&, const Vector3d&) { return 0.f; }));  // no such keyframe
+    LandmarkSelectionSchemeAddDepth add(ap);
+    const auto forced = add.getSelection(lms, kfs);
+    CHECK(forced.size() == 3 && forced.count(0) && forced.count(2) && forced.count(4));  // nearest even ids (has depth)
+}
+
 int main(int argc, char** argv) {
     test_keyframe_schemes();
+    test_landmark_schemes();
     const int n_frames = argc > 1 ? std::atoi(argv[1]) : 24;
     const int n_lm = argc > 2 ? std::atoi(argv[2]) : 1500;
     const int window = 5, history = 10;
@@ -138,6 +200,24 @@ int main(int argc, char** argv) {
     selector.addScheme(KeyframeSelectionSchemePose::createConst(0.1));
     selector.addScheme(KeyframeSparsificationSchemeTime::createConst(0.09e9));
     std::vector<char> is_kf(n_frames, 0);
+    // landmark selection as the KITTI launch wires it (keyframe_ba_monolid.launch:36-38, mono_lidar.cpp:396-430):
+    // voxel sparsification with 200 / 200 / 100 budgets on top of the default cheirality rejection, plus "always keep
+    // the 20 nearest depth landmarks and 20 nearest ground landmarks of the oldest keyframe"
+    {
+        LandmarkSparsificationSchemeVoxel::Parameters vp;
+        vp.max_num_landmarks_near = 200;
+        vp.max_num_landmarks_middle = 200;
+        vp.max_num_landmarks_far = 100;
+        vp.roi_far_xyz = {{40., 40., 40.}};
+        vp.roi_middle_xyz = {{15., 15., 15.}};
+        ba.landmark_selector_->addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
+        LandmarkSelectionSchemeAddDepth::Parameters ap;
+        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
+                                                         [](const Measurement& m, const Vector3d&) { return m.d; }));
+        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
+                                                         [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
+        ba.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
+    }
     std::map<uint64_t, int> frame_of_stamp;
     std::vector<EigenPose> est(n_frames);  // keyframe <- origin estimates as dumped right after each solve
     EigenPose last_motion = EigenPose::Identity();
@@ -201,6 +281,7 @@ int main(int argc, char** argv) {
             CHECK(!summary.empty());
             CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
             CHECK(ba.last_report_.final_cost <= ba.last_report_.initial_cost || ba.last_report_.initial_cost < 0);
+            CHECK(ba.selected_landmark_ids_.size() <= 200 + 200 + 100 + 40);  // the budgets of the voxel scheme + add-depth
         }
         // the node dumps the optimised pose when the frame became a keyframe, its prior otherwise (:281-294)
         est[t] = is_kf[t] ? ba.getKeyframe().getEigenPose() : cur->getEigenPose();
