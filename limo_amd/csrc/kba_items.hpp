@@ -725,6 +725,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
     }
     KBA_SYNC();
+    if (c.pad == 41) return;  // (41-44: profiling aids, early exits after the phases)
     // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe.  Rows are staged through LDS in chunks
     //     (coalesced plane reads), then one lane per (keyframe, entry) adds the rows of ITS keyframe in row order.
     for (int g0 = wd.gp0; g0 < wd.gp0 + wd.n_gp; g0 += kGpChunk) {
@@ -757,6 +758,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
         KBA_SYNC();
     }
+    if (c.pad == 42) return;
     // (3) regulariser rows: one lane evaluates one row into scratch ...
     const int nrows = reg_row_count(wd);
     for (int i = tid; i < nrows; i += nt) {
@@ -773,9 +775,14 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
             for (int i = 0; i < nrows; ++i) {
                 const RegRow& row = rows[i];
                 if (row.n > 0) {
-                    for (int e = tid; e < row.n * row.n; e += nw) {
-                        const int p = e / row.n, q = e % row.n;
-                        H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+                    // <= 16 non-zeros per row: lane = (p offset, q) on a 4 x 16 grid, no integer division
+                    const int q = nw >= 64 ? (tid & 15) : 0, pp = nw >= 64 ? (tid >> 4) : 0, dp = nw >= 64 ? 4 : 1;
+                    for (int p = pp; p < row.n; p += dp) {
+                        if (nw >= 64) {
+                            if (q < row.n) H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
+                        } else {
+                            for (int qq = 0; qq < row.n; ++qq) H[row.col[p] * nc + row.col[qq]] += row.val[p] * row.val[qq];
+                        }
                     }
                     for (int p = tid; p < row.n; p += nw) gc[row.col[p]] += row.val[p] * row.r;
                 }
@@ -784,6 +791,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
         KBA_SYNC();
     }
+    if (c.pad == 43) return;
     // (4) mask constant / absent slots
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
     for (int i = tid; i < nc * nc; i += nt) {
@@ -798,6 +806,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         for (int i = tid; i < nc; i += nt)
             bv.scale_c[wd.cam0 + i] = (cm[i] && c.jacobi_scaling) ? 1.0 / (1.0 + sqrt(H[i * nc + i])) : 1.0;
     }
+    if (c.pad == 44) return;
     // (5) reductions
     double cost = 0.0, failf = 0.0, gmax = 0.0, xn2 = 0.0, reg_free = 0.0, reg_fixed = 0.0;
     for (int b = wd.blk0 + tid; b < wd.blk0 + wd.n_blk; b += nt) {
