@@ -6,6 +6,7 @@
 // against the oracle in the CPU-only test tier (`pytest -m "not gpu"`).  It is NOT part of the product: it is
 // built only into tests/cpp/_build/libkba_emu.so and nothing under limo_amd/ links or loads it.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -288,7 +289,12 @@ struct EmuBatch : Executor {
             if (!bv.st[w].active) continue;
             double red1[1];
             reduce_step(bv, w, 0, 1, red1);
+            const double x_cost_before = bv.st[w].x_cost, radius_before = bv.st[w].radius;
             lm_decide_step(bv.st[w], bv.red[w], c);
+            if (std::getenv("EMU_VERBOSE"))
+                std::fprintf(stderr, "[emu] w%d it %d  x_cost %.12e  cand %.12e  mcc %.6e  step %.3e  radius %.3e  -> accept %d active %d term %d\n", w,
+                             bv.st[w].iter, x_cost_before, bv.red[w].cand_cost, bv.red[w].mcc, std::sqrt(bv.red[w].step2), radius_before,
+                             bv.st[w].accept, bv.st[w].active, bv.st[w].term);
         }
         // accept: candidate -> current
         for (int w = 0; w < bv.n_win; ++w) {
