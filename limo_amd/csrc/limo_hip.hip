@@ -62,14 +62,17 @@ struct limo_ba_batch : Executor {
     int32_t* d_wl_sblk_part = nullptr;                          // Schur worklist of a re-batched active set
     int32_t* d_wl_sblk_full[3] = {nullptr, nullptr, nullptr};   // ... of every window, for spans 1, 2, 4
     int n_wl_sblk_full[3] = {0, 0, 0};
+    int n_wl_sblk_fast_full[3] = {0, 0, 0};  // leading entries that belong to windows of the fast Schur variant
+    int n_wl_sblk_fast = 0;
+    std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
     int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
     std::vector<int32_t> h_wl;
     bool use_wl = false;
     int n_wl_blk = 0, n_wl_lblk = 0, n_wl_sblk = 0, n_wl_win = 0, listed = 0;
     int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0, schur_T = 1;
-    const void* schur_fn = nullptr;
-    bool schur_fast = false;
+    const void *schur_fn_fast = nullptr, *schur_fn_gen = nullptr;  // per-window choice: results do not depend on
+                                                                   // what else is in the batch
 
     static const void* pick_schur(int T, bool fast) {
         if (fast) {
@@ -93,7 +96,7 @@ struct limo_ba_batch : Executor {
     struct RankLists {
         int32_t *full_blk = nullptr, *full_lblk = nullptr, *full_sblk = nullptr;  // every window listed
         int32_t *act_blk = nullptr, *act_lblk = nullptr, *act_sblk = nullptr;     // re-batched active set
-        int n_full_blk = 0, n_full_lblk = 0, n_full_sblk = 0;
+        int n_full_blk = 0, n_full_lblk = 0, n_full_sblk = 0, n_full_sblk_fast = 0, n_sblk_fast = 0;
         const int32_t *blk = nullptr, *lblk = nullptr, *sblk = nullptr;           // lists in use
         int n_blk = 0, n_lblk = 0, n_sblk = 0;
     };
@@ -130,6 +133,19 @@ struct limo_ba_batch : Executor {
 
     int upload() {
         std::memset(&bv, 0, sizeof(bv));
+        win_fast.assign(P.n_win, 1);
+        for (int w = 0; w < P.n_win; ++w) {
+            const WinDesc& d = P.win[w];
+            int nfk = 0;
+            for (int k = 0; k < d.n_kf; ++k) {
+                const int32_t* cs = P.cslot.data() + (size_t)d.cam0 + (size_t)k * kCamSlots;
+                nfk += (cs[0] >= 0 || cs[6] >= 0) ? 1 : 0;
+                int nv = 0;
+                for (int v = 0; v < d.n_view; ++v) nv += P.view_kf[d.view0 + v] == d.kf0 + k;
+                if (nv > 1) win_fast[w] = 0;
+            }
+            if (nfk > 4) win_fast[w] = 0;
+        }
         int status = LIMO_OK;
         for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) {
             if (status != LIMO_OK) return;
@@ -173,7 +189,18 @@ struct limo_ba_batch : Executor {
                 };
                 if (make(P.blk_owner, &rl[i].full_blk, &rl[i].act_blk, &rl[i].n_full_blk)) return LIMO_ERR_RUNTIME;
                 if (make(P.lblk_owner, &rl[i].full_lblk, &rl[i].act_lblk, &rl[i].n_full_lblk)) return LIMO_ERR_RUNTIME;
-                if (make(P.sblk_owner, &rl[i].full_sblk, &rl[i].act_sblk, &rl[i].n_full_sblk)) return LIMO_ERR_RUNTIME;
+                {   // Schur blocks: the fast-variant windows first
+                    std::vector<int32_t> v;
+                    for (int pass = 1; pass >= 0; --pass) {
+                        for (size_t k = 0; k < P.sblk_owner.size(); ++k)
+                            if (P.sblk_owner[k] == r && win_fast[P.sblk_win[k]] == pass) v.push_back((int32_t)k);
+                        if (pass == 1) rl[i].n_full_sblk_fast = (int)v.size();
+                    }
+                    rl[i].n_full_sblk = (int)v.size();
+                    if (dmalloc((void**)&rl[i].full_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
+                    if (dmalloc((void**)&rl[i].act_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
+                    if (!v.empty()) HIP_TRY(ctx, hipMemcpy(rl[i].full_sblk, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+                }
             }
             if (!shard_virtual && dmalloc((void**)&d_lm_tmp, sizeof(double) * 3 * std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
         }
@@ -197,8 +224,14 @@ struct limo_ba_batch : Executor {
         avg_sblk = P.n_win ? (P.n_sblk + P.n_win - 1) / P.n_win : 0;
         for (int k = 0; k < 3; ++k) {  // every window listed, for spans 1, 2, 4
             std::vector<int32_t> v;
-            for (const WinDesc& d : P.win)
-                for (int i = 0; i < d.n_sblk; i += (1 << k)) v.push_back(d.sblk0 + i);
+            for (int pass = 1; pass >= 0; --pass) {
+                for (int w = 0; w < P.n_win; ++w) {
+                    if (win_fast[w] != pass) continue;
+                    const WinDesc& d = P.win[w];
+                    for (int i = 0; i < d.n_sblk; i += (1 << k)) v.push_back(d.sblk0 + i);
+                }
+                if (pass == 1) n_wl_sblk_fast_full[k] = (int)v.size();
+            }
             n_wl_sblk_full[k] = (int)v.size();
             if (dmalloc((void**)&d_wl_sblk_full[k], sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
             if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d_wl_sblk_full[k], v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
@@ -209,21 +242,29 @@ struct limo_ba_batch : Executor {
         int max_nfp = 16;
         for (const WinDesc& d : P.win) max_nfp = std::max(max_nfp, (int)d.nf_pad);
         max_ld_bytes = schur_lds_bytes(max_nfp);
-        schur_T = max_nfp / 16;
-        schur_fast = true;  // k_schur<.., true>: <= 4 keyframes with free slots, one view per keyframe, in every window
-        for (const WinDesc& d : P.win) {
-            int nfk = 0;
-            for (int k = 0; k < d.n_kf; ++k) {
-                const int32_t* cs = P.cslot.data() + (size_t)d.cam0 + (size_t)k * kCamSlots;
-                nfk += (cs[0] >= 0 || cs[6] >= 0) ? 1 : 0;
-                int nv = 0;
-                for (int v = 0; v < d.n_view; ++v) nv += P.view_kf[d.view0 + v] == d.kf0 + k;
-                if (nv > 1) schur_fast = false;
+        {
+            int t_fast = 1, t_gen = 1;
+            bool any_fast = false, any_gen = false;
+            for (int w = 0; w < P.n_win; ++w) {
+                const int t = P.win[w].nf_pad / 16;
+                if (win_fast[w]) {
+                    any_fast = true;
+                    t_fast = std::max(t_fast, t);
+                } else {
+                    any_gen = true;
+                    t_gen = std::max(t_gen, t);
+                }
             }
-            if (nfk > 4) schur_fast = false;
+            schur_T = std::max(t_fast, t_gen);
+            if (any_fast) {
+                schur_fn_fast = pick_schur(t_fast, true);
+                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_fast, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
+            }
+            if (any_gen) {
+                schur_fn_gen = pick_schur(t_gen, false);
+                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_gen, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
+            }
         }
-        schur_fn = pick_schur(schur_T, schur_fast);
-        HIP_TRY(ctx, hipFuncSetAttribute(schur_fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
         asm_bytes = cam_assemble_scratch(max_nc, kBlock) * (int)sizeof(double);
         solve_bytes = cam_solve_scratch(max_nc, kBlock) * (int)sizeof(double);
         int max_lm = 1;
@@ -282,6 +323,7 @@ struct limo_ba_batch : Executor {
     int count_blk(size_t i) const { return shard_P > 1 ? rl[i].n_blk : n_wl_blk; }
     int count_lblk(size_t i) const { return shard_P > 1 ? rl[i].n_lblk : n_wl_lblk; }
     int count_sblk(size_t i) const { return shard_P > 1 ? rl[i].n_sblk : n_wl_sblk; }
+    int count_sblk_fast(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_fast : n_wl_sblk_fast; }
     int shard_of(size_t i) const { return shard_P > 1 ? local_shards[i] : 0; }
 
     // Exchange step: sum the shards' partial arrays of `point` into the consumer view.
@@ -322,7 +364,9 @@ struct limo_ba_batch : Executor {
         const int k = c.schur_span == 4 ? 2 : c.schur_span == 2 ? 1 : 0;
         d_wl_sblk = d_wl_sblk_full[k];
         n_wl_sblk = n_wl_sblk_full[k];
+        n_wl_sblk_fast = n_wl_sblk_fast_full[k];
         for (RankLists& r : rl) {
+            r.n_sblk_fast = r.n_full_sblk_fast;
             r.blk = r.full_blk;
             r.lblk = r.full_lblk;
             r.sblk = r.full_sblk;
@@ -348,9 +392,13 @@ struct limo_ba_batch : Executor {
             for (int i = 0; i < d.n_lblk; ++i) wlb.push_back(d.lblk0 + i);
         }
         set_span((int)ww.size());
-        for (int w : ww) {
-            const WinDesc& d = P.win[w];
-            for (int i = 0; i < d.n_sblk; i += c.schur_span) wsb.push_back(d.sblk0 + i);
+        for (int pass = 1; pass >= 0; --pass) {
+            for (int w : ww) {
+                if (win_fast[w] != pass) continue;
+                const WinDesc& d = P.win[w];
+                for (int i = 0; i < d.n_sblk; i += c.schur_span) wsb.push_back(d.sblk0 + i);
+            }
+            if (pass == 1) n_wl_sblk_fast = (int)wsb.size();
         }
         auto up = [&](int32_t* dst, const std::vector<int32_t>& v) {
             if (!v.empty()) note(hipMemcpyAsync(dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s), "upload worklist");
@@ -370,8 +418,15 @@ struct limo_ba_batch : Executor {
                     if (P.blk_owner[k] == r) b1.push_back(k);
                 for (int k = d.lblk0; k < d.lblk0 + d.n_lblk; ++k)
                     if (P.lblk_owner[k] == r) b2.push_back(k);
-                for (int k = d.sblk0; k < d.sblk0 + d.n_sblk; ++k)
-                    if (P.sblk_owner[k] == r) b3.push_back(k);
+            }
+            for (int pass = 1; pass >= 0; --pass) {
+                for (int w : ww) {
+                    if (win_fast[w] != pass) continue;
+                    const WinDesc& d = P.win[w];
+                    for (int k = d.sblk0; k < d.sblk0 + d.n_sblk; ++k)
+                        if (P.sblk_owner[k] == r) b3.push_back(k);
+                }
+                if (pass == 1) rl[i].n_sblk_fast = (int)b3.size();
             }
             up(rl[i].act_blk, b1);
             up(rl[i].act_lblk, b2);
@@ -482,14 +537,22 @@ struct limo_ba_batch : Executor {
             }
         {
             EventPair* ep = timed(LIMO_KERNEL_SCHUR);
-            for (size_t i = 0; i < pv.size(); ++i)
-                if (count_sblk(i)) {
+            for (size_t i = 0; i < pv.size(); ++i) {
+                const int n_fast = count_sblk_fast(i), n_gen = count_sblk(i) - n_fast;
+                int span = c.schur_span, dbg = c.pad;
+                if (n_fast) {
                     const int32_t* wlp = list_sblk(i);
-                    int span = c.schur_span, dbg = c.pad;
                     void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
-                    note(hipLaunchKernel(schur_fn, dim3(count_sblk(i)), dim3(64), args, max_ld_bytes, s), "launch k_schur");
+                    note(hipLaunchKernel(schur_fn_fast, dim3(n_fast), dim3(64), args, max_ld_bytes, s), "launch k_schur");
                     LAUNCH_CHECK("k_schur");
                 }
+                if (n_gen) {
+                    const int32_t* wlp = list_sblk(i) + n_fast;
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
+                    note(hipLaunchKernel(schur_fn_gen, dim3(n_gen), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
+                    LAUNCH_CHECK("k_schur");
+                }
+            }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
         if (shard_P > 1 && n_wl_win) {

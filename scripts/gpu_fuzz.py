@@ -42,7 +42,7 @@ b.download()
 nb = 0
 for i, (ws_, wb) in enumerate(zip(singles, b.windows)):
     d = np.abs(ws_.kf_pose - wb.kf_pose).max()
-    if d > 1e-6:  # the batch may run other kernel variants (generic Schur path) than the single solve: rounding only
+    if d > 0.0:  # kernel variants are chosen per window: a batch reproduces the single solve bit for bit
         nb += 1
         print("BATCH != SINGLE", i, kws[i], d, flush=True)
 print("fuzz: %d windows, %d oracle mismatches (worst rel cost %.2e, rel pose %.2e), %d batch/single differences" % (N, bad, worst_c, worst_p, nb))
