@@ -13,7 +13,9 @@
 //                                                  LDS + nearest local maximum, D4: largest-triangle search as a wave
 //                                                  reduction over point pairs, plane, ray intersection, D5: gates;
 //                                                  D6b: ground features use the inverse-distance weighted patch
-//   k_band / k_ransac_count / k_ransac_pick / k_refine_*   D6a: RANSAC ground plane (one workgroup per hypothesis)
+//   k_band_* / k_ransac_* / k_refine_*   D6a: RANSAC ground plane: order-preserving compaction of the z band, one lane
+//                                        per hypothesis plane, inlier counts over (hypothesis group, return chunk)
+//                                        workgroups with integer atomics, two-level deterministic refinement sums
 // algorithmic bytes: 16 B read per return + 48 B written per visible return (u,v,x,y,z as fp64 + index);
 // per feature 8 B + ~10 neighbours x 48 B + 4 B out.
 #include <hip/hip_runtime.h>
@@ -47,6 +49,9 @@ struct DepthView {
     int* cell_pts;       // [cells*kCellCap]
     // ground plane
     int* band_idx;       // compacted indices of returns inside the z band, in index order
+    double *bx, *by, *bz;  // camera-frame coordinates of the band returns (same order)
+    int* band_blk;       // [blocks of 256 returns] in-band count per block, then its exclusive prefix
+    double* ref_part;    // [chunks of 1024 band returns][6] partial sums of the refinement passes
     int* band_n;         // [1]
     int* hyp_count;      // [n_hyp]
     double* hyp_plane;   // [n_hyp*4]
@@ -96,30 +101,58 @@ __global__ __launch_bounds__(256) void k_project(DepthView d) {
 }
 
 // ------------------------------------------------------------------------------------------ D6a ground plane
-// deterministic compaction of the returns with lidar z inside [min_z, max_z] (single workgroup, index order)
-__global__ __launch_bounds__(1024) void k_band(DepthView d) {
-    __shared__ int counts[1024];
-    const int chunk = (d.n_pts + 1023) / 1024;
-    const int lo = threadIdx.x * chunk, hi = min(d.n_pts, lo + chunk);
+// Order-preserving compaction of the returns with lidar z inside [min_z, max_z], three coalesced passes:
+// per-block counts -> exclusive prefix over the blocks -> write (index + camera-frame coordinates).
+__device__ __forceinline__ bool in_band(const DepthView& d, int i) {
+    const double z = d.cloud[4 * (size_t)i + 2];
+    return z >= d.p.ransac_plane_min_z && z <= d.p.ransac_plane_max_z;
+}
+__global__ __launch_bounds__(256) void k_band_count(DepthView d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int flag = (i < d.n_pts) && in_band(d, i);
+    const int n = __syncthreads_count(flag);
+    if (threadIdx.x == 0) d.band_blk[blockIdx.x] = n;
+}
+__global__ __launch_bounds__(1024) void k_band_scan(DepthView d, int n_blk) {
+    __shared__ int part[1024];
+    const int chunk = (n_blk + 1023) / 1024;
+    const int lo = threadIdx.x * chunk, hi = min(n_blk, lo + chunk);
     int c = 0;
-    for (int i = lo; i < hi; ++i) {
-        const double z = d.cloud[4 * (size_t)i + 2];
-        c += (z >= d.p.ransac_plane_min_z && z <= d.p.ransac_plane_max_z);
-    }
-    counts[threadIdx.x] = c;
+    for (int b = lo; b < hi; ++b) c += d.band_blk[b];
+    part[threadIdx.x] = c;
     __syncthreads();
-    for (int s = 1; s < 1024; s <<= 1) {  // inclusive scan
-        int v = threadIdx.x >= s ? counts[threadIdx.x - s] : 0;
+    for (int st = 1; st < 1024; st <<= 1) {  // inclusive scan of the per-lane sums
+        const int v = (int)threadIdx.x >= st ? part[threadIdx.x - st] : 0;
         __syncthreads();
-        counts[threadIdx.x] += v;
+        part[threadIdx.x] += v;
         __syncthreads();
     }
-    int pos = counts[threadIdx.x] - c;
-    for (int i = lo; i < hi; ++i) {
-        const double z = d.cloud[4 * (size_t)i + 2];
-        if (z >= d.p.ransac_plane_min_z && z <= d.p.ransac_plane_max_z) d.band_idx[pos++] = i;
+    int run = part[threadIdx.x] - c;
+    for (int b = lo; b < hi; ++b) {
+        const int n = d.band_blk[b];
+        d.band_blk[b] = run;
+        run += n;
     }
-    if (threadIdx.x == 1023) *d.band_n = counts[1023];
+    if (threadIdx.x == 1023) *d.band_n = part[1023];
+}
+__global__ __launch_bounds__(256) void k_band_write(DepthView d) {
+    __shared__ int wave_off[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool flag = (i < d.n_pts) && in_band(d, i);
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_off[wave] = __popcll(m);
+    __syncthreads();
+    int off = d.band_blk[blockIdx.x];
+    for (int k = 0; k < wave; ++k) off += wave_off[k];
+    if (flag) {
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        const double x = d.cloud[4 * (size_t)i], y = d.cloud[4 * (size_t)i + 1], z = d.cloud[4 * (size_t)i + 2];
+        d.band_idx[pos] = i;
+        d.bx[pos] = d.R[0] * x + d.R[1] * y + d.R[2] * z + d.t[0];
+        d.by[pos] = d.R[3] * x + d.R[4] * y + d.R[5] * z + d.t[1];
+        d.bz[pos] = d.R[6] * x + d.R[7] * y + d.R[8] * z + d.t[2];
+    }
 }
 
 __device__ __forceinline__ void cam_point(const DepthView& d, int i, double* p) {
@@ -129,52 +162,74 @@ __device__ __forceinline__ void cam_point(const DepthView& d, int i, double* p) 
     p[2] = d.R[6] * x + d.R[7] * y + d.R[8] * z + d.t[2];
 }
 
-// one workgroup per hypothesis: plane through three seeded band returns, inlier count
-__global__ __launch_bounds__(256) void k_ransac_count(DepthView d) {
-    const int it = blockIdx.x;
+// one lane per hypothesis: plane through three seeded band returns (hyp_count = -1 marks a degenerate draw)
+__global__ __launch_bounds__(256) void k_ransac_planes(DepthView d, int n_hyp) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= n_hyp) return;
     const int nb = *d.band_n;
-    __shared__ double pl[4];
-    __shared__ int ok;
-    __shared__ int wsum[4];
-    if (threadIdx.x == 0) {
-        ok = 0;
-        if (nb >= 3) {
-            const uint64_t h = splitmix64(d.p.ransac_seed * 0x100000001B3ull + (uint64_t)it);
-            const size_t i0 = splitmix64(h) % nb, i1 = splitmix64(h + 1) % nb, i2 = splitmix64(h + 2) % nb;
-            if (i0 != i1 && i0 != i2 && i1 != i2) {
-                double a[3], b[3], c[3];
-                cam_point(d, d.band_idx[i0], a);
-                cam_point(d, d.band_idx[i1], b);
-                cam_point(d, d.band_idx[i2], c);
-                const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
-                double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-                const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                if (nn > 1e-9) {
-                    pl[0] = n[0] / nn;
-                    pl[1] = n[1] / nn;
-                    pl[2] = n[2] / nn;
-                    pl[3] = -(pl[0] * a[0] + pl[1] * a[1] + pl[2] * a[2]);
-                    ok = 1;
-                }
+    double pl[4] = {0.0, 0.0, 0.0, 0.0};
+    int ok = 0;
+    if (nb >= 3) {
+        const uint64_t h = splitmix64(d.p.ransac_seed * 0x100000001B3ull + (uint64_t)it);
+        const size_t i0 = splitmix64(h) % nb, i1 = splitmix64(h + 1) % nb, i2 = splitmix64(h + 2) % nb;
+        if (i0 != i1 && i0 != i2 && i1 != i2) {
+            const double a[3] = {d.bx[i0], d.by[i0], d.bz[i0]}, b[3] = {d.bx[i1], d.by[i1], d.bz[i1]}, c[3] = {d.bx[i2], d.by[i2], d.bz[i2]};
+            const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (nn > 1e-9) {
+                pl[0] = n[0] / nn;
+                pl[1] = n[1] / nn;
+                pl[2] = n[2] / nn;
+                pl[3] = -(pl[0] * a[0] + pl[1] * a[1] + pl[2] * a[2]);
+                ok = 1;
             }
         }
     }
-    __syncthreads();
-    int cnt = 0;
-    if (ok) {
-        for (int q = threadIdx.x; q < nb; q += 256) {
-            double p[3];
-            cam_point(d, d.band_idx[q], p);
-            cnt += fabs(pl[0] * p[0] + pl[1] * p[1] + pl[2] * p[2] + pl[3]) < d.p.ransac_plane_distance_treshold;
-        }
+    d.hyp_count[it] = ok ? 0 : -1;
+    for (int k = 0; k < 4; ++k) d.hyp_plane[4 * it + k] = pl[k];
+}
+
+// Inlier counts: workgroup (hypothesis group of kHypPerBlock, chunk of kRansacChunk band returns); every return is
+// loaded once and tested against the group's planes (LDS); integer atomics make the totals order-independent.
+constexpr int kHypPerBlock = 16;
+constexpr int kRansacChunk = 2048;
+__global__ __launch_bounds__(256) void k_ransac_count(DepthView d, int n_hyp) {
+    __shared__ double pl[kHypPerBlock][4];
+    __shared__ int valid[kHypPerBlock];
+    const int h0 = blockIdx.x * kHypPerBlock;
+    const int nb = *d.band_n;
+    const int q0 = blockIdx.y * kRansacChunk;
+    if (q0 >= nb) return;
+    if (threadIdx.x < kHypPerBlock) {
+        const int h = h0 + threadIdx.x;
+        valid[threadIdx.x] = (h < n_hyp) && d.hyp_count[h] >= 0;  // counts only grow from 0, -1 stays -1
+        for (int k = 0; k < 4; ++k) pl[threadIdx.x][k] = h < n_hyp ? d.hyp_plane[4 * h + k] : 0.0;
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        d.hyp_count[it] = ok ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : -1;
-        for (int k = 0; k < 4; ++k) d.hyp_plane[4 * it + k] = ok ? pl[k] : 0.0;
+    int cnt[kHypPerBlock];  // wave-uniform inlier counts (ballot + popcount: no per-lane counters, no shuffles)
+#pragma unroll
+    for (int k = 0; k < kHypPerBlock; ++k) cnt[k] = 0;
+    const double thr = d.p.ransac_plane_distance_treshold;
+    const int q_end = min(nb, q0 + kRansacChunk);
+    for (int qb = q0; qb < q_end; qb += 256) {
+        const int q = qb + threadIdx.x;
+        const bool live = q < q_end;
+        const double x = live ? d.bx[q] : 0.0, y = live ? d.by[q] : 0.0, z = live ? d.bz[q] : 0.0;
+#pragma unroll
+        for (int k = 0; k < kHypPerBlock; ++k)
+            cnt[k] += __popcll(__ballot(live && fabs(pl[k][0] * x + pl[k][1] * y + pl[k][2] * z + pl[k][3]) < thr));
     }
+    __shared__ int bc[kHypPerBlock];
+    if (threadIdx.x < kHypPerBlock) bc[threadIdx.x] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kHypPerBlock; ++k)
+            if (cnt[k]) atomicAdd(&bc[k], cnt[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kHypPerBlock && bc[threadIdx.x] && valid[threadIdx.x]) atomicAdd(&d.hyp_count[h0 + threadIdx.x], bc[threadIdx.x]);
 }
 
 // sequential RANSAC semantics over the pre-computed hypotheses: keep the best so far, stop once the adaptive iteration
@@ -201,20 +256,23 @@ __global__ void k_ransac_pick(DepthView d, int n_hyp) {
         for (int k = 0; k < 4; ++k) d.plane[k] = d.hyp_plane[4 * bi + k];
 }
 
-// least-squares refinement: weighted centroid, then scatter matrix, over the band returns within refinement_treshold
-// of the RANSAC plane.  pass 0: sums (1, x, y, z); pass 1: scatter (6 unique) around the centroid in d.red[0..3].
-__global__ __launch_bounds__(1024) void k_refine_pass(DepthView d, int pass) {
+// least-squares refinement: centroid, then scatter matrix, over the band returns within refinement_treshold of the
+// RANSAC plane.  pass 0: sums (1, x, y, z); pass 1: scatter (6 unique) around the centroid in d.red[0..3].
+// Two levels in a FIXED order (deterministic): a workgroup reduces a chunk of 1024 returns (4 consecutive ones per lane,
+// then a tree), one lane adds the chunk sums in chunk order.
+__global__ __launch_bounds__(256) void k_refine_part(DepthView d, int pass) {
     if (d.plane[4] == 0.0) return;
-    __shared__ double sh[1024];
+    __shared__ double sh[256];
     const int nb = *d.band_n;
+    const int q0 = blockIdx.x * 1024;
+    if (q0 >= nb) return;
     const double pl[4] = {d.plane[0], d.plane[1], d.plane[2], d.plane[3]};
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const double c[3] = {pass ? d.red[1] / d.red[0] : 0.0, pass ? d.red[2] / d.red[0] : 0.0, pass ? d.red[3] / d.red[0] : 0.0};
-    const int chunk = (nb + 1023) / 1024;  // contiguous chunks: the summation order inside a lane is the index order
-    const int lo = threadIdx.x * chunk, hi = min(nb, lo + chunk);
-    for (int q = lo; q < hi; ++q) {
-        double p[3];
-        cam_point(d, d.band_idx[q], p);
+    for (int k = 0; k < 4; ++k) {
+        const int q = q0 + 4 * threadIdx.x + k;
+        if (q >= nb) break;
+        const double p[3] = {d.bx[q], d.by[q], d.bz[q]};
         if (!(fabs(pl[0] * p[0] + pl[1] * p[1] + pl[2] * p[2] + pl[3]) < d.p.ransac_plane_refinement_treshold)) continue;
         if (pass == 0) {
             acc[0] += 1.0;
@@ -235,12 +293,52 @@ __global__ __launch_bounds__(1024) void k_refine_pass(DepthView d, int pass) {
     for (int k = 0; k < nval; ++k) {
         sh[threadIdx.x] = acc[k];
         __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
             __syncthreads();
         }
-        if (threadIdx.x == 0) d.red[(pass ? 4 : 0) + k] = sh[0];
+        if (threadIdx.x == 0) d.ref_part[(size_t)blockIdx.x * 6 + k] = sh[0];
         __syncthreads();
+    }
+}
+__global__ __launch_bounds__(384) void k_refine_sum(DepthView d, int pass) {
+    if (d.plane[4] == 0.0) return;
+    const int nval = pass ? 6 : 4;
+    const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;  // wave v sums value v
+    if (v >= nval) return;
+    const int nb = *d.band_n;
+    const int n_chunk = (nb + 1023) / 1024;
+    double a = 0.0;
+    for (int b = lane; b < n_chunk; b += 64) a += d.ref_part[(size_t)b * 6 + v];  // fixed partition ...
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);          // ... fixed tree
+    if (lane == 0) d.red[(pass ? 4 : 0) + v] = a;
+}
+
+// One Jacobi rotation of the symmetric 3x3 matrix (a00 a01 a02 a11 a12 a22) in the (I,J) plane, eigenvectors in V;
+// indices are compile-time constants so that everything stays in registers.
+template <int I, int J>
+__device__ __forceinline__ void jacobi_rot(double (&a)[3][3], double (&V)[3][3]) {
+    if (a[I][J] == 0.0) return;
+    const double tau = (a[J][J] - a[I][I]) / (2.0 * a[I][J]);
+    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double x = a[k][I], y = a[k][J];
+        a[k][I] = cs * x - sn * y;
+        a[k][J] = sn * x + cs * y;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double x = a[I][k], y = a[J][k];
+        a[I][k] = cs * x - sn * y;
+        a[J][k] = sn * x + cs * y;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double x = V[k][I], y = V[k][J];
+        V[k][I] = cs * x - sn * y;
+        V[k][J] = sn * x + cs * y;
     }
 }
 
@@ -249,35 +347,21 @@ __device__ void smallest_eigvec(const double* C6, double* n) {  // C6 = xx xy xz
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 50; ++sweep) {
         const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off < 1e-300) break;
-        for (int i = 0; i < 2; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                if (a[i][j] == 0.0) continue;
-                const double tau = (a[j][j] - a[i][i]) / (2.0 * a[i][j]);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
-                for (int k = 0; k < 3; ++k) {
-                    const double x = a[k][i], y = a[k][j];
-                    a[k][i] = cs * x - sn * y;
-                    a[k][j] = sn * x + cs * y;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double x = a[i][k], y = a[j][k];
-                    a[i][k] = cs * x - sn * y;
-                    a[j][k] = sn * x + cs * y;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double x = V[k][i], y = V[k][j];
-                    V[k][i] = cs * x - sn * y;
-                    V[k][j] = sn * x + cs * y;
-                }
-            }
+        const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-40 * diag || off < 1e-300) break;  // converged to far below the rounding of the entries
+        jacobi_rot<0, 1>(a, V);
+        jacobi_rot<0, 2>(a, V);
+        jacobi_rot<1, 2>(a, V);
     }
-    int m = 0;
-    if (a[1][1] < a[m][m]) m = 1;
-    if (a[2][2] < a[m][m]) m = 2;
-    const double nn = sqrt(V[0][m] * V[0][m] + V[1][m] * V[1][m] + V[2][m] * V[2][m]);
-    for (int k = 0; k < 3; ++k) n[k] = V[k][m] / nn;
+    const double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2];
+    const int m = (e1 < e0) ? ((e2 < e1) ? 2 : 1) : ((e2 < e0) ? 2 : 0);
+    const double v0 = m == 0 ? V[0][0] : m == 1 ? V[0][1] : V[0][2];
+    const double v1 = m == 0 ? V[1][0] : m == 1 ? V[1][1] : V[1][2];
+    const double v2 = m == 0 ? V[2][0] : m == 1 ? V[2][1] : V[2][2];
+    const double nn = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+    n[0] = v0 / nn;
+    n[1] = v1 / nn;
+    n[2] = v2 / nn;
 }
 
 __global__ void k_refine_finish(DepthView d) {
@@ -573,12 +657,12 @@ struct DepthWs {
     float* cloud = nullptr;
     double *pu = nullptr, *pv = nullptr, *px = nullptr, *py = nullptr, *pz = nullptr;
     uint8_t *vis = nullptr, *feat_ground = nullptr;
-    int *cell_count = nullptr, *cell_pts = nullptr, *band_idx = nullptr, *band_n = nullptr, *hyp_count = nullptr;
-    double *hyp_plane = nullptr, *plane = nullptr, *red = nullptr;
+    int *cell_count = nullptr, *cell_pts = nullptr, *band_idx = nullptr, *band_n = nullptr, *hyp_count = nullptr, *band_blk = nullptr;
+    double *hyp_plane = nullptr, *plane = nullptr, *red = nullptr, *bx = nullptr, *by = nullptr, *bz = nullptr, *ref_part = nullptr;
     float *feat_uv = nullptr, *out = nullptr;
     void release() {
         void* ptrs[] = {cloud, pu, pv, px, py, pz, vis, feat_ground, cell_count, cell_pts, band_idx, band_n, hyp_count,
-                        hyp_plane, plane, red, feat_uv, out};
+                        hyp_plane, plane, red, feat_uv, out, band_blk, bx, by, bz, ref_part};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         *this = DepthWs();
@@ -677,6 +761,11 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
         rc |= grow(ctx, &W.pz, n_pts);
         rc |= grow(ctx, &W.vis, n_pts);
         rc |= grow(ctx, &W.band_idx, n_pts);
+        rc |= grow(ctx, &W.bx, n_pts);
+        rc |= grow(ctx, &W.by, n_pts);
+        rc |= grow(ctx, &W.bz, n_pts);
+        rc |= grow(ctx, &W.band_blk, (n_pts + 255) / 256 + 1);
+        rc |= grow(ctx, &W.ref_part, ((n_pts + 1023) / 1024 + 1) * 6);
         if (rc != LIMO_OK) return LIMO_ERR_RUNTIME;
         W.cap_pts = n_pts;
     }
@@ -727,6 +816,11 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
     d.cell_pts = W.cell_pts;
     d.band_idx = W.band_idx;
     d.band_n = W.band_n;
+    d.bx = W.bx;
+    d.by = W.by;
+    d.bz = W.bz;
+    d.band_blk = W.band_blk;
+    d.ref_part = W.ref_part;
     d.hyp_count = W.hyp_count;
     d.hyp_plane = W.hyp_plane;
     d.plane = W.plane;
@@ -748,12 +842,19 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
     if (n_pts) hipLaunchKernelGGL(k_project, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, s, d);
     if (any_ground && p.do_use_ransac_plane && n_pts) {
         const int n_hyp = std::max(1, p.ransac_plane_max_iterations);
-        hipLaunchKernelGGL(k_band, dim3(1), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(k_ransac_count, dim3(n_hyp), dim3(256), 0, s, d);
+        const int n_blk = (int)((n_pts + 255) / 256), n_chunk_r = (int)((n_pts + kRansacChunk - 1) / kRansacChunk),
+                  n_chunk_f = (int)((n_pts + 1023) / 1024);  // upper bounds: the band size is only known on the device
+        hipLaunchKernelGGL(k_band_count, dim3(n_blk), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_band_scan, dim3(1), dim3(1024), 0, s, d, n_blk);
+        hipLaunchKernelGGL(k_band_write, dim3(n_blk), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_ransac_planes, dim3((n_hyp + 255) / 256), dim3(256), 0, s, d, n_hyp);
+        hipLaunchKernelGGL(k_ransac_count, dim3((n_hyp + kHypPerBlock - 1) / kHypPerBlock, n_chunk_r), dim3(256), 0, s, d, n_hyp);
         hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(64), 0, s, d, n_hyp);
         if (p.ransac_plane_use_refinement) {
-            hipLaunchKernelGGL(k_refine_pass, dim3(1), dim3(1024), 0, s, d, 0);
-            hipLaunchKernelGGL(k_refine_pass, dim3(1), dim3(1024), 0, s, d, 1);
+            for (int pass = 0; pass < 2; ++pass) {
+                hipLaunchKernelGGL(k_refine_part, dim3(n_chunk_f), dim3(256), 0, s, d, pass);
+                hipLaunchKernelGGL(k_refine_sum, dim3(1), dim3(384), 0, s, d, pass);
+            }
         }
         hipLaunchKernelGGL(k_refine_finish, dim3(1), dim3(64), 0, s, d);
     }
