@@ -502,12 +502,35 @@ KBA_HD void rel_translation(const double* pa, const double* pb, double* d, doubl
 // Number of regulariser rows of a window and evaluation of row `idx`.
 // Row order: [scale reg] then per consecutive pair k0: normal diff (3), dist diff (1), motion (1); then per
 // keyframe global normal (3); pose-only: speed prior (3).
+// Entry (row, k) of a row-major 3x3 held in registers, `row` known only at run time: selects instead of an indexed
+// read, which would push the whole matrix into scratch memory.
+KBA_HD double sel_row3(const double* P, int row, int k) { return row == 0 ? P[k] : (row == 1 ? P[3 + k] : P[6 + k]); }
+
 KBA_HD int reg_row_count(const WinDesc& wd) {
     int n = 0;
     if (wd.has_scale_reg) n += 1;
     if (wd.has_gp_reg) n += (wd.n_kf - 1) * 5 + wd.n_kf * 3;
     if (wd.pose_only && wd.speed_w > 0.0) n += 3;
     return n;
+}
+
+// Rows (in the numbering of reg_row_eval below) whose residual involves keyframes ka and kb (kb == ka or ka + 1), in
+// ascending order: f(first row, number of rows, lowest keyframe of those rows) per run of rows.
+template <class F>
+KBA_HD void reg_rows_of_block(const WinDesc& wd, int ka, int kb, F&& f) {
+    int i0 = 0;
+    if (wd.has_scale_reg) {
+        if (kb <= 1) f(0, 1, 0);  // PoseRegularization(pose 1, pose 0)
+        i0 = 1;
+    }
+    if (wd.has_gp_reg) {
+        const int npair = wd.n_kf - 1;
+        if (ka == kb && ka >= 1) f(i0 + (ka - 1) * 5, 5, ka - 1);  // pair (ka - 1, ka)
+        if (ka < npair) f(i0 + ka * 5, 5, ka);                      // pair (ka, ka + 1)
+        if (ka == kb) f(i0 + npair * 5 + ka * 3, 3, ka);            // rows of keyframe ka alone
+        i0 += npair * 5 + wd.n_kf * 3;
+    }
+    if (wd.pose_only && wd.speed_w > 0.0 && kb == 0) f(i0, 3, 0);
 }
 
 // Evaluates row idx at (pose, pdir, pdist) arrays indexed by GLOBAL keyframe.  Columns are LOCAL camera slots.
@@ -555,8 +578,8 @@ KBA_HD void reg_row_eval(const WinDesc& wd, const uint8_t* cmask, const double* 
                     double P1[9], P0[9];
                     unitvec_plus_jac(n1, P1);
                     unitvec_plus_jac(n0, P0);
-                    for (int k = 0; k < 3; ++k) push(k1, 6 + k, sw * P1[sub * 3 + k]);
-                    for (int k = 0; k < 3; ++k) push(k0, 6 + k, -sw * P0[sub * 3 + k]);
+                    for (int k = 0; k < 3; ++k) push(k1, 6 + k, sw * sel_row3(P1, sub, k));
+                    for (int k = 0; k < 3; ++k) push(k0, 6 + k, -sw * sel_row3(P0, sub, k));
                 }
             } else if (sub == 3) {  // GroundPlaneDistanceRegularization(h1, h0), weight 10
                 const double sw = sqrt(10.0);
@@ -609,7 +632,7 @@ KBA_HD void reg_row_eval(const WinDesc& wd, const uint8_t* cmask, const double* 
             if (want_jac) {
                 double P[9];
                 unitvec_plus_jac(n, P);
-                for (int kk = 0; kk < 3; ++kk) push(k, 6 + kk, -sw * P[sub * 3 + kk]);
+                for (int kk = 0; kk < 3; ++kk) push(k, 6 + kk, -sw * sel_row3(P, sub, kk));
             }
             return;
         }
@@ -624,12 +647,13 @@ KBA_HD void reg_row_eval(const WinDesc& wd, const uint8_t* cmask, const double* 
             u[k] = -(wd.speed_Rb[0 + k] * wd.speed_tb[0] + wd.speed_Rb[3 + k] * wd.speed_tb[1] + wd.speed_Rb[6 + k] * wd.speed_tb[2]);
         quat_R(p, R);
         mat3_vec(R, u, Ru);
-        row.r = sw * ((Ru[i] + p[4 + i]) / wd.speed_dt - wd.speed_vel[i]);
+        const double Rui = i == 0 ? Ru[0] : (i == 1 ? Ru[1] : Ru[2]);
+        row.r = sw * ((Rui + p[4 + i]) / wd.speed_dt - wd.speed_vel[i]);
         all_const = !blk_free(0, 0);
         if (want_jac) {
             double M[9];
             rot_tangent_jac(p, u, M);
-            for (int k = 0; k < 3; ++k) push(0, k, sw * M[i * 3 + k] / wd.speed_dt);
+            for (int k = 0; k < 3; ++k) push(0, k, sw * sel_row3(M, i, k) / wd.speed_dt);
             for (int k = 0; k < 3; ++k) push(0, 3 + k, sw * ((i == k) ? 1.0 : 0.0) / wd.speed_dt);
         }
         return;
@@ -681,10 +705,23 @@ KBA_HD double coop_max(double v, int tid, int nt, double* red) {
 
 // scratch doubles needed by cam_assemble / cam_solve for a system of nc slots and nt lanes
 constexpr int kGpChunk = 128;  // ground-plane rows staged in LDS per pass of cam_assemble
-KBA_HD int cam_assemble_scratch(int nc, int nt) {
-    const int rows = (int)((sizeof(RegRow) * kMaxRegRows + 7) / 8);
+// A regulariser row touches at most two neighbouring keyframes: kept dense over their 2 x kCamSlots columns as
+// [r | first keyframe | 20 values] so that the lane owning an entry of H can add the rows in row order.
+constexpr int kRegDense = 2 + 2 * kCamSlots;
+KBA_HD int cam_max_reg_rows(int nc) {  // upper bound of reg_row_count for a window of nc camera slots
+    const int nkf = nc / kCamSlots;
+    return 1 + (nkf > 0 ? (nkf - 1) * 5 + 3 * nkf : 0) + 3;
+}
+// scratch of cam_assemble: H (nc x nc) | regulariser rows, aliased by the ground-plane staging | dense regulariser
+// rows, aliased by the reduction tree of the last phase
+KBA_HD int cam_assemble_union(int nc) {
+    const int rows = (int)((sizeof(RegRow) * cam_max_reg_rows(nc) + 7) / 8);
     const int gp = kGpChunk * 12;
-    return nc * nc + 6 * nt + (rows > gp ? rows : gp);
+    return rows > gp ? rows : gp;
+}
+KBA_HD int cam_assemble_scratch(int nc, int nt) {
+    const int dense = cam_max_reg_rows(nc) * kRegDense;
+    return nc * nc + cam_assemble_union(nc) + (6 * nt > dense ? 6 * nt : dense);
 }
 KBA_HD int cam_solve_scratch(int nc, int nt) {
     return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + 3 * nt;  // A | y | dl | fl | red, sized for nf == nc
@@ -692,14 +729,15 @@ KBA_HD int cam_solve_scratch(int nc, int nt) {
 
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
 // Jacobi scaling of the camera columns, cost / gradient-norm / |x| reductions.
-// scratch: H (nc*nc) | red (nt) | regulariser rows.
+// scratch: see cam_assemble_scratch.
 KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int tid, int nt, double* scratch) {
     const WinDesc& wd = bv.win[w];
     const int nc = wd.nc;
     double* H = scratch;
-    double* red = scratch + nc * nc;
-    RegRow* rows = reinterpret_cast<RegRow*>(red + 6 * nt);
-    double* gps = red + 6 * nt;  // ground-plane staging, reused by the regulariser rows afterwards
+    double* gps = scratch + nc * nc;  // ground-plane staging, reused by the regulariser rows afterwards
+    RegRow* rows = reinterpret_cast<RegRow*>(gps);
+    double* dense = gps + cam_assemble_union(nc);  // dense regulariser rows, reused by the reductions afterwards
+    double* red = dense;
     double* gc = bv.gc + (int64_t)wd.cam0;
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
@@ -759,38 +797,74 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         KBA_SYNC();
     }
     if (c.pad == 42) return;
-    // (3) regulariser rows: one lane evaluates one row into scratch ...
+    // (3) regulariser rows: one lane evaluates one row into scratch and spreads it over the columns of its (at most
+    //     two, neighbouring) keyframes ...
     const int nrows = reg_row_count(wd);
-    for (int i = tid; i < nrows; i += nt) {
+    // Row -> lane: the row kinds differ a lot (pose-pair rows differentiate a relative translation, the others are
+    // a few multiplications), and lanes of one wave that take different kinds run them one after the other.  With a
+    // full workgroup every wave gets one kind: 0 motion rows, 1 normal-difference rows, 2 distance rows (+ the
+    // scale row), 3 the per-keyframe and speed rows.
+    const int reg_base = wd.has_scale_reg ? 1 : 0, reg_npair = wd.has_gp_reg ? wd.n_kf - 1 : 0;
+    for (int i0 = tid; i0 < (nt >= 256 ? nt : nrows); i0 += nt) {
+        int i = i0;
+        if (nt >= 256) {
+            const int wv = tid >> 6, ln = tid & 63;
+            i = -1;
+            if (wv == 0) {
+                if (ln < reg_npair) i = reg_base + ln * 5 + 4;
+            } else if (wv == 1) {
+                if (ln < reg_npair * 3) i = reg_base + (ln / 3) * 5 + ln % 3;
+            } else if (wv == 2) {
+                if (ln < reg_npair)
+                    i = reg_base + ln * 5 + 3;
+                else if (ln == 63 && wd.has_scale_reg)
+                    i = 0;
+            } else if (wv == 3) {
+                if (reg_base + reg_npair * 5 + ln < nrows) i = reg_base + reg_npair * 5 + ln;
+            }
+            if (i < 0) continue;
+        }
         int all_const;
         reg_row_eval(wd, bv.cmask, bv.pose, bv.pdir, bv.pdist, i, true, rows[i], all_const);
         if (all_const) rows[i].n = -1;  // fixed-cost row
+        const RegRow& row = rows[i];
+        double* dd = dense + i * kRegDense;
+        int klo = 1 << 20;
+        for (int p = 0; p < row.n; ++p) klo = row.col[p] / kCamSlots < klo ? row.col[p] / kCamSlots : klo;
+        if (row.n <= 0) klo = -(1 << 20);  // contributes nowhere
+        for (int q = 0; q < 2 * kCamSlots; ++q) dd[2 + q] = 0.0;
+        for (int p = 0; p < row.n; ++p) dd[2 + row.col[p] - klo * kCamSlots] = row.val[p];
+        dd[0] = row.r;
+        dd[1] = (double)klo;
     }
     KBA_SYNC();
-    // ... then rows are added one after another (fixed order), each row's <=16x16 outer product spread over lanes
-    //     (serial in the rows: run by the first wave alone, no workgroup barrier per row)
-    {
-        const int nw = nt < 64 ? nt : 64;
-        if (tid < nw) {
-            for (int i = 0; i < nrows; ++i) {
-                const RegRow& row = rows[i];
-                if (row.n > 0) {
-                    // <= 16 non-zeros per row: lane = (p offset, q) on a 4 x 16 grid, no integer division
-                    const int q = nw >= 64 ? (tid & 15) : 0, pp = nw >= 64 ? (tid >> 4) : 0, dp = nw >= 64 ? 4 : 1;
-                    for (int p = pp; p < row.n; p += dp) {
-                        if (nw >= 64) {
-                            if (q < row.n) H[row.col[p] * nc + row.col[q]] += row.val[p] * row.val[q];
-                        } else {
-                            for (int qq = 0; qq < row.n; ++qq) H[row.col[p] * nc + row.col[qq]] += row.val[p] * row.val[qq];
-                        }
-                    }
-                    for (int p = tid; p < row.n; p += nw) gc[row.col[p]] += row.val[p] * row.r;
-                }
-                KBA_WAVE_SYNC();
-            }
-        }
-        KBA_SYNC();
+    if (c.pad == 45) return;
+    // ... then every entry of the block tridiagonal of H (diagonal blocks, then the blocks (k, k+1) and their mirror
+    //     images) is owned by one lane, which adds the rows' products in row order: no serial pass over the rows,
+    //     same sum per entry for any lane count.
+    for (int e = tid; e < (2 * wd.n_kf - 1) * kCamSlots * kCamSlots; e += nt) {
+        const int blk = e / (kCamSlots * kCamSlots), q = e % (kCamSlots * kCamSlots);
+        const int ka = blk < wd.n_kf ? blk : blk - wd.n_kf, kb = blk < wd.n_kf ? blk : ka + 1;
+        const int a = ka * kCamSlots + q / kCamSlots, b = kb * kCamSlots + q % kCamSlots;
+        double acc = H[a * nc + b];
+        reg_rows_of_block(wd, ka, kb, [&](int lo, int cnt, int base) {
+            const double* da = dense + lo * kRegDense + 2 + a - base * kCamSlots;
+            const double* db = dense + lo * kRegDense + 2 + b - base * kCamSlots;
+            for (int i = 0; i < cnt; ++i) acc += da[i * kRegDense] * db[i * kRegDense];
+        });
+        H[a * nc + b] = acc;
+        if (ka != kb) H[b * nc + a] = acc;
     }
+    for (int a = tid; a < nc; a += nt) {
+        double acc = gc[a];
+        reg_rows_of_block(wd, a / kCamSlots, a / kCamSlots, [&](int lo, int cnt, int base) {
+            const double* da = dense + lo * kRegDense + 2 + a - base * kCamSlots;
+            const double* dr = dense + lo * kRegDense;
+            for (int i = 0; i < cnt; ++i) acc += da[i * kRegDense] * dr[i * kRegDense];
+        });
+        gc[a] = acc;
+    }
+    KBA_SYNC();
     if (c.pad == 43) return;
     // (4) mask constant / absent slots
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
@@ -894,40 +968,55 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     double* dc = bv.delta_c + wd.cam0;
     const int slab = nfp * nfp;
     const int nfq = wd.nfq;
-    (void)flag;
     for (int a = tid; a < nc; a += nt)
         if (cs[a] >= 0) fl[cs[a]] = a;
     KBA_SYNC();
     // ---- assemble [S | rhs]: S = S_c H S_c + D^2 - sum slabs (upper triangle), rhs = S_c g_c - sum slabs
     // partial slabs of the Schur workgroups, or (landmark-sharded solve) the per-shard sums of them
     const double* sp = c.schur_nslab > 0 ? bv.S_red + wd.sred_off : bv.S_part + wd.spart_off;
-    for (int i = tid; i < nf * lda; i += nt) {
-        const int ca = i / lda, cb = i % lda;
-        if (cb < ca) continue;  // lower triangle unused
-        const int a = fl[ca];
-        double s;
-        int64_t off;
-        if (cb < nf) {
-            const int b = fl[cb];
-            s = sc[a] * sc[b] * Hg[a * nc + b];
-            if (ca == cb) s += fmin(fmax(s, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-            off = (int64_t)schur_col(ca, nfq) * nfp + schur_col(cb, nfq);
-        } else {
-            s = sc[a] * bv.gc[wd.cam0 + a];
-            const int za = schur_col(ca, nfq);  // upper-triangle entry (za, nfq) or (nfq, za)
-            off = za < nfq ? (int64_t)za * nfp + nfq : (int64_t)nfq * nfp + za;
+    // Entries of the upper triangle + rhs column, enumerated row by row (row ca: cb = ca..nf) so that every lane gets
+    // the same share; a lane sums up to 4 entries at once, 4 slabs each: 16 independent loads in flight (one window
+    // alone on the GPU is bound by exactly this latency chain).  Per entry the order of the sum stays q mod 4.
+    const int n_need = nf * (nf + 1) / 2 + nf;
+    const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : (wd.n_sblk + c.schur_span - 1) / c.schur_span;
+    for (int i0 = tid; i0 < n_need; i0 += 4 * nt) {
+        double s[4], acc[4][4];
+        int64_t off[4];
+        int dst[4];
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e * nt;
+            dst[e] = -1;
+            off[e] = 0;
+            s[e] = 0.0;
+            for (int r = 0; r < 4; ++r) acc[e][r] = 0.0;
+            if (i >= n_need) continue;
+            // row ca starts at ca * lda - ca (ca - 1) / 2
+            int ca = (int)(((2 * lda + 1) - sqrt((double)((2 * lda + 1) * (2 * lda + 1) - 8 * i))) * 0.5);
+            while (ca > 0 && ca * lda - ca * (ca - 1) / 2 > i) --ca;
+            while ((ca + 1) * lda - (ca + 1) * ca / 2 <= i) ++ca;
+            const int cb = ca + (i - (ca * lda - ca * (ca - 1) / 2));
+            const int a = fl[ca];
+            if (cb < nf) {
+                const int b = fl[cb];
+                double v = sc[a] * sc[b] * Hg[a * nc + b];
+                if (ca == cb) v += fmin(fmax(v, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+                s[e] = v;
+                off[e] = (int64_t)schur_col(ca, nfq) * nfp + schur_col(cb, nfq);
+            } else {
+                s[e] = sc[a] * bv.gc[wd.cam0 + a];
+                const int za = schur_col(ca, nfq);  // upper-triangle entry (za, nfq) or (nfq, za)
+                off[e] = za < nfq ? (int64_t)za * nfp + nfq : (int64_t)nfq * nfp + za;
+            }
+            dst[e] = ca * lda + cb;
         }
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int q = 0;
-        const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : (wd.n_sblk + c.schur_span - 1) / c.schur_span;
-        for (; q + 4 <= n_slab; q += 4) {  // independent loads in flight
-            s0 += sp[(int64_t)q * slab + off];
-            s1 += sp[(int64_t)(q + 1) * slab + off];
-            s2 += sp[(int64_t)(q + 2) * slab + off];
-            s3 += sp[(int64_t)(q + 3) * slab + off];
-        }
-        for (; q < n_slab; ++q) s0 += sp[(int64_t)q * slab + off];
-        A[i] = s - ((s0 + s1) + (s2 + s3));
+        for (; q + 4 <= n_slab; q += 4)
+            for (int e = 0; e < 4; ++e)
+                for (int r = 0; r < 4; ++r) acc[e][r] += sp[(int64_t)(q + r) * slab + off[e]];
+        for (; q < n_slab; ++q)
+            for (int e = 0; e < 4; ++e) acc[e][0] += sp[(int64_t)q * slab + off[e]];
+        for (int e = 0; e < 4; ++e)
+            if (dst[e] >= 0) A[dst[e]] = s[e] - ((acc[e][0] + acc[e][1]) + (acc[e][2] + acc[e][3]));
     }
     KBA_SYNC();
     if (c.pad == 1) return;
@@ -935,6 +1024,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     //      A = U^T U, y = U^-T rhs.  One barrier per pivot: row k is rescaled while step k+1 updates rows > k.
     //      Eigen LLT<Upper> semantics: failure when a pivot is <= 0.
     bool failed = false;
+    (void)flag;
     const int tw = nt >= 16 ? 16 : 1, th = nt / tw, tx = tid % tw, ty = tid / tw;
     for (int k = 0; k < nf; ++k) {
         const double d = A[k * lda + k];

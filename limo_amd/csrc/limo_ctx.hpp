@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
+#include <vector>
 
 struct limo_ctx {
     int device = 0;
@@ -14,4 +16,48 @@ struct limo_ctx {
     void (*depth_ws_free)(void*) = nullptr;
     void* comm = nullptr;                   // ncclComm_t of a landmark-sharded solve (limo_ctx_comm_init), else null
     int comm_rank = 0, comm_world = 1;
+    // Device blocks released by finished batches, kept for the next one (size class = power of two): a single-window
+    // call (limo_ba_solve, limo_ba_adjust_pose_only) would otherwise spend more time in hipMalloc / hipFree than in
+    // its kernels.  At most kPoolPerClass blocks per class are kept; everything is freed with the context.
+    static constexpr int kPoolPerClass = 4;
+    static constexpr size_t kPoolMaxBlock = 32u << 20;  // larger blocks (big batches) go straight to hipMalloc / hipFree
+    std::map<size_t, std::vector<void*>> pool;
+    void* staging = nullptr;                // pinned host staging buffer of small uploads
+    size_t staging_cap = 0;
+
+    static size_t size_class(size_t bytes) {
+        size_t c = 256;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    hipError_t pool_alloc(void** p, size_t bytes) {
+        if (bytes > kPoolMaxBlock) return hipMalloc(p, bytes);
+        const size_t c = size_class(bytes);
+        auto it = pool.find(c);
+        if (it != pool.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            return hipSuccess;
+        }
+        return hipMalloc(p, c);
+    }
+    void pool_free(void* p, size_t bytes) {
+        if (bytes > kPoolMaxBlock) {
+            (void)hipFree(p);
+            return;
+        }
+        auto& v = pool[size_class(bytes)];
+        if ((int)v.size() < kPoolPerClass)
+            v.push_back(p);
+        else
+            (void)hipFree(p);
+    }
+    void pool_release() {
+        for (auto& kv : pool)
+            for (void* p : kv.second) (void)hipFree(p);
+        pool.clear();
+        if (staging) (void)hipHostFree(staging);
+        staging = nullptr;
+        staging_cap = 0;
+    }
 };

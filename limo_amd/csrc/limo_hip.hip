@@ -49,7 +49,7 @@ struct limo_ba_batch : Executor {
     BatchView bv;
     SolveConsts c;
     limo_ba_options opts;
-    std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> allocs;  // device blocks of this batch (returned to the context's pool)
     double *d_plane_rep = nullptr, *d_plane_dep = nullptr;
     double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
     uint8_t* d_lm_state0 = nullptr;
@@ -112,7 +112,7 @@ struct limo_ba_batch : Executor {
     double last_solve_sec = 0.0;
 
     ~limo_ba_batch() override {
-        for (void* p : allocs) (void)hipFree(p);
+        for (auto& a : allocs) ctx->pool_free(a.first, a.second);
         if (h_active) (void)hipHostFree(h_active);
         if (h_flags) (void)hipHostFree(h_flags);
         for (auto& e : ev_pool) {
@@ -126,8 +126,9 @@ struct limo_ba_batch : Executor {
     }
 
     int dmalloc(void** p, size_t bytes) {
-        HIP_TRY(ctx, hipMalloc(p, bytes ? bytes : 8));
-        allocs.push_back(*p);
+        bytes = bytes ? bytes : 8;
+        HIP_TRY(ctx, ctx->pool_alloc(p, bytes));
+        allocs.push_back({*p, bytes});
         return LIMO_OK;
     }
 
@@ -146,22 +147,56 @@ struct limo_ba_batch : Executor {
             }
             if (nfk > 4) win_fast[w] = 0;
         }
+        // Every buffer of the batch view lives in ONE device block: [initialised buffers | zero-filled buffers].
+        // Small batches (a single window) stage the initialised part in pinned host memory and upload it with one
+        // copy; large ones copy buffer by buffer (no second host copy of hundreds of MB).  One memset for the rest.
         int status = LIMO_OK;
-        for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) {
-            if (status != LIMO_OK) return;
-            void* p = nullptr;
-            if (dmalloc(&p, bytes) != LIMO_OK) {
-                status = LIMO_ERR_RUNTIME;
-                return;
+        struct Ent {
+            void** slot;
+            size_t bytes, off;
+            const void* init;
+        };
+        std::vector<Ent> ents;
+        for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) { ents.push_back({slot, bytes ? bytes : 8, 0, init}); });
+        // the pristine copies limo_ba_batch_reset restores from
+        ents.push_back({(void**)&d_pose0, sizeof(double) * 7 * std::max(1, P.TK), 0, P.pose.empty() ? nullptr : P.pose.data()});
+        ents.push_back({(void**)&d_pdir0, sizeof(double) * 3 * std::max(1, P.TK), 0, P.pdir.empty() ? nullptr : P.pdir.data()});
+        ents.push_back({(void**)&d_pdist0, sizeof(double) * std::max(1, P.TK), 0, P.pdist.empty() ? nullptr : P.pdist.data()});
+        ents.push_back({(void**)&d_lm0, sizeof(double) * 3 * std::max(1, P.TL), 0, P.lm.empty() ? nullptr : P.lm.data()});
+        ents.push_back({(void**)&d_lm_state0, (size_t)std::max(1, P.TL), 0, P.lm_state.empty() ? nullptr : P.lm_state.data()});
+        auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t init_total = 0, zero_total = 0;
+        for (Ent& e : ents)
+            if (e.init) {
+                e.off = init_total;
+                init_total += align(e.bytes);
             }
-            hipError_t e = init ? hipMemcpyAsync(p, init, bytes, hipMemcpyHostToDevice, ctx->stream)
-                                : hipMemsetAsync(p, 0, bytes ? bytes : 8, ctx->stream);
-            if (e != hipSuccess) {
-                ctx->err = std::string("upload: ") + hipGetErrorString(e);
-                status = LIMO_ERR_RUNTIME;
+        for (Ent& e : ents)
+            if (!e.init) {
+                e.off = init_total + zero_total;
+                zero_total += align(e.bytes);
             }
-            *slot = p;
-        });
+        char* arena = nullptr;
+        if (dmalloc((void**)&arena, init_total + zero_total)) return LIMO_ERR_RUNTIME;
+        for (Ent& e : ents) *e.slot = arena + e.off;
+        constexpr size_t kStageMax = 16u << 20;
+        if (init_total <= kStageMax) {
+            if (ctx->staging_cap < init_total) {
+                if (ctx->staging) (void)hipHostFree(ctx->staging);
+                ctx->staging = nullptr;
+                ctx->staging_cap = 0;
+                HIP_TRY(ctx, hipHostMalloc(&ctx->staging, std::max<size_t>(init_total, 1u << 20)));
+                ctx->staging_cap = std::max<size_t>(init_total, 1u << 20);
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // an earlier upload may still read the staging buffer
+            for (const Ent& e : ents)
+                if (e.init) std::memcpy(static_cast<char*>(ctx->staging) + e.off, e.init, e.bytes);
+            if (init_total) HIP_TRY(ctx, hipMemcpyAsync(arena, ctx->staging, init_total, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            for (const Ent& e : ents)
+                if (e.init) HIP_TRY(ctx, hipMemcpyAsync(arena + e.off, e.init, e.bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (zero_total) HIP_TRY(ctx, hipMemsetAsync(arena + init_total, 0, zero_total, ctx->stream));
         if (status != LIMO_OK) return status;
         pv.assign(1, bv);
         if (shard_P > 1) {
@@ -206,16 +241,6 @@ struct limo_ba_batch : Executor {
         }
         if (dmalloc((void**)&d_plane_rep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_plane_dep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_pose0, sizeof(double) * 7 * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_pdir0, sizeof(double) * 3 * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_pdist0, sizeof(double) * std::max(1, P.TK))) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_lm0, sizeof(double) * 3 * std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_lm_state0, std::max(1, P.TL))) return LIMO_ERR_RUNTIME;
-        HIP_TRY(ctx, hipMemcpyAsync(d_pose0, P.pose.data(), sizeof(double) * P.pose.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_pdir0, P.pdir.data(), sizeof(double) * P.pdir.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_pdist0, P.pdist.data(), sizeof(double) * P.pdist.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_lm0, P.lm.data(), sizeof(double) * P.lm.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_lm_state0, P.lm_state.data(), P.lm_state.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipHostMalloc((void**)&h_active, 64));
         HIP_TRY(ctx, hipHostMalloc((void**)&h_flags, sizeof(int32_t) * std::max(1, P.n_win)));
         if (dmalloc((void**)&d_wl_blk, sizeof(int32_t) * std::max(1, P.n_blk))) return LIMO_ERR_RUNTIME;
@@ -653,6 +678,7 @@ void limo_ctx_destroy(limo_ctx* ctx) {
     if (!ctx) return;
     if (ctx->depth_ws && ctx->depth_ws_free) ctx->depth_ws_free(ctx->depth_ws);
     if (ctx->comm) (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+    ctx->pool_release();
     if (ctx->own) (void)hipStreamDestroy(ctx->own);
     delete ctx;
 }
