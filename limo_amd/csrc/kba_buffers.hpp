@@ -104,7 +104,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(reg_cost, NW * 2 * D, nullptr);
     KBA_BUF(trim_rep, TL * D, nullptr);
     KBA_BUF(trim_dep, TL * D, nullptr);
-    KBA_BUF(n_active, 4 * I, nullptr);
+    KBA_BUF(n_active, 8 * I, nullptr);
 #undef KBA_BUF
 }
 

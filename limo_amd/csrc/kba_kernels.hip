@@ -454,7 +454,21 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
         if (threadIdx.x == 0) lm_decide_lin(st, bv.red[w], bv.reg_cost[2 * w + 1], c);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && st.active) atomicAdd(bv.n_active, 1);
+    // Count the windows that go on iterating; the workgroup that finishes last publishes the count straight into
+    // pinned host memory (the host polls it one iteration behind) and re-arms the counters - no memset / copy
+    // commands between the kernels of an iteration.
+    if (threadIdx.x == 0) {
+        if (st.active) atomicAdd(bv.n_active, 1);
+        __threadfence();
+        if (atomicAdd(bv.n_active + 1, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int total = atomicAdd(bv.n_active, 0);
+            bv.n_active[0] = 0;
+            bv.n_active[1] = 0;
+            *(volatile int32_t*)bv.n_active_host = total;
+            __threadfence_system();
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {

@@ -171,7 +171,8 @@ struct BatchView {
     double* reg_cost;           // [n_win*2]: free / fixed regulariser cost at the linearisation point
     // --- trimming
     double *trim_rep, *trim_dep;   // [TL] max un-robustified residual norm per landmark, <0 = no block
-    int32_t* n_active;          // [1] counter
+    int32_t* n_active;          // [2] {windows still iterating, workgroups of k_cam_assemble done} of this iteration
+    int32_t* n_active_host;     // pinned host word the last workgroup publishes the count to (not a batch buffer)
 };
 
 }  // namespace kba

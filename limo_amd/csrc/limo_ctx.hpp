@@ -21,7 +21,7 @@ struct limo_ctx {
     // its kernels.  At most kPoolPerClass blocks per class are kept; everything is freed with the context.
     static constexpr int kPoolPerClass = 4;
     static constexpr size_t kPoolMaxBlock = 32u << 20;  // larger blocks (big batches) go straight to hipMalloc / hipFree
-    std::map<size_t, std::vector<void*>> pool;
+    std::map<size_t, std::vector<void*>> pool, host_pool;  // device blocks / pinned host blocks
     void* staging = nullptr;                // pinned host staging buffer of small uploads
     size_t staging_cap = 0;
 
@@ -52,7 +52,27 @@ struct limo_ctx {
         else
             (void)hipFree(p);
     }
+    hipError_t host_alloc(void** p, size_t bytes) {
+        const size_t c = size_class(bytes);
+        auto it = host_pool.find(c);
+        if (it != host_pool.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            return hipSuccess;
+        }
+        return hipHostMalloc(p, c);
+    }
+    void host_free(void* p, size_t bytes) {
+        auto& v = host_pool[size_class(bytes)];
+        if ((int)v.size() < kPoolPerClass && bytes <= kPoolMaxBlock)
+            v.push_back(p);
+        else
+            (void)hipHostFree(p);
+    }
     void pool_release() {
+        for (auto& kv : host_pool)
+            for (void* p : kv.second) (void)hipHostFree(p);
+        host_pool.clear();
         for (auto& kv : pool)
             for (void* p : kv.second) (void)hipFree(p);
         pool.clear();

@@ -53,7 +53,9 @@ struct limo_ba_batch : Executor {
     double *d_plane_rep = nullptr, *d_plane_dep = nullptr;
     double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
     uint8_t* d_lm_state0 = nullptr;
-    int32_t* h_active = nullptr;  // pinned, 4 slots
+    int32_t* h_active = nullptr;  // pinned, 4 slots: written by k_cam_assemble, read by the host one iteration later
+    int32_t* d_h_active = nullptr;  // the same words as the device sees them
+    size_t h_flags_bytes = 0;
     hipEvent_t act_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int it_no = 0;
     // worklists of the windows that still iterate (nullptr = every workgroup): rebuilt on the host whenever the
@@ -113,8 +115,8 @@ struct limo_ba_batch : Executor {
 
     ~limo_ba_batch() override {
         for (auto& a : allocs) ctx->pool_free(a.first, a.second);
-        if (h_active) (void)hipHostFree(h_active);
-        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_active) ctx->host_free(h_active, 64);
+        if (h_flags) ctx->host_free(h_flags, h_flags_bytes);
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -241,8 +243,11 @@ struct limo_ba_batch : Executor {
         }
         if (dmalloc((void**)&d_plane_rep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_plane_dep, sizeof(double) * P.SO)) return LIMO_ERR_RUNTIME;
-        HIP_TRY(ctx, hipHostMalloc((void**)&h_active, 64));
-        HIP_TRY(ctx, hipHostMalloc((void**)&h_flags, sizeof(int32_t) * std::max(1, P.n_win)));
+        HIP_TRY(ctx, ctx->host_alloc((void**)&h_active, 64));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_h_active, h_active, 0));
+        bv.n_active_host = nullptr;
+        h_flags_bytes = sizeof(int32_t) * std::max(1, P.n_win);
+        HIP_TRY(ctx, ctx->host_alloc((void**)&h_flags, h_flags_bytes));
         if (dmalloc((void**)&d_wl_blk, sizeof(int32_t) * std::max(1, P.n_blk))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_wl_lblk, sizeof(int32_t) * std::max(1, P.n_lblk))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_wl_sblk_part, sizeof(int32_t) * std::max(1, P.n_sblk))) return LIMO_ERR_RUNTIME;
@@ -522,12 +527,11 @@ struct limo_ba_batch : Executor {
         allreduce(1);
         // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
         const int slot = it_no & 3;
-        note(hipMemsetAsync(bv.n_active + slot, 0, sizeof(int32_t), s), "memset n_active");
         BatchView bvs = bv;
-        bvs.n_active = bv.n_active + slot;
+        bvs.n_active = bv.n_active + 2 * slot;
+        bvs.n_active_host = d_h_active + slot;
         if (n_wl_win) hipLaunchKernelGGL(k_cam_assemble, dim3(n_wl_win), dim3(kBlock), asm_bytes, s, bvs, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_cam_assemble");
-        note(hipMemcpyAsync(h_active + slot, bv.n_active + slot, sizeof(int32_t), hipMemcpyDeviceToHost, s), "memcpy n_active");
         note(hipEventRecord(act_ev[slot], s), "record n_active");
     }
 
