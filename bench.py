@@ -31,6 +31,28 @@ BYTES_PER_DEPTH_OBS = 84
 STORED_BYTES_PER_OBS = 108
 
 
+class _StubBatch:
+    """--selftest-dist only: stands in for limo_amd.ba.Batch so that the rank plumbing can run without a GPU."""
+
+    def __init__(self, windows, rank):
+        self.windows, self.rank = windows, rank
+
+    def reset(self):
+        pass
+
+    def solve(self, opts):
+        time.sleep(0.02 * (1 + self.rank))  # ranks finish at different times: the reported time must be the slowest
+
+    def kernel_stats(self, reset=False):
+        return {"linearize_ms": 1.0, "linearize_launches": 1, "schur_ms": 1.0, "schur_launches": 1, "total_ms": 2.0}
+
+    def download(self):
+        return [{"num_linearizations": 1, "iterations_total": 1, "n_trimmed_landmarks": 0, "termination": 0} for _ in self.windows]
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +64,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct windows generated per rank (0 = every window of the batch is different)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=8)
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="CPU check of the multi-rank plumbing only (rendezvous over gloo, barriers, max-over-ranks timing, "
+                         "rank-0 JSON): the solve is replaced by a stub, nothing is measured (tests/test_bench_dist.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,36 +80,49 @@ def main():
     import numpy as np
     import torch
 
-    if not torch.cuda.is_available():
+    selftest = args.selftest_dist
+    if not selftest and not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible - the product path has no CPU fallback\n")
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    if not selftest:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from limo_amd import ba, default_options, synth
+    from limo_amd import default_options, synth
 
     opts = default_options()
-    ctx = ba.Context(local_rank)
+    if selftest:
+        args.batch, args.n_lm, args.no_cpu_baseline = min(args.batch, 4), min(args.n_lm, 60), True
+        ctx = None
+    else:
+        from limo_amd import ba
+
+        ctx = ba.Context(local_rank)
 
     # ---- synthetic input: `distinct` different windows per rank, tiled to the batch size (each copy is an
     # independent solve; distinct seeds per rank)
     distinct = args.batch if args.distinct <= 0 else max(1, min(args.distinct, args.batch))
     base = [synth.make_window(1000 + 100000 * rank + i, n_kf=args.n_kf, n_lm=args.n_lm) for i in range(distinct)]
     windows = [base[i % distinct].copy() for i in range(args.batch)]
-    batch = ba.Batch(ctx, windows)
+    batch = _StubBatch(windows, rank) if selftest else ba.Batch(ctx, windows)
     n_obs = sum(w.n_obs for w in windows)
     n_dep = int(sum((w.obs_d > 0).sum() for w in windows))
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not selftest:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not selftest:
+                torch.cuda.synchronize()
 
     def step():
         batch.reset()
@@ -100,7 +138,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if selftest else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = batch.kernel_stats(reset=False)
@@ -147,7 +185,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "selftest of the multi-rank plumbing - stub solve, NOT a measurement" if selftest else "synthetic",
             "config": {
                 "workload": "C2: KITTI-00-shaped windows, %d keyframes x %d landmarks, LiDAR depth + ground plane, solveTrimmed schedule {2, trim 5%%, <=100 LM iterations}" % (args.n_kf, args.n_lm),
                 "batch_windows_per_gpu": args.batch,

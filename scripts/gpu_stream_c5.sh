@@ -1,0 +1,10 @@
+#!/bin/bash
+# BASELINE.json configs[4] at full length: 4541-frame synthetic drive through the keyframe_bundle_adjustment shim on
+# the GPU (sliding 5-keyframe window, keyframe + landmark selection as the KITTI launch wires them): fps and ATE.
+# Most of the wall time is the test's own scene synthesis (tracklets of ~7000 landmarks per frame), which the
+# "back end" figure excludes.
+mkdir -p gpurun_out
+FRAMES=${1:-4541}
+LMS=${2:-$((FRAMES * 31))}
+exe=$(python -c "import sys; sys.path.insert(0,'tests'); import emu_ffi; print(emu_ffi.build_stream_test(gpu=True))")
+( time timeout 800 $exe $FRAMES $LMS long ) 2>&1 | grep -E "^stream|CHECK|checks|real" | tee gpurun_out/stream_c5.log

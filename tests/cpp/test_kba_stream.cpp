@@ -5,6 +5,7 @@
 // (every frame is taken as a keyframe; SURVEY §8f-3's keyframe selection stays on the host and is not the subject).
 // Checks the trajectory against the synthetic ground truth (absolute trajectory error) and the window bookkeeping.
 // Linked against the emulated C-ABI in the CPU test tier and against liblimo_hip.so in the GPU tier.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -146,6 +147,7 @@ int main(int argc, char** argv) {
     test_landmark_schemes();
     const int n_frames = argc > 1 ? std::atoi(argv[1]) : 24;
     const int n_lm = argc > 2 ? std::atoi(argv[2]) : 1500;
+    const bool long_run = argc > 3;  // any third argument: report fps / ATE of a long drive, no accuracy thresholds
     const int window = 5, history = 10;
     // camera <- vehicle (vehicle x forward, y left, z up; camera z forward, x right, y down), KITTI-like intrinsics
     EigenPose cam_veh = EigenPose::Identity();
@@ -165,6 +167,7 @@ int main(int argc, char** argv) {
     std::vector<EigenPose> origin_veh(n_frames);
     {
         EigenPose p = EigenPose::Identity();
+        if (const char* y0 = std::getenv("STREAM_YAW0")) p.rotate(std::atof(y0), Vector3d(0., 0., 1.));  // start heading
         for (int t = 0; t < n_frames; ++t) {
             origin_veh[t] = p;
             p.translate(Vector3d(0.55, 0., 0.));
@@ -174,8 +177,10 @@ int main(int argc, char** argv) {
     // landmarks in the origin frame along the route; 20 % on the ground plane (z = -0.31 under the vehicle origin)
     std::vector<Vector3d> lms(n_lm);
     std::vector<char> on_ground(n_lm);
+    std::vector<int> anchor_of(n_lm);
     for (int i = 0; i < n_lm; ++i) {
         const int anchor = (int)uni(0, n_frames - 1);
+        anchor_of[i] = anchor;
         on_ground[i] = uni(0, 1) < 0.2;
         const Vector3d local(uni(4., 45.), uni(-12., 12.), on_ground[i] ? -0.31 : uni(-0.2, 4.0));
         lms[i] = origin_veh[anchor] * local;
@@ -188,6 +193,14 @@ int main(int argc, char** argv) {
         v = f * pc[1] / z + cy;
         return u >= 0 && u < W && v >= 0 && v < H;
     };
+    // A landmark can only be in view within [-130, +110] frames of its anchor (4..45 m ahead of it, seen from 1..60 m
+    // at 0.55 m per frame): frames look at that slice of the anchor-sorted list instead of at every landmark.
+    std::vector<int> by_anchor(n_lm);
+    for (int i = 0; i < n_lm; ++i) by_anchor[i] = i;
+    std::stable_sort(by_anchor.begin(), by_anchor.end(), [&](int a, int b) { return anchor_of[a] < anchor_of[b]; });
+    std::vector<int> first_with_anchor(n_frames + 1, n_lm);
+    for (int j = n_lm - 1; j >= 0; --j) first_with_anchor[anchor_of[by_anchor[j]]] = j;
+    for (int t = n_frames - 1; t >= 0; --t) first_with_anchor[t] = std::min(first_with_anchor[t], first_with_anchor[t + 1]);
     std::vector<char> has_depth(n_lm);
     for (int i = 0; i < n_lm; ++i) has_depth[i] = uni(0, 1) < 0.45;
 
@@ -210,25 +223,28 @@ int main(int argc, char** argv) {
         vp.max_num_landmarks_far = 100;
         vp.roi_far_xyz = {{40., 40., 40.}};
         vp.roi_middle_xyz = {{15., 15., 15.}};
-        ba.landmark_selector_->addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
+        if (!std::getenv("STREAM_NO_VOXEL")) ba.landmark_selector_->addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
         LandmarkSelectionSchemeAddDepth::Parameters ap;
         ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
                                                          [](const Measurement& m, const Vector3d&) { return m.d; }));
         ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
                                                          [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
-        ba.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
+        if (!std::getenv("STREAM_NO_ADDDEPTH")) ba.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
     }
     std::map<uint64_t, int> frame_of_stamp;
     std::vector<EigenPose> est(n_frames);  // keyframe <- origin estimates as dumped right after each solve
     EigenPose last_motion = EigenPose::Identity();
-    double t_solve = 0.;
+    double t_solve = 0., t_ba = 0.;
     int n_solves = 0;
     for (int t = 0; t < n_frames; ++t) {
         // tracklets of this frame: every landmark visible now, with its history over the consecutive frames it was seen
         Tracklets ts;
         for (int k = 0; k < history && t - k >= 0; ++k) ts.stamps.push_back((uint64_t)(t - k) * 50000000ull + 1000ull);
         frame_of_stamp[ts.stamps[0]] = t;
-        for (int i = 0; i < n_lm; ++i) {
+        const int j_lo = first_with_anchor[std::max(0, t - 130)], j_hi = first_with_anchor[std::min(n_frames, t + 111)];
+        std::vector<int> in_range(by_anchor.begin() + j_lo, by_anchor.begin() + j_hi);
+        std::sort(in_range.begin(), in_range.end());  // tracklets in landmark-id order, as before
+        for (int i : in_range) {
             matches_msg_types::Tracklet tr;
             tr.id = i;
             for (int k = 0; k < (int)ts.stamps.size(); ++k) {
@@ -249,7 +265,7 @@ int main(int argc, char** argv) {
             }
         }
         // motion prior: constant velocity from the last two estimates, perturbed (mono_lidar.cpp:150-185)
-        EigenPose prior = EigenPose::Identity();
+        EigenPose prior = origin_veh[0].inverse();
         if (t == 1) prior = origin_veh[1].inverse();
         if (t >= 2) prior = last_motion * est[t - 1];
         if (t >= 2 && ba.keyframes_.size() < 3) prior = origin_veh[t].inverse();  // bootstrap: no motion-only refinement yet
@@ -257,12 +273,22 @@ int main(int argc, char** argv) {
             prior.translate(Vector3d(gauss(0.05), gauss(0.03), gauss(0.02)));
             prior.rotate(gauss(0.004), Vector3d(0., 0., 1.));
         }
+        {   // The prior is a product of estimated transforms: bring its rotation back onto SO(3).  Without this the
+            // matrix -> quaternion -> matrix round trips of the loop (convert() does not normalise, like the
+            // reference's definitions.cpp:14-28) let |q| drift; the trace <= 0 branch of the conversion amplifies the
+            // drift, so a drive diverges a few frames after its heading passes 90 degrees.
+            Pose q = convert(prior);
+            const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (int i = 0; i < 4; ++i) q[i] /= n;
+            prior = convert(q);
+        }
         Plane gp;
         gp.distance = 0.31;  // height over ground (launch file), normal +z in the vehicle frame
         gp.direction = {{0., 0., 1.}};
+        const auto t_frame0 = std::chrono::steady_clock::now();
         auto cur = std::make_shared<Keyframe>(ts.stamps[0], ts, cam, prior,
                                               t == 0 ? Keyframe::FixationStatus::Pose : Keyframe::FixationStatus::None, gp);
-        if (ba.keyframes_.size() >= 3) {
+        if (ba.keyframes_.size() >= 3 && !std::getenv("STREAM_NO_POSEONLY")) {
             ba.adjustPoseOnly(*cur);
             CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
         }
@@ -285,6 +311,48 @@ int main(int argc, char** argv) {
         }
         // the node dumps the optimised pose when the frame became a keyframe, its prior otherwise (:281-294)
         est[t] = is_kf[t] ? ba.getKeyframe().getEigenPose() : cur->getEigenPose();
+        t_ba += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_frame0).count();
+        if (std::getenv("STREAM_TRACE")) {
+            const Vector3d e = est[t].inverse().translation() - origin_veh[t].translation();
+            std::printf("frame %d kf %d err %.4f m, tracks %zu, term %d, cost %.4g -> %.4g, its %d, selected %zu\n", t, (int)is_kf[t], e.norm(),
+                        ts.tracks.size(), ba.last_report_.termination, ba.last_report_.initial_cost, ba.last_report_.final_cost,
+                        ba.last_report_.iterations_total, ba.selected_landmark_ids_.size());
+            // landmark errors: selected set, and all landmarks with depth / without
+            std::vector<double> es, ed, en;
+            for (const auto& kv : ba.landmarks_) {
+                const auto& L = *kv.second;
+                const Vector3d& g = lms[kv.first];
+                const double e2 = std::sqrt((L.pos[0] - g[0]) * (L.pos[0] - g[0]) + (L.pos[1] - g[1]) * (L.pos[1] - g[1]) + (L.pos[2] - g[2]) * (L.pos[2] - g[2]));
+                if (std::abs(anchor_of[kv.first] - t) > 40) continue;
+                (L.has_measured_depth ? ed : en).push_back(e2);
+                if (ba.selected_landmark_ids_.count(kv.first)) es.push_back(e2);
+            }
+            {
+                const EigenPose D = est[t] * origin_veh[t];  // estimated vehicle <- true vehicle
+                const double ang = std::acos(std::max(-1., std::min(1., (D.R[0] + D.R[4] + D.R[8] - 1.) / 2.)));
+                std::printf("      true vehicle origin in the estimated vehicle frame (fwd, left, up): %.4f %.4f %.4f m, rotation error %.5f rad\n", D.t[0], D.t[1], D.t[2], ang);
+            }
+            {   // reprojection rms of this frame's measurements of the SELECTED landmarks (estimated positions) under the
+                // ground-truth pose and under the estimated pose
+                double s_gt = 0., s_est = 0.;
+                int n = 0;
+                const EigenPose Tg = origin_veh[t].inverse(), Te = est[t];
+                for (const auto& tr : ts.tracks) {
+                    if (!ba.selected_landmark_ids_.count(tr.id) || !ba.landmarks_.count(tr.id)) continue;
+                    const auto& L = *ba.landmarks_.at(tr.id);
+                    const Vector3d P(L.pos[0], L.pos[1], L.pos[2]);
+                    const Vector3d a = cam_veh * (Tg * P), b = cam_veh * (Te * P);
+                    const double ug = f * a[0] / a[2] + cx, vg = f * a[1] / a[2] + cy, ue = f * b[0] / b[2] + cx, ve = f * b[1] / b[2] + cy;
+                    const double mu = tr.feature_points[0].u, mv = tr.feature_points[0].v;
+                    s_gt += (ug - mu) * (ug - mu) + (vg - mv) * (vg - mv);
+                    s_est += (ue - mu) * (ue - mu) + (ve - mv) * (ve - mv);
+                    ++n;
+                }
+                std::printf("      reprojection rms over %d selected tracks: GT pose %.2f px, estimated pose %.2f px\n", n, std::sqrt(s_gt / std::max(1, n)), std::sqrt(s_est / std::max(1, n)));
+            }
+            auto med = [](std::vector<double>& v) { if (v.empty()) return -1.; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            std::printf("      landmark error medians: selected %.3f (n %zu), depth %.3f (n %zu), no depth %.3f (n %zu)\n", med(es), es.size(), med(ed), ed.size(), med(en), en.size());
+        }
         if (t >= 1) last_motion = est[t] * est[t - 1].inverse();
     }
     // absolute trajectory error of the dumped poses (vehicle positions in the origin frame; first pose is fixed = GT)
@@ -301,8 +369,12 @@ int main(int argc, char** argv) {
     CHECK(n_kf_total >= n_frames / 3 && n_kf_total <= (2 * n_frames) / 3 + 1);  // about every second frame
     std::printf("stream: %d frames, %d keyframes, %d landmarks, window %d: ATE rmse %.4f m (max %.4f m) over %.1f m; %d solves, %.1f ms per solve()\n",
                 n_frames, n_kf_total, n_lm, window, ate, worst, path, n_solves, n_solves ? 1e3 * t_solve / n_solves : 0.);
-    CHECK(ate < 0.05);
-    CHECK(worst < 0.12);
+    std::printf("stream: back end (keyframe construction, adjustPoseOnly, selection, push, window cut, solve) %.2f ms per frame -> %.1f frames/s\n",
+                1e3 * t_ba / n_frames, n_frames / t_ba);
+    if (!long_run) {
+        CHECK(ate < 0.05);
+        CHECK(worst < 0.12);
+    }
     CHECK((int)ba.keyframes_.size() == n_kf_total);
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;
