@@ -3,6 +3,7 @@
 // in ONE call (limo_amd/kba push()).  HBM-side this is a 64-byte-per-ray scan; nothing to tile.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 
 #include "landmark_init.hpp"
@@ -32,8 +33,14 @@ __global__ void k_landmark_init(int n, const int32_t* ray_off, const limo_ray* r
         }                                                                        \
     } while (0)
 
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
 }  // namespace
 
+// One pinned staging block carries [ray_off | rays | use_depth] up and [positions | ok] down, one device block holds
+// both: two copies and one kernel per call, all on the context's stream, blocks from the context's pools (a keyframe
+// calls this once; per-buffer hipMallocAsync + copies from pageable memory cost more than the kernel and, with
+// ROCm 7.0, were the one place where a 4541-frame drive was not reproducible from run to run).
 extern "C" int limo_landmark_init(limo_ctx* ctx, int32_t n, const int32_t* ray_off, const limo_ray* rays,
                                   const uint8_t* use_depth, double* pos_out, uint8_t* ok) {
     if (!ctx) return LIMO_ERR_INVALID;  // device work: needs a context (no host fallback)
@@ -43,30 +50,28 @@ extern "C" int limo_landmark_init(limo_ctx* ctx, int32_t n, const int32_t* ray_o
         if (ray_off[i + 1] < ray_off[i]) return LIMO_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
     const size_t n_rays = (size_t)ray_off[n];
+    const size_t b_off = sizeof(int32_t) * (n + 1), b_rays = sizeof(limo_ray) * n_rays, b_use = (size_t)n;
+    const size_t o_rays = align256(b_off), o_use = o_rays + align256(b_rays), in_bytes = o_use + align256(b_use);
+    const size_t b_pos = sizeof(double) * 3 * n, o_ok = align256(b_pos), out_bytes = o_ok + align256((size_t)n);
+    const size_t total = in_bytes + out_bytes;
     int rc = LIMO_OK;
-    int32_t* d_off = nullptr;
-    limo_ray* d_rays = nullptr;
-    uint8_t *d_use = nullptr, *d_ok = nullptr;
-    double* d_pos = nullptr;
+    char *h = nullptr, *d = nullptr;
     hipStream_t s = ctx->stream;
-    LI_TRY(hipMallocAsync((void**)&d_off, sizeof(int32_t) * (n + 1), s));
-    LI_TRY(hipMallocAsync((void**)&d_rays, sizeof(limo_ray) * (n_rays ? n_rays : 1), s));
-    LI_TRY(hipMallocAsync((void**)&d_use, (size_t)n, s));
-    LI_TRY(hipMallocAsync((void**)&d_ok, (size_t)n, s));
-    LI_TRY(hipMallocAsync((void**)&d_pos, sizeof(double) * 3 * n, s));
-    LI_TRY(hipMemcpyAsync(d_off, ray_off, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, s));
-    if (n_rays) LI_TRY(hipMemcpyAsync(d_rays, rays, sizeof(limo_ray) * n_rays, hipMemcpyHostToDevice, s));
-    LI_TRY(hipMemcpyAsync(d_use, use_depth, (size_t)n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_landmark_init, dim3((n + 127) / 128), dim3(128), 0, s, n, d_off, d_rays, d_use, d_pos, d_ok);
+    LI_TRY(ctx->host_alloc((void**)&h, total));
+    LI_TRY(ctx->pool_alloc((void**)&d, total));
+    std::memcpy(h, ray_off, b_off);
+    if (b_rays) std::memcpy(h + o_rays, rays, b_rays);
+    std::memcpy(h + o_use, use_depth, b_use);
+    LI_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_landmark_init, dim3((n + 127) / 128), dim3(128), 0, s, n, (const int32_t*)d, (const limo_ray*)(d + o_rays),
+                       (const uint8_t*)(d + o_use), (double*)(d + in_bytes), (uint8_t*)(d + in_bytes + o_ok));
     LI_TRY(hipGetLastError());
-    LI_TRY(hipMemcpyAsync(pos_out, d_pos, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
-    LI_TRY(hipMemcpyAsync(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost, s));
+    LI_TRY(hipMemcpyAsync(h + in_bytes, d + in_bytes, out_bytes, hipMemcpyDeviceToHost, s));
     LI_TRY(hipStreamSynchronize(s));
+    std::memcpy(pos_out, h + in_bytes, b_pos);
+    std::memcpy(ok, h + in_bytes + o_ok, (size_t)n);
 done:
-    if (d_off) (void)hipFreeAsync(d_off, s);
-    if (d_rays) (void)hipFreeAsync(d_rays, s);
-    if (d_use) (void)hipFreeAsync(d_use, s);
-    if (d_ok) (void)hipFreeAsync(d_ok, s);
-    if (d_pos) (void)hipFreeAsync(d_pos, s);
+    if (h) ctx->host_free(h, total);
+    if (d) ctx->pool_free(d, total);
     return rc;
 }

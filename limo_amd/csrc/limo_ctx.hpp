@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -33,6 +34,8 @@ struct limo_ctx {
     hipError_t pool_alloc(void** p, size_t bytes) {
         if (bytes > kPoolMaxBlock) return hipMalloc(p, bytes);
         const size_t c = size_class(bytes);
+        static const bool no_reuse = std::getenv("KBA_NO_POOL") != nullptr;  // debugging aid
+        if (no_reuse) return hipMalloc(p, c);
         auto it = pool.find(c);
         if (it != pool.end() && !it->second.empty()) {
             *p = it->second.back();
@@ -47,7 +50,8 @@ struct limo_ctx {
             return;
         }
         auto& v = pool[size_class(bytes)];
-        if ((int)v.size() < kPoolPerClass)
+        static const bool no_reuse = std::getenv("KBA_NO_POOL") != nullptr;
+        if ((int)v.size() < kPoolPerClass && !no_reuse)
             v.push_back(p);
         else
             (void)hipFree(p);

@@ -131,6 +131,13 @@ struct limo_ba_batch : Executor {
         bytes = bytes ? bytes : 8;
         HIP_TRY(ctx, ctx->pool_alloc(p, bytes));
         allocs.push_back({*p, bytes});
+        // debugging aid: KBA_POISON=1 fills every block with NaN bytes first, so that a kernel reading a word nobody
+        // wrote shows up as a wrong result instead of depending on what the block held before
+        static const bool poison = std::getenv("KBA_POISON") != nullptr;
+        if (poison) {
+            HIP_TRY(ctx, hipMemsetAsync(*p, 0xFF, bytes, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         return LIMO_OK;
     }
 

@@ -142,11 +142,31 @@ static void test_landmark_schemes() {
     CHECK(forced.size() == 3 && forced.count(0) && forced.count(2) && forced.count(4));  // nearest even ids (has depth)
 }
 
+// Three N(0,1) draws that depend only on `key` (counter-based: splitmix64 + Box-Muller), so a measurement is the same
+// in every tracklet message that repeats it and costs no generator seeding.
+static void hash_normals(uint64_t key, double* out) {
+    auto next = [&key]() {
+        key += 0x9e3779b97f4a7c15ull;
+        uint64_t z = key;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);  // (0, 1)
+    };
+    const double two_pi = 6.283185307179586;
+    const double r0 = std::sqrt(-2.0 * std::log(next())), a0 = two_pi * next();
+    const double r1 = std::sqrt(-2.0 * std::log(next())), a1 = two_pi * next();
+    out[0] = r0 * std::cos(a0);
+    out[1] = r0 * std::sin(a0);
+    out[2] = r1 * std::cos(a1);
+}
+
 int main(int argc, char** argv) {
     test_keyframe_schemes();
     test_landmark_schemes();
     const int n_frames = argc > 1 ? std::atoi(argv[1]) : 24;
     const int n_lm = argc > 2 ? std::atoi(argv[2]) : 1500;
+    if (const char* sd = std::getenv("STREAM_SEED")) rng.seed((uint64_t)std::atoll(sd));  // other scenes than the default one
     const bool long_run = argc > 3;  // any third argument: report fps / ATE of a long drive, no accuracy thresholds
     const int window = 5, history = 10;
     // camera <- vehicle (vehicle x forward, y left, z up; camera z forward, x right, y down), KITTI-like intrinsics
@@ -236,7 +256,8 @@ int main(int argc, char** argv) {
     EigenPose last_motion = EigenPose::Identity();
     double t_solve = 0., t_ba = 0.;
     int n_solves = 0;
-    for (int t = 0; t < n_frames; ++t) {
+    const int t_stop = std::getenv("STREAM_STOP") ? std::atoi(std::getenv("STREAM_STOP")) : n_frames;  // debugging aid
+    for (int t = 0; t < n_frames && t < t_stop; ++t) {
         // tracklets of this frame: every landmark visible now, with its history over the consecutive frames it was seen
         Tracklets ts;
         for (int k = 0; k < history && t - k >= 0; ++k) ts.stamps.push_back((uint64_t)(t - k) * 50000000ull + 1000ull);
@@ -251,11 +272,11 @@ int main(int argc, char** argv) {
                 double u, v, z;
                 if (!project(t - k, i, u, v, z)) break;
                 // deterministic per (frame, landmark) noise so that a measurement is the same in every tracklet message
-                std::mt19937_64 r2((uint64_t)(t - k) * 1000003ull + i);
-                std::normal_distribution<double> n01(0., 1.);
-                u += 0.3 * n01(r2);
-                v += 0.3 * n01(r2);
-                const double d = z + 0.03 * n01(r2);
+                double n3[3];
+                hash_normals((uint64_t)(t - k) * 1000003ull + (uint64_t)i, n3);
+                u += 0.3 * n3[0];
+                v += 0.3 * n3[1];
+                const double d = z + 0.03 * n3[2];
                 tr.feature_points.push_back(has_depth[i] ? FeaturePoint((float)u, (float)v, (float)d) : FeaturePoint((float)u, (float)v));
             }
             if (tr.feature_points.size() >= 1) {
@@ -294,7 +315,21 @@ int main(int argc, char** argv) {
         }
         const auto selected = selector.select({cur}, ba.getActiveKeyframePtrs());
         CHECK(selected.size() < 2);
+        auto count_bad = [&](const char* where) {
+            if (!std::getenv("STREAM_TRACE")) return;
+            int bad = 0;
+            unsigned long first = 0;
+            for (const auto& kv : ba.landmarks_)
+                if (!std::isfinite(kv.second->pos[0]) || !std::isfinite(kv.second->pos[1]) || !std::isfinite(kv.second->pos[2])) {
+                    if (!bad) first = kv.first;
+                    ++bad;
+                }
+            if (bad) std::printf("      [%s, frame %d] %d landmarks with non-finite position, first id %lu (depth %d, ground %d)\n", where, t, bad, first,
+                                 (int)ba.landmarks_.at(first)->has_measured_depth, (int)ba.landmarks_.at(first)->is_ground_plane);
+        };
+        count_bad("before push");
         for (const auto& kf : selected) ba.push(*kf);
+        count_bad("after push");
         is_kf[t] = !selected.empty();
         if (!selected.empty() && ba.keyframes_.size() > 2) {
             ba.deactivateKeyframes(3, 3, window);
@@ -302,6 +337,7 @@ int main(int argc, char** argv) {
             CHECK((int)ba.active_keyframe_ids_.size() <= window);
             const auto t0 = std::chrono::steady_clock::now();
             const std::string summary = ba.solve();
+            count_bad("after solve");
             t_solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             ++n_solves;
             CHECK(!summary.empty());

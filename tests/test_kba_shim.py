@@ -1,5 +1,6 @@
 """The reference's own gtest scenarios (restated in tests/cpp/test_kba_shim.cpp) against the keyframe_bundle_adjustment
 C++ shim (limo_amd/kba): CPU tier links the emulated C-ABI, GPU tier links liblimo_hip.so."""
+import os
 import subprocess
 
 import pytest
@@ -24,20 +25,41 @@ def test_reference_scenarios_on_gpu():
     run(emu_ffi.build_shim_tests(gpu=True))
 
 
-def run_stream(exe, n_frames, n_lm):
-    r = subprocess.run([exe, str(n_frames), str(n_lm)], capture_output=True, text=True, timeout=900)
+def run_stream(exe, n_frames, n_lm, env=None, extra=()):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([exe, str(n_frames), str(n_lm)] + list(extra), capture_output=True, text=True, timeout=900, env=e)
     print(r.stdout[-2000:])
     print(r.stderr[-1000:])
     assert r.returncode == 0, "streaming scenario failed:\n" + r.stdout[-2000:]
     assert " 0 failed" in r.stdout
+    return r.stdout
 
 
 def test_streaming_sequence_with_emulated_backend():
     """BASELINE.json configs[4] in miniature: sliding 5-keyframe window over a synthetic drive, the per-frame call
     order of the reference's node (adjustPoseOnly -> push -> deactivateKeyframes -> solve), ATE against ground truth."""
-    run_stream(emu_ffi.build_stream_test(gpu=False), 24, 800)
+    exe = emu_ffi.build_stream_test(gpu=False)
+    run_stream(exe, 24, 800)
+    # the same drive heading backwards in the origin frame (quaternions of the poses in the trace <= 0 branch of the
+    # matrix -> quaternion conversion): the accuracy thresholds hold for any heading
+    run_stream(exe, 24, 800, env={"STREAM_YAW0": "2.6"})
 
 
 @pytest.mark.gpu
 def test_streaming_sequence_on_gpu():
     run_stream(emu_ffi.build_stream_test(gpu=True), 80, 2500)
+
+
+@pytest.mark.gpu
+def test_long_streaming_sequence_on_gpu_is_reproducible():
+    """600 frames (the heading passes 180 degrees): every call must succeed, the drift stays small, and two runs of the
+    same drive print the same per-frame trace - the device entry points are deterministic and leave nothing behind."""
+    exe = emu_ffi.build_stream_test(gpu=True)
+    outs = [run_stream(exe, 600, 18600, env={"STREAM_TRACE": "1"}, extra=["long"]) for _ in range(2)]
+    frames = [[l for l in o.splitlines() if l.startswith("frame ")] for o in outs]
+    assert len(frames[0]) == 600 and frames[0] == frames[1]
+    summary = [l for l in outs[0].splitlines() if l.startswith("stream: 600 frames")][0]
+    ate = float(summary.split("ATE rmse ")[1].split(" m")[0])
+    assert ate < 0.25, summary
+    assert "non-finite" not in outs[0] and "cost -1" not in outs[0]
