@@ -12,6 +12,11 @@
 //                                       src/landmark_selection_scheme_add_depth.cpp:16-76: per configured keyframe,
 //                                       force in the N landmarks that pass a predicate and sort lowest by a key
 //                                       (e.g. the 20 nearest landmarks with measured depth).
+//   LandmarkSparsificationSchemeObservability   internal/landmark_selection_scheme_observability.hpp:28-88,
+//                                       src/landmark_selection_scheme_observability.cpp:52-170: the same three fields
+//                                       cut by image flow relative to the largest flow instead of by position.
+//   LandmarkRejectionSchemeDimensionPlausibility   internal/landmark_selection_scheme_dimension_plausibility.hpp:20-85:
+//                                       keep the landmarks inside a box in the frame of the newest keyframe.
 //
 // Where this restatement decides something the reference leaves to its libraries (documented, not hidden):
 //   * voxel thinning: pcl::VoxelGrid emits one CENTROID per occupied voxel and averages the label field with it, so the
@@ -255,6 +260,101 @@ public:
 
 private:
     Parameters params_;
+};
+
+// Fields by observability: |mean image flow| relative to the largest flow among the landmarks - at least
+// bound_near_middle of it = near field, at most bound_middle_far = far field, middle in between.  Near and middle prefer
+// landmarks with a measured depth (their budget is filled from those first); near takes the largest flows, middle a
+// random subset, far the longest tracks.
+class LandmarkSparsificationSchemeObservability : public LandmarkSparsificationSchemeBase, public LandmarkCategorizatonInterface {
+public:
+    struct BinParameters {
+        unsigned int max_num_landmarks_near{300}, max_num_landmarks_middle{300}, max_num_landmarks_far{300};
+        double bound_near_middle = 0.4;  // fractions of the largest flow
+        double bound_middle_far = 0.2;
+    };
+    struct Parameters {
+        int histogram_cache_size{500};  // kept for source compatibility; the bounds are fractions, no histogram is built
+        BinParameters bin_params_;
+    };
+    explicit LandmarkSparsificationSchemeObservability(Parameters p) : params_(p) { identifier = "observability"; }
+
+    std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        std::set<LandmarkId> out;
+        for (const auto& el : getCategorizedSelection(landmarks, keyframes)) out.insert(el.first);
+        return out;
+    }
+
+    std::map<LandmarkId, Category> getCategorizedSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        std::map<LandmarkId, Category> out;
+        std::vector<LandmarkId> ids;
+        for (const auto& el : landmarks) ids.push_back(el.first);
+        std::map<LandmarkId, double> flow = landmark_helpers::calcFlow(ids, keyframes, true);
+        if (flow.empty()) return out;
+        double max_flow = 0.;
+        for (auto& el : flow) {
+            el.second = std::abs(el.second);
+            max_flow = std::max(max_flow, el.second);
+        }
+        const BinParameters& b = params_.bin_params_;
+        std::vector<LandmarkId> near_d, near_n, mid_d, mid_n, far;
+        for (const auto& el : landmarks) {
+            const auto it = flow.find(el.first);
+            if (it == flow.end()) continue;  // never seen twice by one camera: no flow (the reference's map_data.at would throw)
+            const bool depth = el.second->has_measured_depth;
+            if (it->second >= b.bound_near_middle * max_flow)
+                (depth ? near_d : near_n).push_back(el.first);
+            else if (it->second > b.bound_middle_far * max_flow)
+                (depth ? mid_d : mid_n).push_back(el.first);
+            else
+                far.push_back(el.first);
+        }
+        std::vector<LandmarkId> near = landmark_helpers::chooseNearLmIds(b.max_num_landmarks_near, near_d, flow);
+        for (const auto& id : landmark_helpers::chooseNearLmIds(b.max_num_landmarks_near - near.size(), near_n, flow)) near.push_back(id);
+        std::vector<LandmarkId> mid = landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle, mid_d);
+        for (const auto& id : landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle - mid.size(), mid_n)) mid.push_back(id);
+        for (const auto& id : near) out[id] = Category::NearField;
+        for (const auto& id : mid) out[id] = Category::MiddleField;
+        for (const auto& id : landmark_helpers::chooseFarLmIds(b.max_num_landmarks_far, far, keyframes)) out[id] = Category::FarField;
+        return out;
+    }
+
+    static ConstPtr createConst(Parameters p) { return ConstPtr(new LandmarkSparsificationSchemeObservability(p)); }
+    static Ptr create(Parameters p) { return Ptr(new LandmarkSparsificationSchemeObservability(p)); }
+
+    Parameters params_;
+};
+
+// Keep the landmarks that lie inside an axis-aligned box in the frame of the NEWEST keyframe (largest id).
+class LandmarkRejectionSchemeDimensionPlausibility : public LandmarkRejectionSchemeBase {
+public:
+    struct Params {
+        // defaults as in the reference: numeric_limits<double>::min() is the smallest POSITIVE double, so an unset lower
+        // bound still demands a positive coordinate
+        double min_x{std::numeric_limits<double>::min()}, max_x{std::numeric_limits<double>::max()};
+        double min_y{std::numeric_limits<double>::min()}, max_y{std::numeric_limits<double>::max()};
+        double min_z{std::numeric_limits<double>::min()}, max_z{std::numeric_limits<double>::max()};
+    };
+    explicit LandmarkRejectionSchemeDimensionPlausibility(const Params& p) : params_(p) { identifier = "dimension plausibility"; }
+
+    std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        std::set<LandmarkId> out;
+        if (keyframes.empty()) return out;
+        const EigenPose T = keyframes.rbegin()->second->getEigenPose();
+        for (const auto& el : landmarks) {
+            const Vector3d p = T * Vector3d(el.second->pos[0], el.second->pos[1], el.second->pos[2]);
+            if (p[0] > params_.min_x && p[0] < params_.max_x && p[1] > params_.min_y && p[1] < params_.max_y && p[2] > params_.min_z &&
+                p[2] < params_.max_z)
+                out.insert(el.first);
+        }
+        return out;
+    }
+
+    static ConstPtr createConst(const Params& p) { return ConstPtr(new LandmarkRejectionSchemeDimensionPlausibility(p)); }
+    static Ptr create(const Params& p) { return Ptr(new LandmarkRejectionSchemeDimensionPlausibility(p)); }
+
+private:
+    Params params_;
 };
 
 }  // namespace keyframe_bundle_adjustment

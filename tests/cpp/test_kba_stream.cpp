@@ -140,6 +140,33 @@ static void test_landmark_schemes() {
     LandmarkSelectionSchemeAddDepth add(ap);
     const auto forced = add.getSelection(lms, kfs);
     CHECK(forced.size() == 3 && forced.count(0) && forced.count(2) && forced.count(4));  // nearest even ids (has depth)
+    // observability: flow of landmark i is i px (41 has none); largest = 42 -> near from 16.8 px, far up to 8.4 px
+    LandmarkSparsificationSchemeObservability::Parameters op;
+    op.bin_params_.max_num_landmarks_near = 4;
+    op.bin_params_.max_num_landmarks_middle = 3;
+    op.bin_params_.max_num_landmarks_far = 2;
+    LandmarkSparsificationSchemeObservability obs(op);
+    const auto ocat = obs.getCategorizedSelection(lms, kfs);
+    int on = 0, om = 0, of = 0;
+    for (const auto& c : ocat) {
+        on += c.second == Cat::NearField;
+        om += c.second == Cat::MiddleField;
+        of += c.second == Cat::FarField;
+        if (c.second == Cat::NearField) CHECK(c.first >= 17);
+        if (c.second == Cat::MiddleField) CHECK(c.first > 8 && c.first < 17);
+        if (c.second == Cat::FarField) CHECK(c.first <= 8);
+    }
+    CHECK(on == 4 && om == 3 && of == 2 && !ocat.count(41));
+    CHECK(ocat.count(42) && ocat.count(40) && ocat.count(38) && ocat.count(36));  // near: largest flows among those WITH depth (even ids) first
+    CHECK(obs.getSelection(lms, kfs).size() == 9);
+    // dimension plausibility: box in the frame of the newest keyframe (2 m further along x)
+    LandmarkRejectionSchemeDimensionPlausibility::Params dp;
+    dp.max_x = 3.2;   // x_new = x - 2: the 40 clustered points sit at 3.0 .. 3.39
+    dp.max_y = 10.;
+    dp.max_z = 100.;
+    LandmarkRejectionSchemeDimensionPlausibility dim(dp);
+    const auto plausible = dim.getSelection(lms, kfs);
+    CHECK(plausible.size() == 20 && plausible.count(0) && plausible.count(19) && !plausible.count(20) && !plausible.count(40) && !plausible.count(42));
 }
 
 // Three N(0,1) draws that depend only on `key` (counter-based: splitmix64 + Box-Muller), so a measurement is the same
