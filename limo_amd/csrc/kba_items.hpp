@@ -14,11 +14,6 @@
 #ifndef KBA_SYNC
 #define KBA_SYNC() ((void)0)
 #endif
-// Ordering point inside ONE wave (serial sections run by the first wave of a workgroup: LDS operations of a wave
-// execute in program order, the fence only keeps the compiler from moving them).  No-op in the serial emulator.
-#ifndef KBA_WAVE_SYNC
-#define KBA_WAVE_SYNC() ((void)0)
-#endif
 
 namespace kba {
 

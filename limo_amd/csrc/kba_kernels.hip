@@ -21,12 +21,6 @@
 #include <hip/hip_runtime.h>
 
 #define KBA_SYNC() __syncthreads()
-#define KBA_WAVE_SYNC()                                      \
-    do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
 #include "kba_items.hpp"
 
 namespace kba {
