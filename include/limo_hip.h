@@ -154,6 +154,9 @@ typedef struct limo_ba_batch limo_ba_batch;
 
 /* --- context ------------------------------------------------------------------------------------ */
 int limo_abi_version(void);
+/* A context = one GPU + one stream + the scratch it reuses between calls.  Not thread-safe: one context per host
+ * thread (several contexts may share a GPU).  Device blocks and pinned staging buffers released by finished calls
+ * (<= 32 MB each, a few per size class) stay with the context for the next call and are freed by limo_ctx_destroy. */
 int limo_ctx_create(int device, limo_ctx** out);
 void limo_ctx_destroy(limo_ctx* ctx);
 /* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own. */
