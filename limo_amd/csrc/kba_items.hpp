@@ -1016,11 +1016,16 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     KBA_SYNC();
     if (c.pad == 1) return;
     // ---- right-looking Cholesky of the upper triangle fused with the forward substitution (rhs = extra column):
-    //      A = U^T U, y = U^-T rhs.  One barrier per pivot: row k is rescaled while step k+1 updates rows > k.
+    //      A = U^T U, y = U^-T rhs.  One barrier per pivot; the rows are divided by sqrt(d_k) in one pass at the end.
     //      Eigen LLT<Upper> semantics: failure when a pivot is <= 0.
+    //      The kernel's time is the slowest wave's path through the pivots (cycle counters: the first wave of a
+    //      workgroup used to own the four longest rows of every trailing update, all of the previous row's sqrt +
+    //      division chain and the diagonal's sqrt behind the barrier: 1830 cycles per pivot against 800 for the
+    //      last wave), so trailing rows go round-robin over the waves and nothing but the update sits between barriers.
     bool failed = false;
     (void)flag;
-    const int tw = nt >= 16 ? 16 : 1, th = nt / tw, tx = tid % tw, ty = tid / tw;
+    const int tw = nt >= 16 ? 16 : 1, th = nt / tw, tx = tid % tw;
+    const int ty = nt == 256 ? ((tid >> 4) & 3) * 4 + (tid >> 6) : tid / tw;  // wave w: rows w, w + 4, w + 8, w + 12 (+16 ...)
     for (int k = 0; k < nf; ++k) {
         const double d = A[k * lda + k];
         if (!(d > 0.0)) {
@@ -1032,12 +1037,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             const double aki = A[k * lda + i] * inv_d;
             for (int j = i + tx; j <= nf; j += tw) A[i * lda + j] -= aki * A[k * lda + j];
         }
-        if (k > 0) {  // finish row k-1: U[k-1][j] = A[k-1][j] / sqrt(d_{k-1})
-            const double dp = sqrt(A[(k - 1) * lda + (k - 1)]);
-            for (int j = k + tid; j <= nf; j += nt) A[(k - 1) * lda + j] /= dp;
-        }
         KBA_SYNC();
-        if (k > 0 && tid == 0) A[(k - 1) * lda + (k - 1)] = sqrt(A[(k - 1) * lda + (k - 1)]);
     }
     if (failed) {
         if (tid == 0) {
@@ -1050,12 +1050,12 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         for (int a = tid; a < nc; a += nt) dc[a] = 0.0;
         return;
     }
-    if (nf > 0) {  // last row
-        const double dp = sqrt(A[(nf - 1) * lda + (nf - 1)]);
-        if (tid == 0) {
-            A[(nf - 1) * lda + nf] /= dp;
-            A[(nf - 1) * lda + (nf - 1)] = dp;
-        }
+    // U[k][j] = A[k][j] / sqrt(d_k), U[k][k] = sqrt(d_k)   (y holds the square roots until the substitution below)
+    for (int k = tid; k < nf; k += nt) y[k] = sqrt(A[k * lda + k]);
+    KBA_SYNC();
+    for (int k = ty; k < nf; k += th) {
+        const double dp = y[k];
+        for (int j = k + tx; j <= nf; j += tw) A[k * lda + j] = j == k ? dp : A[k * lda + j] / dp;
     }
     KBA_SYNC();
     if (c.pad == 2) return;
