@@ -1059,14 +1059,36 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     }
     KBA_SYNC();
     if (c.pad == 2) return;
-    // ---- backward substitution U x = y (y = column nf), column oriented, one barrier per unknown
-    for (int i = tid; i < nf; i += nt) y[i] = A[i * lda + nf];
-    KBA_SYNC();
-    for (int i = nf - 1; i >= 0; --i) {
-        const double xi = y[i] / A[i * lda + i];
-        for (int j = tid; j < i; j += nt) y[j] -= A[j * lda + i] * xi;
+    // ---- backward substitution U x = y (y = column nf), column oriented
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nt >= 64 && nf <= 64) {
+        // gfx950: by the first wave alone, y_j in a register of lane j, x_i broadcast by v_readlane - no barrier and no
+        // LDS round trip on the chain of nf dependent unknowns (same operations per entry as the loop below)
+        if (tid < 64) {
+            const bool mine = tid < nf;
+            double yv = mine ? A[tid * lda + nf] : 0.0;
+            const double diag = mine ? A[tid * lda + tid] : 1.0;
+            for (int i = nf - 1; i >= 0; --i) {
+                const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(yv), i), __builtin_amdgcn_readlane(__double2loint(yv), i)) /
+                                  __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(diag), i), __builtin_amdgcn_readlane(__double2loint(diag), i));
+                if (tid < i)
+                    yv -= A[tid * lda + i] * xi;
+                else if (tid == i)
+                    yv = xi;
+            }
+            if (mine) y[tid] = yv;
+        }
+    } else
+#endif
+    {   // one barrier per unknown
+        for (int i = tid; i < nf; i += nt) y[i] = A[i * lda + nf];
         KBA_SYNC();
-        if (tid == 0) y[i] = xi;
+        for (int i = nf - 1; i >= 0; --i) {
+            const double xi = y[i] / A[i * lda + i];
+            for (int j = tid; j < i; j += nt) y[j] -= A[j * lda + i] * xi;
+            KBA_SYNC();
+            if (tid == 0) y[i] = xi;
+        }
     }
     KBA_SYNC();
     if (c.pad == 3) return;
