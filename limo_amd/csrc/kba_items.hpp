@@ -14,6 +14,19 @@
 #ifndef KBA_SYNC
 #define KBA_SYNC() ((void)0)
 #endif
+// Phase stamps of the window-level items (debug builds of the HIP library with -DKBA_PROFILE_TICKS: the first and the
+// last lane of window 0 record clock64() at every stamp, the kernel wrapper prints the differences).
+#if defined(KBA_PROFILE_TICKS) && defined(__HIPCC__)
+__device__ long long kba_ticks[2][24];
+#endif
+#if defined(KBA_PROFILE_TICKS) && defined(__HIP_DEVICE_COMPILE__)
+#define KBA_TICK(n)                                                                   \
+    do {                                                                              \
+        if (w == 0 && (tid == 0 || tid == nt - 1)) kba_ticks[tid != 0][n] = clock64(); \
+    } while (0)
+#else
+#define KBA_TICK(n) ((void)0)
+#endif
 
 namespace kba {
 
@@ -734,6 +747,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     double* dense = gps + cam_assemble_union(nc);  // dense regulariser rows, reused by the reductions afterwards
     double* red = dense;
     double* gc = bv.gc + (int64_t)wd.cam0;
+    KBA_TICK(0);
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
     KBA_SYNC();
@@ -758,6 +772,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
     }
     KBA_SYNC();
+    KBA_TICK(1);
     if (c.pad == 41) return;  // (41-44: profiling aids, early exits after the phases)
     // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe.  Rows are staged through LDS in chunks
     //     (coalesced plane reads), then one lane per (keyframe, entry) adds the rows of ITS keyframe in row order.
@@ -791,6 +806,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         }
         KBA_SYNC();
     }
+    KBA_TICK(2);
     if (c.pad == 42) return;
     // (3) regulariser rows: one lane evaluates one row into scratch and spreads it over the columns of its (at most
     //     two, neighbouring) keyframes ...
@@ -833,6 +849,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         dd[1] = (double)klo;
     }
     KBA_SYNC();
+    KBA_TICK(3);
     if (c.pad == 45) return;
     // ... then every entry of the block tridiagonal of H (diagonal blocks, then the blocks (k, k+1) and their mirror
     //     images) is owned by one lane, which adds the rows' products in row order: no serial pass over the rows,
@@ -860,6 +877,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         gc[a] = acc;
     }
     KBA_SYNC();
+    KBA_TICK(4);
     if (c.pad == 43) return;
     // (4) mask constant / absent slots
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
@@ -875,6 +893,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         for (int i = tid; i < nc; i += nt)
             bv.scale_c[wd.cam0 + i] = (cm[i] && c.jacobi_scaling) ? 1.0 / (1.0 + sqrt(H[i * nc + i])) : 1.0;
     }
+    KBA_TICK(5);
     if (c.pad == 44) return;
     // (5) reductions
     double cost = 0.0, failf = 0.0, gmax = 0.0, xn2 = 0.0, reg_free = 0.0, reg_fixed = 0.0;
@@ -941,6 +960,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         bv.reg_cost[2 * w] = reg_free;
         bv.reg_cost[2 * w + 1] = reg_fixed;
     }
+    KBA_TICK(6);
 }
 
 // Workgroup-per-window: S = S_c H S_c + D^2 - sum Schur slabs, rhs = S_c g_c - sum slabs; dense Cholesky; camera
@@ -963,6 +983,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     double* dc = bv.delta_c + wd.cam0;
     const int slab = nfp * nfp;
     const int nfq = wd.nfq;
+    KBA_TICK(8);
     for (int a = tid; a < nc; a += nt)
         if (cs[a] >= 0) fl[cs[a]] = a;
     KBA_SYNC();
@@ -1014,6 +1035,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             if (dst[e] >= 0) A[dst[e]] = s[e] - ((acc[e][0] + acc[e][1]) + (acc[e][2] + acc[e][3]));
     }
     KBA_SYNC();
+    KBA_TICK(9);
     if (c.pad == 1) return;
     // ---- right-looking Cholesky of the upper triangle fused with the forward substitution (rhs = extra column):
     //      A = U^T U, y = U^-T rhs.  One barrier per pivot; the rows are divided by sqrt(d_k) in one pass at the end.
@@ -1058,6 +1080,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         for (int j = k + tx; j <= nf; j += tw) A[k * lda + j] = j == k ? dp : A[k * lda + j] / dp;
     }
     KBA_SYNC();
+    KBA_TICK(10);
     if (c.pad == 2) return;
     // ---- backward substitution U x = y (y = column nf), column oriented
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1091,6 +1114,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
     }
     KBA_SYNC();
+    KBA_TICK(11);
     if (c.pad == 3) return;
     for (int a = tid; a < nc; a += nt) {
         const int ca = cs[a];
@@ -1144,6 +1168,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             bv.pdist_c[gk] = bv.pdist[gk];
         }
     }
+    KBA_TICK(12);
     // three sums folded in one tree (red holds 3*nt doubles)
     red[0 * nt + tid] = part;
     red[1 * nt + tid] = step2;
@@ -1164,6 +1189,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         r.step2 = red[nt];
         r.cand2 = red[2 * nt];
     }
+    KBA_TICK(13);
 }
 
 

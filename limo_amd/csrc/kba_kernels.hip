@@ -445,6 +445,13 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
     if (st.active && st.need_lin) {
         cam_assemble(bv, c, w, threadIdx.x, blockDim.x, smem);
         __syncthreads();
+#ifdef KBA_PROFILE_TICKS
+        if (w == 0 && threadIdx.x == 0)
+            for (int l = 0; l < 2; ++l)
+                printf("[ticks cam_assemble %s lane] observation blocks %lld, ground-plane rows %lld, regulariser rows %lld, their sums %lld, mask + store %lld, reductions %lld\n",
+                       l ? "last" : "first", kba_ticks[l][1] - kba_ticks[l][0], kba_ticks[l][2] - kba_ticks[l][1], kba_ticks[l][3] - kba_ticks[l][2],
+                       kba_ticks[l][4] - kba_ticks[l][3], kba_ticks[l][5] - kba_ticks[l][4], kba_ticks[l][6] - kba_ticks[l][5]);
+#endif
         if (threadIdx.x == 0) lm_decide_lin(st, bv.red[w], bv.reg_cost[2 * w + 1], c);
     }
     __syncthreads();
@@ -471,6 +478,14 @@ __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
     cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, &flag);
+#ifdef KBA_PROFILE_TICKS
+    __syncthreads();
+    if (w == 0 && threadIdx.x == 0)
+        for (int l = 0; l < 2; ++l)
+            printf("[ticks cam_solve %s lane] slab sum %lld, cholesky %lld, back-substitution %lld, step %lld, reduction %lld\n", l ? "last" : "first",
+                   kba_ticks[l][9] - kba_ticks[l][8], kba_ticks[l][10] - kba_ticks[l][9], kba_ticks[l][11] - kba_ticks[l][10],
+                   kba_ticks[l][12] - kba_ticks[l][11], kba_ticks[l][13] - kba_ticks[l][12]);
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c, const int32_t* wl) {
