@@ -686,29 +686,44 @@ KBA_HD double block_grad_inf(int kind, const double* x, const double* g) {
     return m;
 }
 
-// Deterministic workgroup reductions over `nt` lanes (nt a power of two; nt == 1 in the emulator).
-// red must hold nt doubles.  Every lane of the workgroup must call these.
-KBA_HD double coop_sum(double v, int tid, int nt, double* red) {
-    red[tid] = v;
+// N per-lane values reduced over the workgroup, the first NSUM by addition, the rest by maximum; every lane gets the
+// results.  red: N * nt doubles (host tree) / N * (nt / 64) doubles (device).  On gfx950 the waves reduce with
+// butterfly shuffles (every lane of a wave ends with the same bits) and meet once in LDS: one barrier instead of
+// log2(nt) of them - the trees were 4-5 us of each window-level kernel.
+template <int N, int NSUM>
+KBA_HD void coop_reduce(double* v, int tid, int nt, double* red) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nt >= 64 && (nt & 63) == 0) {
+        const int wave = tid >> 6, nw = nt >> 6;
+        for (int q = 0; q < N; ++q) {
+            double x = v[q];
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(x, off, 64);
+                x = q < NSUM ? x + o : fmax(x, o);
+            }
+            if ((tid & 63) == 0) red[wave * N + q] = x;
+        }
+        KBA_SYNC();
+        for (int q = 0; q < N; ++q) {
+            double x = red[q];
+            for (int u = 1; u < nw; ++u) x = q < NSUM ? x + red[u * N + q] : fmax(x, red[u * N + q]);
+            v[q] = x;
+        }
+        KBA_SYNC();
+        return;
+    }
+#endif
+    for (int q = 0; q < N; ++q) red[q * nt + tid] = v[q];
     KBA_SYNC();
     for (int s = nt >> 1; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+        if (tid < s) {
+            for (int q = 0; q < NSUM; ++q) red[q * nt + tid] += red[q * nt + tid + s];
+            for (int q = NSUM; q < N; ++q) red[q * nt + tid] = fmax(red[q * nt + tid], red[q * nt + tid + s]);
+        }
         KBA_SYNC();
     }
-    const double out = red[0];
+    for (int q = 0; q < N; ++q) v[q] = red[q * nt];
     KBA_SYNC();
-    return out;
-}
-KBA_HD double coop_max(double v, int tid, int nt, double* red) {
-    red[tid] = v;
-    KBA_SYNC();
-    for (int s = nt >> 1; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
-        KBA_SYNC();
-    }
-    const double out = red[0];
-    KBA_SYNC();
-    return out;
 }
 
 // scratch doubles needed by cam_assemble / cam_solve for a system of nc slots and nt lanes
@@ -929,27 +944,15 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
             xn2 += bv.pdist[gk] * bv.pdist[gk];
         }
     }
-    {   // six reductions folded in one tree (4 sums, 2 maxima); red holds 6*nt doubles
-        red[0 * nt + tid] = reg_free;
-        red[1 * nt + tid] = reg_fixed;
-        red[2 * nt + tid] = cost;
-        red[3 * nt + tid] = xn2;
-        red[4 * nt + tid] = failf;
-        red[5 * nt + tid] = gmax;
-        KBA_SYNC();
-        for (int s = nt >> 1; s > 0; s >>= 1) {
-            if (tid < s) {
-                for (int q = 0; q < 4; ++q) red[q * nt + tid] += red[q * nt + tid + s];
-                for (int q = 4; q < 6; ++q) red[q * nt + tid] = fmax(red[q * nt + tid], red[q * nt + tid + s]);
-            }
-            KBA_SYNC();
-        }
-        reg_free = red[0];
-        reg_fixed = red[1 * nt];
-        cost = red[2 * nt] + reg_free;
-        xn2 = red[3 * nt];
-        failf = red[4 * nt];
-        gmax = red[5 * nt];
+    {   // six reductions at once (4 sums, 2 maxima); red holds 6*nt doubles
+        double v[6] = {reg_free, reg_fixed, cost, xn2, failf, gmax};
+        coop_reduce<6, 4>(v, tid, nt, red);
+        reg_free = v[0];
+        reg_fixed = v[1];
+        cost = v[2] + reg_free;
+        xn2 = v[3];
+        failf = v[4];
+        gmax = v[5];
     }
     if (tid == 0) {
         WinRed& r = bv.red[w];
@@ -1130,7 +1133,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     for (int a = tid; a < nc; a += nt) {
         if (cs[a] < 0) continue;
         double hd = 0.0;
-        for (int b = 0; b < nc; ++b) hd += Hg[a * nc + b] * dl[b];
+        for (int b = 0; b < nc; ++b) hd += Hg[b * nc + a] * dl[b];  // H is symmetric to the bit: column a = row a, read coalesced
         part += -bv.gc[wd.cam0 + a] * dl[a] - 0.5 * dl[a] * hd;
     }
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
@@ -1169,25 +1172,15 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
     }
     KBA_TICK(12);
-    // three sums folded in one tree (red holds 3*nt doubles)
-    red[0 * nt + tid] = part;
-    red[1 * nt + tid] = step2;
-    red[2 * nt + tid] = cand2;
-    KBA_SYNC();
-    for (int sft = nt >> 1; sft > 0; sft >>= 1) {
-        if (tid < sft) {
-            red[0 * nt + tid] += red[0 * nt + tid + sft];
-            red[1 * nt + tid] += red[1 * nt + tid + sft];
-            red[2 * nt + tid] += red[2 * nt + tid + sft];
-        }
-        KBA_SYNC();
-    }
+    // three sums at once (red holds 3*nt doubles)
+    double v3[3] = {part, step2, cand2};
+    coop_reduce<3, 3>(v3, tid, nt, red);
     if (tid == 0) {
         WinRed& r = bv.red[w];
         r.chol_fail = 0;
-        r.mcc = red[0];
-        r.step2 = red[nt];
-        r.cand2 = red[2 * nt];
+        r.mcc = v3[0];
+        r.step2 = v3[1];
+        r.cand2 = v3[2];
     }
     KBA_TICK(13);
 }
@@ -1215,12 +1208,14 @@ KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red
         reg_row_eval(wd, bv.cmask, bv.pose_c, bv.pdir_c, bv.pdist_c, i, false, row, all_const);
         if (!all_const) cost += 0.5 * row.r * row.r;
     }
-    mcc = coop_sum(mcc, tid, nt, red);
-    s2 = coop_sum(s2, tid, nt, red);
-    c2 = coop_sum(c2, tid, nt, red);
-    cost = coop_sum(cost, tid, nt, red);
-    lfail = coop_max(lfail, tid, nt, red);
-    cfail = coop_max(cfail, tid, nt, red);
+    double v[6] = {mcc, s2, c2, cost, lfail, cfail};
+    coop_reduce<6, 4>(v, tid, nt, red);  // red: 6 * nt doubles on the host, 6 per wave on the device
+    mcc = v[0];
+    s2 = v[1];
+    c2 = v[2];
+    cost = v[3];
+    lfail = v[4];
+    cfail = v[5];
     if (tid == 0) {
         WinRed& r = bv.red[w];
         r.mcc += mcc;

@@ -287,7 +287,7 @@ struct EmuBatch : Executor {
         exchange(4);
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active) continue;
-            double red1[1];
+            double red1[6];
             reduce_step(bv, w, 0, 1, red1);
             const double x_cost_before = bv.st[w].x_cost, radius_before = bv.st[w].radius;
             lm_decide_step(bv.st[w], bv.red[w], c);
