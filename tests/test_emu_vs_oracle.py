@@ -179,3 +179,33 @@ def test_empty_and_ragged_windows(oracle, emu):
     oracle.solve(ro, default_options())
     assert np.array_equal(re_.lm_pos[3], rag.lm_pos[3])
     assert rel_pose_err(re_.kf_pose, ro.kf_pose) <= TOL
+
+
+def test_random_window_shapes_match_oracle(oracle, emu):
+    """A seeded sweep over window shapes the fixed cases above do not name (keyframe count, landmark count, share of
+    depth / ground-plane / outlier measurements, mono / stereo, with / without plane parameters): the same trimming
+    sets and terminations as the oracle, poses and cost inside the parity bar; solved one by one and as ONE ragged batch
+    (the batch must give the bits of the single solves)."""
+    rng = np.random.default_rng(2024)
+    o = default_options()
+    ws = []
+    for i in range(10):
+        kw = dict(n_kf=int(rng.integers(3, 9)), n_lm=int(rng.choice([40, 90, 150, 260, 420])),
+                  depth_prob=float(rng.choice([0.0, 0.02, 0.3, 0.9])), ground_frac=float(rng.choice([0.0, 0.1, 0.4])),
+                  outlier_frac=float(rng.choice([0.0, 0.05, 0.15])), stereo_baseline=float(rng.choice([0.0, 0.0, 0.54])),
+                  with_ground_plane=bool(rng.integers(0, 2)))
+        ws.append(synth.make_window(20000 + i, **kw))
+    singles = []
+    for w in ws:
+        we, wo = w.copy(), w.copy()
+        re_ = emu.solve_batch([we], o)[0]
+        ro, _ = oracle.solve(wo, o)
+        for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks", "num_solves", "termination"):
+            assert re_[k] == ro[k], k
+        assert abs(re_["final_cost"] - ro["final_cost"]) <= TOL * abs(ro["final_cost"])
+        assert rel_pose_err(we.kf_pose, wo.kf_pose) <= TOL
+        singles.append(we)
+    batch = [w.copy() for w in ws]
+    emu.solve_batch(batch, o)
+    for a, b in zip(batch, singles):
+        assert np.array_equal(a.kf_pose, b.kf_pose) and np.array_equal(a.lm_pos, b.lm_pos)
