@@ -58,7 +58,10 @@ enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
 enum limo_status {
     LIMO_OK = 0,
     LIMO_ERR_INVALID = -1,      /* null pointer, negative size, index out of range        */
-    LIMO_ERR_NOT_ENOUGH_KF = -2, /* solve() with < 3 keyframes (NotEnoughKeyframesException) */
+    LIMO_ERR_NOT_ENOUGH_KF = -2, /* solve() on a window without active keyframes.  The reference's
+                                    NotEnoughKeyframesException counts all PUSHED keyframes (< 3,
+                                    bundle_adjuster_keyframes.cpp:630): the caller's check; the window of
+                                    ACTIVE keyframes may hold 1 or 2 and is solved like the reference does */
     LIMO_ERR_RUNTIME = -3,      /* HIP runtime error                                       */
     LIMO_ERR_NO_DEVICE = -4     /* no gfx950 device / extension cannot run                 */
 };
@@ -180,6 +183,10 @@ int limo_ba_batch_solve(limo_ba_batch* batch, const limo_ba_options* opts);
 int limo_ba_batch_reset(limo_ba_batch* batch);
 int limo_ba_batch_download(limo_ba_batch* batch, limo_ba_window* windows_out, limo_ba_report* reports);
 void limo_ba_batch_destroy(limo_ba_batch* batch);
+/* Which landmarks of window `window` the trimming rounds of the last solve removed (the outlier groups
+ * robust_optimization::solveTrimmed erases, robust_solving.cpp:183-215; the reference only logs their number):
+ * removed[l] = 1 for landmark l (the caller's landmark order), else 0.  removed has n_lm entries. */
+int limo_ba_batch_trimmed(limo_ba_batch* batch, int32_t window, uint8_t* removed);
 /* Device time (ms, HIP events on the batch's stream) and launch count of the Jacobian-evaluation kernel
  * accumulated since create()/the last call with reset != 0; either output may be NULL. */
 int limo_ba_batch_kernel_stats(limo_ba_batch* batch, int reset, double* linearize_ms, int64_t* linearize_launches,

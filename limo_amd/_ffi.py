@@ -161,6 +161,7 @@ ABI_SYMBOLS = [
     "limo_ba_batch_reset",
     "limo_ba_batch_download",
     "limo_ba_batch_destroy",
+    "limo_ba_batch_trimmed",
     "limo_ba_batch_kernel_stats",
     "limo_ba_batch_kernel_time",
     "limo_comm_unique_id",
@@ -205,6 +206,7 @@ def load():
     lib.limo_ba_batch_download.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaReport)]
     lib.limo_ba_batch_destroy.argtypes = [vp]
     lib.limo_ba_batch_destroy.restype = None
+    lib.limo_ba_batch_trimmed.argtypes = [vp, C.c_int32, c_uint8_p]
     lib.limo_ba_batch_kernel_stats.argtypes = [vp, C.c_int, c_double_p, c_int64_p, c_double_p]
     lib.limo_ba_batch_kernel_time.argtypes = [vp, C.c_int, c_double_p, c_int64_p]
     lib.limo_comm_unique_id.argtypes = [C.c_char_p]

@@ -133,6 +133,12 @@ class Batch:
         _check(self.lib.limo_ba_batch_download(self.ptr, self._arr, reps), self.ctx.ptr, "limo_ba_batch_download")
         return [r.as_dict() for r in reps]
 
+    def trimmed(self, w=0):
+        """Indices (caller's order) of the landmarks of window w removed by the trimming rounds of the last solve."""
+        flags = np.zeros(max(1, self.windows[w].n_lm), np.uint8)
+        _check(self.lib.limo_ba_batch_trimmed(self.ptr, int(w), flags.ctypes.data_as(_ffi.c_uint8_p)), self.ctx.ptr, "limo_ba_batch_trimmed")
+        return np.nonzero(flags[: self.windows[w].n_lm])[0].astype(np.int32)
+
     def kernel_stats(self, reset=False):
         ms = C.c_double()
         n = C.c_int64()

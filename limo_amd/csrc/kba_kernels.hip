@@ -204,7 +204,7 @@ __host__ __device__ inline int schur_ld(int nfp) {
     return nfp + 1;
 }
 
-constexpr int kSchurMaxViews = 64;
+constexpr int kSchurMaxViews = kMaxViews;  // checked at pack time (kba_pack.cpp)
 
 __host__ __device__ inline int schur_lds_bytes(int nfp) {
     return (3 * kSchurLm * schur_ld(nfp) + kMaxNc + 9 * kMaxKf) * (int)sizeof(double) + (kMaxNc + kSchurMaxViews + kMaxKf + 4) * (int)sizeof(int);

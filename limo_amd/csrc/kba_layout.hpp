@@ -18,6 +18,7 @@
 namespace kba {
 
 constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimization_window of the KITTI launch = 12)
+constexpr int kMaxViews = 64;     // max (keyframe, camera) views per window (LDS tables of the Schur kernels)
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels

@@ -89,8 +89,13 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             err1[w] = msg;
         };
         if (W.n_kf < 0 || W.n_lm < 0 || W.n_obs < 0 || W.n_cam < 0) return fail(LIMO_ERR_INVALID, "negative size");
-        if (!po.pose_only && !po.evaluate_only && W.n_kf < 3)
-            return fail(LIMO_ERR_NOT_ENOUGH_KF, "Not enough keyframes available in bundle_adjuster_keyframes. Should be 3");
+        // The reference's NotEnoughKeyframesException counts ALL pushed keyframes (keyframes_.size() < 3,
+        // bundle_adjuster_keyframes.cpp:630) - that check lives in the C++ shim.  The window only holds the ACTIVE
+        // ones, and the reference solves happily with two (deactivateKeyframes(min_conn, 3, max) can leave exactly the
+        // two newest, mono_lidar.cpp:249) or one of them: the scale / ground-plane regularisers simply need > 1
+        // (:771, :891).  Only an empty window has nothing to solve.
+        if (!po.pose_only && !po.evaluate_only && W.n_kf < 1)
+            return fail(LIMO_ERR_NOT_ENOUGH_KF, "window without active keyframes");
         if (po.pose_only && W.n_kf != 1) return fail(LIMO_ERR_INVALID, "pose-only window must hold exactly one keyframe");
         if (W.n_kf > kMaxKf) return fail(LIMO_ERR_INVALID, "window has more keyframes than kMaxKf (12)");
         if ((W.n_kf && (!W.kf_pose || !W.kf_plane_dir || !W.kf_plane_dist || !W.kf_fixation)) ||
@@ -111,6 +116,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                     vid[(size_t)k * W.n_cam + c] = nv++;
                     views[w].push_back({k, c});
                 }
+        if (nv > kMaxViews) return fail(LIMO_ERR_INVALID, "window has more than kMaxViews (64) (keyframe, camera) views with observations");
         obs_view[w].resize(W.n_obs);
         for (int i = 0; i < W.n_obs; ++i) obs_view[w][i] = vid[(size_t)W.obs_kf[i] * W.n_cam + W.obs_cam[i]];
     });

@@ -46,8 +46,15 @@ extern "C" int limo_landmark_init(limo_ctx* ctx, int32_t n, const int32_t* ray_o
     if (!ctx) return LIMO_ERR_INVALID;  // device work: needs a context (no host fallback)
     if (n < 0 || (n > 0 && (!ray_off || !rays || !use_depth || !pos_out || !ok))) return LIMO_ERR_INVALID;
     if (n == 0) return LIMO_OK;
+    if (ray_off[0] != 0) {  // CSR base: the kernel indexes rays[ray_off[i] ..) on the device
+        ctx->err = "limo_landmark_init: ray_off[0] must be 0";
+        return LIMO_ERR_INVALID;
+    }
     for (int i = 0; i < n; ++i)
-        if (ray_off[i + 1] < ray_off[i]) return LIMO_ERR_INVALID;
+        if (ray_off[i + 1] < ray_off[i]) {
+            ctx->err = "limo_landmark_init: ray_off must be non-decreasing";
+            return LIMO_ERR_INVALID;
+        }
     if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
     const size_t n_rays = (size_t)ray_off[n];
     const size_t b_off = sizeof(int32_t) * (n + 1), b_rays = sizeof(limo_ray) * n_rays, b_use = (size_t)n;
@@ -71,6 +78,9 @@ extern "C" int limo_landmark_init(limo_ctx* ctx, int32_t n, const int32_t* ray_o
     std::memcpy(pos_out, h + in_bytes, b_pos);
     std::memcpy(ok, h + in_bytes + o_ok, (size_t)n);
 done:
+    // an error after the upload / launch was queued: the blocks may still be in flight - drain the stream before they
+    // go back to the pools (the next call would otherwise reuse memory the device is still reading or writing)
+    if (rc != LIMO_OK) (void)hipStreamSynchronize(s);
     if (h) ctx->host_free(h, total);
     if (d) ctx->pool_free(d, total);
     return rc;

@@ -868,6 +868,21 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
     return LIMO_OK;
 }
 
+int limo_ba_batch_trimmed(limo_ba_batch* b, int32_t w, uint8_t* removed) {
+    if (!b || !removed || w < 0 || w >= b->P.n_win) return LIMO_ERR_INVALID;
+    limo_ctx* ctx = b->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    const WinDesc& d = b->P.win[w];
+    std::vector<uint8_t> st((size_t)std::max(1, (int)d.n_lm));
+    if (d.n_lm) {
+        HIP_TRY(ctx, hipMemcpyAsync(st.data(), b->bv.lm_state + d.lm0, (size_t)d.n_lm, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int l = 0; l < d.n_lm; ++l)  // packed order -> the caller's order; in the problem at create(), out of it now
+        removed[b->P.lm_id[d.lm0 + l]] = (b->P.lm_state[d.lm0 + l] != 0 && st[l] == 0) ? 1 : 0;
+    return LIMO_OK;
+}
+
 void limo_ba_batch_destroy(limo_ba_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);

@@ -214,6 +214,10 @@ void print_summary(const SolverSummary& s) {
                     it.trust_region_radius, (int)it.step_is_valid, (int)it.step_is_successful);
 }
 
+// group ids (= landmark indices of the caller's window) removed by the last solve_trimmed of this thread: lets a
+// test rebuild the problem the final solve actually saw (tests/test_basin_restart.py)
+static thread_local std::vector<unsigned long> g_last_removed;
+
 struct TrimResult {
     std::vector<SolverSummary> summaries;
     int n_trimmed = 0;
@@ -266,6 +270,7 @@ TrimResult solve_trimmed(const std::vector<int>& number_iterations,
     R.summaries.push_back(fin);
     if (getenv("ORACLE_VERBOSE")) print_summary(fin);
     R.n_trimmed = (int)all_removed.size();
+    g_last_removed.assign(all_removed.begin(), all_removed.end());
     return R;
 }
 
@@ -404,7 +409,7 @@ void oracle_ba_default_options(limo_ba_options* o) {
 int oracle_ba_solve(limo_ba_window* w, const limo_ba_options* o, limo_ba_report* rep, int num_threads,
                     int num_linear_solver_threads, double* phase_times) {
     if (!w || !o) return LIMO_ERR_INVALID;
-    if (w->n_kf < 3) return LIMO_ERR_NOT_ENOUGH_KF;  // :630-632
+    if (w->n_kf < 1) return LIMO_ERR_NOT_ENOUGH_KF;  // (:630-632 counts ALL pushed keyframes: the caller's check; active ones may be 1 or 2)
     auto t0 = std::chrono::steady_clock::now();
     Built B;
     build_solve_problem(*w, *o, B);
@@ -420,6 +425,16 @@ int oracle_ba_solve(limo_ba_window* w, const limo_ba_options* o, limo_ba_report*
     fill_report(R, B, rep, phase_times);
     if (rep) rep->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return LIMO_OK;
+}
+
+// Landmark indices trimmed by the last oracle_ba_solve / oracle_ba_adjust_pose_only on this thread; returns the count.
+int oracle_last_trimmed(int32_t* out, int cap) {
+    int n = 0;
+    for (unsigned long id : g_last_removed) {
+        if (n < cap && out) out[n] = (int32_t)id;
+        ++n;
+    }
+    return n;
 }
 
 // adjustPoseOnly, :820-888.  window: n_kf == 1, landmarks constant.

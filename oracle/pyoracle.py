@@ -32,6 +32,7 @@ def load():
     lib.oracle_ba_default_options.argtypes = [C.POINTER(_ffi.BaOptions)]
     lib.oracle_ba_default_options.restype = None
     lib.oracle_ba_solve.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.c_int, dp]
+    lib.oracle_last_trimmed.argtypes = [ip, C.c_int]
     lib.oracle_ba_adjust_pose_only.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.SpeedPrior), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int]
     lib.oracle_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
     lib.oracle_ba_problem_cost.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), dp, ip]
@@ -64,6 +65,15 @@ def solve(window, opts, num_threads=1, num_linear_solver_threads=1):
     if rc != 0:
         raise RuntimeError("oracle_ba_solve rc=%d" % rc)
     return rep.as_dict(), pt
+
+
+def last_trimmed():
+    """Landmark indices (caller's order) removed by the trimming rounds of the last solve on this thread."""
+    lib = load()
+    n = lib.oracle_last_trimmed(None, 0)
+    out = np.zeros(max(1, n), np.int32)
+    lib.oracle_last_trimmed(out.ctypes.data_as(_ffi.c_int32_p), n)
+    return np.sort(out[:n])
 
 
 def adjust_pose_only(window, prior, opts, num_threads=1):

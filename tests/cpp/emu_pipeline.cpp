@@ -370,6 +370,17 @@ void fill_report(const EmuBatch& B, int w, limo_ba_report* r) {
     r->final_cost = s.solve_final_cost;
 }
 
+// per window: indices (caller's order) of the landmarks the trimming rounds removed - what limo_ba_batch_trimmed reports
+static thread_local std::vector<std::vector<int32_t>> g_last_trimmed;
+void record_trimmed(const EmuBatch& B) {
+    g_last_trimmed.assign(B.bv.n_win, {});
+    for (int w = 0; w < B.bv.n_win; ++w) {
+        const WinDesc& d = B.bv.win[w];
+        for (int l = 0; l < d.n_lm; ++l)
+            if (B.P.lm_state[d.lm0 + l] != 0 && B.bv.lm_state[d.lm0 + l] == 0) g_last_trimmed[w].push_back(B.bv.lm_id[d.lm0 + l]);
+    }
+}
+
 void write_back(const EmuBatch& B, limo_ba_window* windows) {
     for (int w = 0; w < B.bv.n_win; ++w) {
         const WinDesc& d = B.bv.win[w];
@@ -398,9 +409,21 @@ int emu_ba_solve_batch(int32_t n, limo_ba_window* windows, const limo_ba_options
     B.alloc();
     run_schedule(B, *o);
     write_back(B, windows);
+    record_trimmed(B);
     if (reports)
         for (int w = 0; w < n; ++w) fill_report(B, w, reports + w);
     return LIMO_OK;
+}
+
+// Landmarks (caller's indices) of window w removed by trimming in the last emu_ba_solve_batch of this thread.
+int emu_last_trimmed(int w, int32_t* out, int cap) {
+    if (w < 0 || w >= (int)g_last_trimmed.size()) return -1;
+    int n = 0;
+    for (int32_t id : g_last_trimmed[w]) {
+        if (n < cap && out) out[n] = id;
+        ++n;
+    }
+    return n;
 }
 
 // Landmark-sharded solve of one window.  cb == NULL: n_shards virtual shards in this process (the

@@ -89,6 +89,7 @@ def load():
         dp, u8p = _ffi.c_double_p, _ffi.c_uint8_p
         lib.emu_ba_solve_batch.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.POINTER(_ffi.SpeedPrior)]
         lib.emu_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+        lib.emu_last_trimmed.argtypes = [C.c_int, _ffi.c_int32_p, C.c_int]
         lib.emu_ba_solve_sharded.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, C.POINTER(_ffi.BaReport)]
         _lib = lib
     return _lib
@@ -104,6 +105,15 @@ def solve_batch(windows, opts, pose_only=False, prior=None):
     if rc != 0:
         raise RuntimeError("emu_ba_solve_batch rc=%d" % rc)
     return [r.as_dict() for r in reps]
+
+
+def last_trimmed(w=0):
+    """Caller-order landmark indices trimmed in window w of the last solve_batch."""
+    lib = load()
+    n = lib.emu_last_trimmed(int(w), None, 0)
+    out = np.zeros(max(1, n), np.int32)
+    lib.emu_last_trimmed(int(w), out.ctypes.data_as(_ffi.c_int32_p), n)
+    return np.sort(out[:n])
 
 
 def evaluate(window, opts, apply_loss=True):

@@ -80,9 +80,33 @@ def test_batch_ragged_matches_single(ctx, oracle):
 
 
 def test_not_enough_keyframes(ctx):
-    w = synth.make_window(5, n_kf=2, n_lm=50)
+    """Only a window without active keyframes is refused; two (or one) active keyframes are solved like the reference
+    does (its NotEnoughKeyframesException counts PUSHED keyframes: the shim's check) - cases kf2 / kf1 below."""
+    from limo_amd.window import Window
+
+    w2 = synth.make_window(5, n_kf=3, n_lm=50)
+    w = Window(kf_pose=np.zeros((0, 7)), kf_plane_dir=np.zeros((0, 3)), kf_plane_dist=np.zeros(0), kf_fixation=np.zeros(0, np.int32),
+               cam=w2.cam, lm_pos=w2.lm_pos, lm_weight=w2.lm_weight, lm_is_ground=w2.lm_is_ground, obs_kf=np.zeros(0, np.int32),
+               obs_lm=np.zeros(0, np.int32), obs_cam=np.zeros(0, np.int32), obs_u=np.zeros(0, np.float32),
+               obs_v=np.zeros(0, np.float32), obs_d=np.zeros(0, np.float32))
     with pytest.raises(ba.NotEnoughKeyframes):
         ctx.solve(w, default_options())
+
+
+def test_solver_time_cap(ctx, oracle):
+    from test_emu_vs_oracle import check_time_cap
+
+    last = {}
+
+    def solve(w, o):
+        b = ba.Batch(ctx, [w])
+        b.solve(o)
+        rep = b.download()[0]
+        last["t"] = b.trimmed(0)
+        b.close()
+        return rep
+
+    check_time_cap(solve, lambda w, o: oracle.solve(w, o)[0], lambda: last["t"], oracle.last_trimmed)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -163,6 +187,6 @@ def test_invalid_input_is_rejected(ctx):
     w.obs_kf[0] = 99
     with pytest.raises(ba.LimoError):
         ctx.solve(w, default_options())
-    big = synth.make_window(6, n_kf=13, n_lm=40)  # more than kMaxKf keyframes
+    big = synth.make_window(6, n_kf=33, n_lm=40)  # more than kMaxKf keyframes
     with pytest.raises(ba.LimoError):
         ctx.solve(big, default_options())
