@@ -215,8 +215,10 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
     part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
 }
 
-// (V' + D^2) = L L^T with V' = S V S (Jacobi-scaled), D^2 = clamp(diag V')/radius;  stores L^-1 and t = L^-1 S g.
-// Returns 1 on Cholesky failure.
+// (V' + D^2) = L L^T with V' = S V S (Jacobi-scaled), D^2 = clamp(diag V')/radius.  Stores what the step needs of
+// the landmark block:  Bt = L^-1 S  (lower triangular, 6: [l00 s0 | l10 s0, l11 s1 | l20 s0, l21 s1, l22 s2]) - every
+// later use of L^-1 comes with the scale attached (Y' = .. S L^-T = .. Bt^T, delta = -S L^-T t = -Bt^T t) - and
+// t = L^-1 S g = Bt g.  Returns 1 on Cholesky failure.
 KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
     if (bv.lm_state[gl] != 1) return 0;
     const int w = bv.lm_win[gl];
@@ -224,7 +226,7 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
     double s[3], V[6], g[3];
     for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
     for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
-    for (int i = 0; i < 3; ++i) g[i] = s[i] * bv.lm_g[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
     double A[6] = {s[0] * s[0] * V[0], s[0] * s[1] * V[1], s[0] * s[2] * V[2],
                    s[1] * s[1] * V[3], s[1] * s[2] * V[4], s[2] * s[2] * V[5]};
     A[0] += fmin(fmax(A[0], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
@@ -236,10 +238,11 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
         fail = 1;
         for (int i = 0; i < 6; ++i) Li[i] = 0.0;
     }
-    for (int i = 0; i < 6; ++i) bv.lm_Li[i * bv.SL + gl] = Li[i];
-    bv.lm_t[0 * bv.SL + gl] = Li[0] * g[0];
-    bv.lm_t[1 * bv.SL + gl] = Li[1] * g[0] + Li[2] * g[1];
-    bv.lm_t[2 * bv.SL + gl] = Li[3] * g[0] + Li[4] * g[1] + Li[5] * g[2];
+    const double Bt[6] = {Li[0] * s[0], Li[1] * s[0], Li[2] * s[1], Li[3] * s[0], Li[4] * s[1], Li[5] * s[2]};
+    for (int i = 0; i < 6; ++i) bv.lm_Li[i * bv.SL + gl] = Bt[i];
+    bv.lm_t[0 * bv.SL + gl] = Bt[0] * g[0];
+    bv.lm_t[1 * bv.SL + gl] = Bt[1] * g[0] + Bt[2] * g[1];
+    bv.lm_t[2 * bv.SL + gl] = Bt[3] * g[0] + Bt[4] * g[1] + Bt[5] * g[2];
     return fail;
 }
 
@@ -253,9 +256,9 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
 // schur_pair_block: the 3 x 10 block of Y' that landmark gl contributes to keyframe kl (local index): all of the
 // keyframe's views of the landmark (Ft = c^T Rc, F = Ft [M | I], E = Ft R rebuilt from the factored planes) plus its ground-plane
 // row when that row is attached to kl.  Y[a*3 + c'] for local slot a; masked slots are left zero.
-//   lmk = landmark scale (3) | L^-1 (6, lower, row-major);  sc = Jacobi scale of the window's slots (local index);
-//   vkl[j] = local keyframe of view j.
-// Pose part of one observation:  Y[a*3 + c'] += sc[a] (F^T E)[a][c] s_c Li[c'][c]   for the six pose slots, with
+//   lmk = Bt = L^-1 S of the landmark (6, lower, row-major; lm_damp_lane);  sc = Jacobi scale of the window's slots
+//   (local index);  vkl[j] = local keyframe of view j.
+// Pose part of one observation:  Y[a*3 + c'] += sc[a] (F^T E)[a][c] Bt[c'][c]   for the six pose slots, with
 // F^T E = [M^T G ; G],  G = Ft^T Ft R  (F = Ft [M | I], E = Ft R).
 KBA_HD void schur_pose_block(const double* Ft, const double* R, const double* M, const double* lmk, const double* sc6,
                              double* Y) {
@@ -273,10 +276,10 @@ KBA_HD void schur_pose_block(const double* Ft, const double* R, const double* M,
         G[3 + j] = a01 * R[j] + a11 * R[3 + j] + a12 * R[6 + j];
         G[6 + j] = a02 * R[j] + a12 * R[3 + j] + a22 * R[6 + j];
     }
-    // landmark-side factor  B[c][c'] = s_c Li[c'][c]  (Li lower triangular, row-major 6)
-    const double b00 = lmk[0] * lmk[3], b01 = lmk[0] * lmk[4], b02 = lmk[0] * lmk[6];
-    const double b11 = lmk[1] * lmk[5], b12 = lmk[1] * lmk[7];
-    const double b22 = lmk[2] * lmk[8];
+    // landmark-side factor  B[c][c'] = Bt[c'][c]
+    const double b00 = lmk[0], b01 = lmk[1], b02 = lmk[3];
+    const double b11 = lmk[2], b12 = lmk[4];
+    const double b22 = lmk[5];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double w0, w1, w2;
@@ -301,8 +304,7 @@ KBA_HD void schur_gp_block(const BatchView& bv, int gg, const uint8_t* cm, const
     double E[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = bv.gp_E[i * bv.SG + gg];
-    const double e0 = E[0] * lmk[0], e1 = E[1] * lmk[1], e2 = E[2] * lmk[2];
-    const double y0 = e0 * lmk[3], y1 = e0 * lmk[4] + e1 * lmk[5], y2 = e0 * lmk[6] + e1 * lmk[7] + e2 * lmk[8];
+    const double y0 = E[0] * lmk[0], y1 = E[0] * lmk[1] + E[1] * lmk[2], y2 = E[0] * lmk[3] + E[1] * lmk[4] + E[2] * lmk[5];
 #pragma unroll
     for (int a = 0; a < kCamSlots; ++a) {
         if (!cm[a]) continue;
@@ -346,9 +348,24 @@ KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int
 
 KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) lmk[i] = bv.lm_scale[i * bv.SL + gl];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) lmk[i] = bv.lm_Li[i * bv.SL + gl];
+}
+
+// Partial slabs of a window: a wave takes `span` consecutive Schur blocks of ONE class (plain / ground-plane) and
+// writes one slab; plain groups come first.
+KBA_HD int schur_plain_slabs(const WinDesc& wd, int span) { return (wd.n_sblk_plain + span - 1) / span; }
+KBA_HD int schur_slabs(const WinDesc& wd, int span) {
+    return schur_plain_slabs(wd, span) + (wd.n_sblk - wd.n_sblk_plain + span - 1) / span;
+}
+KBA_HD int schur_slab_of(const WinDesc& wd, int sb, int span) {
+    const int i = sb - wd.sblk0;
+    return i < wd.n_sblk_plain ? i / span : schur_plain_slabs(wd, span) + (i - wd.n_sblk_plain) / span;
+}
+// last block (inclusive) of the group that starts at block sb
+KBA_HD int schur_group_last(const WinDesc& wd, int sb, int span) {
+    const int i = sb - wd.sblk0;
+    const int end = i < wd.n_sblk_plain ? wd.n_sblk_plain : wd.n_sblk;
+    return wd.sblk0 + (i + span < end ? i + span : end) - 1;
 }
 
 // Landmark-sharded solve: entry e of slab `shard` of S_red = sum over ALL partial slabs of the window in this shard's
@@ -411,22 +428,19 @@ KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
         for (int k = 0; k < kCamSlots; ++k) q += bv.gp_F[k * bv.SG + gg] * dc[k];
         for (int cc = 0; cc < 3; ++cc) a[cc] += bv.gp_E[cc * bv.SG + gg] * q;
     }
-    double s[3], Li[6], t[3], V[6], g[3];
-    for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
-    for (int i = 0; i < 6; ++i) Li[i] = bv.lm_Li[i * bv.SL + gl];
+    double Bt[6], t[3], V[6], g[3];
+    for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];  // L^-1 S (lm_damp_lane)
     for (int i = 0; i < 3; ++i) t[i] = bv.lm_t[i * bv.SL + gl];
     for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
     for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
-    // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c)
-    const double b0 = s[0] * a[0], b1 = s[1] * a[1], b2 = s[2] * a[2];
-    const double t0 = t[0] + Li[0] * b0;
-    const double t1 = t[1] + Li[1] * b0 + Li[2] * b1;
-    const double t2 = t[2] + Li[3] * b0 + Li[4] * b1 + Li[5] * b2;
-    // y = L^-T t
-    const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
-    const double y1 = Li[2] * t1 + Li[4] * t2;
-    const double y2 = Li[5] * t2;
-    const double d0 = -s[0] * y0, d1 = -s[1] * y1, d2 = -s[2] * y2;
+    // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c):  t' = t + L^-1 S a
+    const double t0 = t[0] + Bt[0] * a[0];
+    const double t1 = t[1] + Bt[1] * a[0] + Bt[2] * a[1];
+    const double t2 = t[2] + Bt[3] * a[0] + Bt[4] * a[1] + Bt[5] * a[2];
+    // delta_l = -S L^-T t'
+    const double d0 = -(Bt[0] * t0 + Bt[1] * t1 + Bt[3] * t2);
+    const double d1 = -(Bt[2] * t1 + Bt[4] * t2);
+    const double d2 = -(Bt[5] * t2);
     xc[0] = x[0] + d0;
     xc[1] = x[1] + d1;
     xc[2] = x[2] + d2;
@@ -997,7 +1011,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     // the same share; a lane sums up to 4 entries at once, 4 slabs each: 16 independent loads in flight (one window
     // alone on the GPU is bound by exactly this latency chain).  Per entry the order of the sum stays q mod 4.
     const int n_need = nf * (nf + 1) / 2 + nf;
-    const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : (wd.n_sblk + c.schur_span - 1) / c.schur_span;
+    const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : schur_slabs(wd, c.schur_span);
     for (int i0 = tid; i0 < n_need; i0 += 4 * nt) {
         double s[4], acc[4][4];
         int64_t off[4];

@@ -213,7 +213,7 @@ __host__ __device__ inline int schur_lds_bytes(int nfp) {
 // What a lane of the fast path holds one tile ahead (its landmark of the next tile, its keyframe is fixed).
 struct SchurPre {
     double c[4];    // factored Jacobian of the (landmark, keyframe) observation: (au, xn, yn, sd)
-    double lmk[9];  // landmark scale (3) | L^-1 (6)
+    double lmk[6];  // Bt = L^-1 S of the landmark (lm_damp_lane)
     double p[3];    // landmark position
     double t[3];    // L^-1 S g (lanes kq == 0 only)
     int gl;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, kq = lane >> 4;
-    const int sb_last = min(sb + span, wd.sblk0 + wd.n_sblk) - 1;
+    const int sb_last = schur_group_last(wd, sb, span);  // blocks of one class (plain / ground-plane) only
     const int lm_first = bv.sblk_lm0[sb];
     const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
 
@@ -304,9 +304,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         P.seen = P.live && slot >= 0;
         if (P.live && my_kl >= 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) P.lmk[i] = bv.lm_scale[i * bv.SL + gl];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) P.lmk[3 + i] = bv.lm_Li[i * bv.SL + gl];
+            for (int i = 0; i < 6; ++i) P.lmk[i] = bv.lm_Li[i * bv.SL + gl];
         }
         if (P.live && kq == 0) {
 #pragma unroll
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         } else {
             const int gl = lm_first + l0 + li;
             const bool live = li < nl && bv.lm_state[gl] == 1;
-            double lmk[9];
+            double lmk[6];
             if (live) schur_load_lm(bv, gl, lmk);
             if (kq == 0) {
 #pragma unroll
@@ -420,7 +418,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         }
         __syncthreads();
     }
-    double* out = bv.S_part + wd.spart_off + (int64_t)((sb - wd.sblk0) / span) * ((int64_t)nfp * nfp);
+    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span) * ((int64_t)nfp * nfp);
     int idx = 0;
 #pragma unroll
     for (int tr = 0; tr < TM; ++tr)
@@ -434,6 +432,200 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
                 }
             }
             ++idx;
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------ Schur complement, plain blocks
+// k_schur_plain<TQ>: the Schur blocks of landmarks WITHOUT a ground-plane row (about 80 % of a window) of the fast
+// class (WinDesc::schur_fast: <= 4 free keyframes, one view each).  Their tiles only touch the pose columns, so the
+// kernel is sized for exactly that and for OCCUPANCY (the general kernel above runs 2 waves / SIMD on 248 registers and
+// 18.8 KB of LDS; its per-tile chain fill -> LDS -> 12 k-steps is latency-bound):
+//   * Z tile [48][ld] with ld = nfq + 1 (25 columns for four free keyframes, odd): 9.6 KB.  Panel reads past column
+//     nfq run into the next row - finite values that only reach output entries nobody reads (masked to zero at the
+//     store) - so no padding columns exist;
+//   * TQ (1 or 2) panels -> 1 or 3 accumulator tiles (24 AGPRs) instead of 6;
+//   * keyframe constants (R, Rc, q, scale, columns) sit in LDS, the landmark-side inputs of ONE tile in registers: the
+//     loads of the next tile are issued right after the fill and complete under the 36 MFMAs of the current one.
+// One wave per workgroup, no cross-wave synchronisation; `span` consecutive plain blocks of a window per wave.
+constexpr int kSpBatch = 4;  // k-steps whose panel reads are in flight together
+constexpr int kSpKf = 28;  // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of the pose slots (6)
+
+__host__ __device__ inline int schur_plain_lds_bytes(int nfq) {
+    return (3 * kSchurLm * (nfq + 1) + 16 + 4 * kSpKf) * (int)sizeof(double) + 4 * 8 * (int)sizeof(int);
+}
+
+template <int TQ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_schur_plain(BatchView bv, const int32_t* wl, int span) {
+    const int sb = wl[blockIdx.x];
+    const int w = bv.sblk_win[sb];
+    if (!bv.st[w].active) return;
+    const WinDesc& wd = bv.win[w];
+    const int nfq = wd.nfq, nfp = wd.nf_pad, ld = nfq + 1;  // nfq is a multiple of 6: ld is odd
+    const int Tq = (nfq + 16) / 16;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Z = smem;                                   // [48][ld] + 16 zeros (the last row's panel overrun)
+    double* kc = Z + 3 * kSchurLm * ld + 16;            // [4][kSpKf]
+    int* zcs = reinterpret_cast<int*>(kc + 4 * kSpKf);  // [4][8] tile column of the pose slots (or -1)
+    const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
+    const int n_fk = wd.n_fk;
+    int my_view = -1;
+    if (kq < n_fk) {
+        const int kl = wd.fk[kq];
+        my_view = wd.fk_view[kq];
+        double* mine = kc + kq * kSpKf;
+        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + kl);
+        if (li == 0) {
+            double R[9];
+            quat_R(pose, R);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mine[i] = R[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mine[18 + i] = pose[i];
+        } else if (li < 10) {
+            mine[9 + li - 1] = my_view >= 0 ? bv.view_cam[16 * (int64_t)my_view + 4 + li - 1] : 0.0;
+        } else {
+            const int a = li - 10, slot = wd.cam0 + kl * kCamSlots + a;
+            mine[22 + a] = bv.scale_c[slot];
+            zcs[kq * 8 + a] = bv.cslot[slot];  // pose slots: compact index == tile column (< nfq)
+        }
+    }
+    if (lane < 16) Z[3 * kSchurLm * ld + lane] = 0.0;
+    __syncthreads();
+    const bool have = kq < n_fk && zcs[kq * 8] >= 0 && my_view >= 0;
+    const double* mine = kc + (kq < n_fk ? kq : 0) * kSpKf;
+    const int32_t* my_slots = bv.lm_slot + (int64_t)(my_view >= 0 ? my_view - wd.view0 : 0) * bv.SL;
+    const int sb_last = schur_group_last(wd, sb, span);
+    const int lm_first = bv.sblk_lm0[sb];
+    const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
+
+    constexpr int NT = TQ * (TQ + 1) / 2;
+    v4f64 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // software pipeline: slot / state of the tile after next, inputs of the next tile
+    auto fetch_index = [&](int l0, int& st, int& slot) {
+        st = 0;
+        slot = -1;
+        if (l0 + li < n_lm_blk) {
+            const int gl = lm_first + l0 + li;
+            st = bv.lm_state[gl];
+            if (have) slot = my_slots[gl];
+        }
+    };
+    double c4[4], p[3], Bt[6], t3[3];
+    bool live = false, seen = false;
+    auto fetch_data = [&](int l0, int st, int slot) {
+        const int gl = lm_first + l0 + li;
+        live = st == 1;
+        seen = live && slot >= 0;
+        if (seen) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + slot];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[i] = bv.lm[3 * (int64_t)gl + i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];
+        }
+        if (live && kq == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t3[i] = bv.lm_t[i * bv.SL + gl];
+        }
+    };
+    int n_st, n_slot;
+    {
+        int st0, slot0;
+        fetch_index(0, st0, slot0);
+        fetch_index(kSchurLm, n_st, n_slot);
+        fetch_data(0, st0, slot0);
+    }
+    for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
+        // ---- fill: this lane's 3 x 6 block of Y' (zeros where the landmark is not observed by the keyframe)
+        if (kq == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? t3[cc] : 0.0;
+        }
+        if (have) {
+            double Y[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) Y[i] = 0.0;
+            if (seen) {
+                double M[9], Ft[9];
+                rot_tangent_jac(mine + 18, p, M);
+                ft_build(c4, mine + 9, Ft);
+                schur_pose_block(Ft, mine, M, Bt, mine + 22, Y);
+            }
+            const int zc0 = zcs[kq * 8];  // the six pose slots of a keyframe are consecutive columns
+            double* zrow = Z + 3 * li * ld + zc0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                zrow[a] = Y[a * 3 + 0];
+                zrow[ld + a] = Y[a * 3 + 1];
+                zrow[2 * ld + a] = Y[a * 3 + 2];
+            }
+        }
+        // ---- loads of the next tile (complete under the MFMAs below), indices of the one after
+        {
+            const int st = n_st, slot = n_slot;
+            fetch_index(l0 + 2 * kSchurLm, n_st, n_slot);
+            fetch_data(l0 + kSchurLm, st, slot);
+        }
+        __syncthreads();
+        // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps
+        const double* zp = Z + kq * ld + li;
+        if (TQ == 1 || Tq == 1) {  // wave-uniform
+#pragma unroll
+            for (int h = 0; h < 12; h += kSpBatch) {
+                double pa[kSpBatch];
+#pragma unroll
+                for (int j = 0; j < kSpBatch; ++j) pa[j] = zp[(h + j) * 4 * ld];
+#pragma unroll
+                for (int j = 0; j < kSpBatch; ++j) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
+            }
+        } else if constexpr (TQ > 1) {
+            // the panel reads of kSpBatch k-steps are issued together, the 3 * kSpBatch MFMAs follow back to back
+#pragma unroll
+            for (int h = 0; h < 12; h += kSpBatch) {
+                double pa[kSpBatch], pb[kSpBatch];
+#pragma unroll
+                for (int j = 0; j < kSpBatch; ++j) {
+                    pa[j] = zp[(h + j) * 4 * ld];
+                    pb[j] = zp[(h + j) * 4 * ld + 16];
+                }
+#pragma unroll
+                for (int j = 0; j < kSpBatch; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pb[j], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[j], pb[j], acc[2], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix; entries outside [0, nfq]^2 are zero for plain
+    //      landmarks (and must be written: a slab may have belonged to a ground-plane group at another granularity)
+    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span) * ((int64_t)nfp * nfp);
+    const int T = nfp / 16;
+    int idx = 0;
+#pragma unroll
+    for (int tr = 0; tr < TQ; ++tr)
+#pragma unroll
+        for (int tc = tr; tc < TQ; ++tc) {
+            if (tc < T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+                    const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
+                    out[row * nfp + col] = (row <= nfq && col <= nfq) ? acc[idx][r] : 0.0;
+                }
+            }
+            ++idx;
+        }
+    for (int tc = TQ; tc < T; ++tc)
+        for (int tr = 0; tr <= tc; ++tr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
         }
 }
 

@@ -41,7 +41,14 @@ struct WinDesc {
     int32_t blk0, n_blk;      // linearize / cost workgroups (one view each)
     int32_t lblk0, n_lblk;    // landmark workgroups
     int32_t gp0, n_gp;
-    int32_t sblk0, n_sblk;    // Schur workgroups
+    int32_t sblk0, n_sblk;    // Schur blocks (<= kSchurLmPerBlock landmarks each)
+    int32_t n_sblk_plain;     // the first n_sblk_plain of them hold landmarks WITHOUT a ground-plane row (no block straddles
+                              // lm_gp0): their Schur tiles only touch the pose columns [0, nfq]
+    // "fast" Schur variant: at most four keyframes with free slots and one view per keyframe (decided at pack time, per
+    // window, so a window takes the same kernel alone and inside any batch)
+    int32_t schur_fast, n_fk;
+    int32_t fk[4];            // local keyframe index of the free keyframes
+    int32_t fk_view[4];       // their view (GLOBAL view index) or -1
     int32_t nc, nc_pad;       // 10*n_kf, rounded up to 16
     int32_t nf, nf_pad;       // free camera slots (compact Schur system); nf + 1 (rhs column) rounded up to 16
     int32_t nfq;              // free POSE slots: compact indices [0,nfq) are pose slots, [nfq,nf) plane slots.  In the

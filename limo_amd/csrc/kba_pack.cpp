@@ -429,17 +429,46 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             }
         d.n_lblk = (int)L.lblk_win.size() - d.lblk0;
         d.sblk0 = (int)L.sblk_win.size();
+        d.n_sblk_plain = 0;
         if (!po.pose_only && !po.evaluate_only && d.nf > 0) {
             const int per = kSchurLmPerBlock;
-            for (size_t si = 0; si + 1 < seg.size(); ++si)
-                for (int l0 = seg[si]; l0 < seg[si + 1]; l0 += per) {
+            // no Schur block straddles a shard run or the plain / ground-plane boundary
+            const int n_plain = W.n_lm - (int)gp_tmp.size();
+            std::vector<int> cuts(seg);
+            cuts.push_back(n_plain);
+            std::sort(cuts.begin(), cuts.end());
+            cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+            for (size_t si = 0; si + 1 < cuts.size(); ++si)
+                for (int l0 = cuts[si]; l0 < cuts[si + 1]; l0 += per) {
                     L.sblk_win.push_back(w);
                     L.sblk_lm0.push_back(d.lm0 + l0);
-                    L.sblk_n.push_back(std::min(per, seg[si + 1] - l0));
+                    L.sblk_n.push_back(std::min(per, cuts[si + 1] - l0));
                     L.sblk_owner.push_back(P.lm_id[d.lm0 + l0] % NS);
+                    if (l0 < n_plain) d.n_sblk_plain++;
                 }
         }
         d.n_sblk = (int)L.sblk_win.size() - d.sblk0;
+        // fast Schur variant (kba_kernels.hip): <= 4 keyframes with a free slot, one view per keyframe
+        d.schur_fast = 1;
+        d.n_fk = 0;
+        for (int q = 0; q < 4; ++q) d.fk[q] = d.fk_view[q] = -1;
+        for (int k = 0; k < W.n_kf; ++k) {
+            int nv = 0, view = -1;
+            for (int v = 0; v < d.n_view; ++v)
+                if (views[w][v].kf == k) {
+                    ++nv;
+                    view = d.view0 + v;
+                }
+            if (nv > 1) d.schur_fast = 0;
+            if (freem[k * kCamSlots] || freem[k * kCamSlots + 6]) {
+                if (d.n_fk < 4) {
+                    d.fk[d.n_fk] = k;
+                    d.fk_view[d.n_fk] = view;
+                }
+                d.n_fk++;
+            }
+        }
+        if (d.n_fk > 4) d.schur_fast = 0;
         };
     for_windows(pack_one);
     const auto t_p2 = std::chrono::steady_clock::now();

@@ -63,9 +63,14 @@ struct limo_ba_batch : Executor {
     int32_t *d_wl_blk = nullptr, *d_wl_lblk = nullptr, *d_wl_sblk = nullptr, *d_wl_win = nullptr, *d_flags = nullptr;
     int32_t* d_wl_sblk_part = nullptr;                          // Schur worklist of a re-batched active set
     int32_t* d_wl_sblk_full[3] = {nullptr, nullptr, nullptr};   // ... of every window, for spans 1, 2, 4
+    // Schur worklists are ordered [plain groups of fast windows | ground-plane groups of fast windows | generic windows]
     int n_wl_sblk_full[3] = {0, 0, 0};
-    int n_wl_sblk_fast_full[3] = {0, 0, 0};  // leading entries that belong to windows of the fast Schur variant
-    int n_wl_sblk_fast = 0;
+    int n_wl_sblk_plain_full[3] = {0, 0, 0};  // leading entries: plain groups of fast-class windows (k_schur_plain)
+    int n_wl_sblk_fgp_full[3] = {0, 0, 0};    // then: ground-plane groups of fast-class windows (k_schur<T, true>)
+    int n_wl_sblk_plain = 0, n_wl_sblk_fgp = 0;
+    bool use_plain_kernel = true;             // KBA_SCHUR_PLAIN=0: plain groups go through k_schur<T, true> too (A/B timing)
+    const void* schur_fn_plain = nullptr;
+    int plain_lds_bytes = 0;
     std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
     int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
@@ -98,7 +103,7 @@ struct limo_ba_batch : Executor {
     struct RankLists {
         int32_t *full_blk = nullptr, *full_lblk = nullptr, *full_sblk = nullptr;  // every window listed
         int32_t *act_blk = nullptr, *act_lblk = nullptr, *act_sblk = nullptr;     // re-batched active set
-        int n_full_blk = 0, n_full_lblk = 0, n_full_sblk = 0, n_full_sblk_fast = 0, n_sblk_fast = 0;
+        int n_full_blk = 0, n_full_lblk = 0, n_full_sblk = 0, n_full_sblk_plain = 0, n_full_sblk_fgp = 0, n_sblk_plain = 0, n_sblk_fgp = 0;
         const int32_t *blk = nullptr, *lblk = nullptr, *sblk = nullptr;           // lists in use
         int n_blk = 0, n_lblk = 0, n_sblk = 0;
     };
@@ -141,21 +146,35 @@ struct limo_ba_batch : Executor {
         return LIMO_OK;
     }
 
+    // Schur worklist over `windows` (all of them when null): first block of every group of `span` blocks of one class,
+    // ordered [plain groups of fast windows | ground-plane groups of fast windows | groups of generic windows];
+    // owner >= 0 keeps the blocks of that shard only.
+    void build_sblk_list(const std::vector<int32_t>* windows, int span, int owner, std::vector<int32_t>& v, int& n_plain, int& n_fgp) const {
+        v.clear();
+        n_plain = n_fgp = 0;
+        const int nw = windows ? (int)windows->size() : P.n_win;
+        for (int cls = 0; cls < 3; ++cls) {
+            for (int q = 0; q < nw; ++q) {
+                const int w = windows ? (*windows)[q] : q;
+                const WinDesc& d = P.win[w];
+                if ((cls < 2) != (win_fast[w] != 0)) continue;
+                auto groups = [&](int i0, int i1) {
+                    for (int i = i0; i < i1; i += span)
+                        if (owner < 0 || P.sblk_owner[d.sblk0 + i] == owner) v.push_back(d.sblk0 + i);
+                };
+                if (cls != 1) groups(0, d.n_sblk_plain);
+                if (cls != 0) groups(d.n_sblk_plain, d.n_sblk);
+            }
+            if (cls == 0) n_plain = (int)v.size();
+            if (cls == 1) n_fgp = (int)v.size() - n_plain;
+        }
+    }
+
     int upload() {
         std::memset(&bv, 0, sizeof(bv));
         win_fast.assign(P.n_win, 1);
-        for (int w = 0; w < P.n_win; ++w) {
-            const WinDesc& d = P.win[w];
-            int nfk = 0;
-            for (int k = 0; k < d.n_kf; ++k) {
-                const int32_t* cs = P.cslot.data() + (size_t)d.cam0 + (size_t)k * kCamSlots;
-                nfk += (cs[0] >= 0 || cs[6] >= 0) ? 1 : 0;
-                int nv = 0;
-                for (int v = 0; v < d.n_view; ++v) nv += P.view_kf[d.view0 + v] == d.kf0 + k;
-                if (nv > 1) win_fast[w] = 0;
-            }
-            if (nfk > 4) win_fast[w] = 0;
-        }
+        for (int w = 0; w < P.n_win; ++w) win_fast[w] = P.win[w].schur_fast ? 1 : 0;  // decided at pack time (kba_pack.cpp)
+        if (const char* e = std::getenv("KBA_SCHUR_PLAIN")) use_plain_kernel = std::atoi(e) != 0;
         // Every buffer of the batch view lives in ONE device block: [initialised buffers | zero-filled buffers].
         // Small batches (a single window) stage the initialised part in pinned host memory and upload it with one
         // copy; large ones copy buffer by buffer (no second host copy of hundreds of MB).  One memset for the rest.
@@ -233,13 +252,9 @@ struct limo_ba_batch : Executor {
                 };
                 if (make(P.blk_owner, &rl[i].full_blk, &rl[i].act_blk, &rl[i].n_full_blk)) return LIMO_ERR_RUNTIME;
                 if (make(P.lblk_owner, &rl[i].full_lblk, &rl[i].act_lblk, &rl[i].n_full_lblk)) return LIMO_ERR_RUNTIME;
-                {   // Schur blocks: the fast-variant windows first
+                {   // Schur blocks (span 1)
                     std::vector<int32_t> v;
-                    for (int pass = 1; pass >= 0; --pass) {
-                        for (size_t k = 0; k < P.sblk_owner.size(); ++k)
-                            if (P.sblk_owner[k] == r && win_fast[P.sblk_win[k]] == pass) v.push_back((int32_t)k);
-                        if (pass == 1) rl[i].n_full_sblk_fast = (int)v.size();
-                    }
+                    build_sblk_list(nullptr, 1, r, v, rl[i].n_full_sblk_plain, rl[i].n_full_sblk_fgp);
                     rl[i].n_full_sblk = (int)v.size();
                     if (dmalloc((void**)&rl[i].full_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
                     if (dmalloc((void**)&rl[i].act_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
@@ -261,14 +276,7 @@ struct limo_ba_batch : Executor {
         avg_sblk = P.n_win ? (P.n_sblk + P.n_win - 1) / P.n_win : 0;
         for (int k = 0; k < 3; ++k) {  // every window listed, for spans 1, 2, 4
             std::vector<int32_t> v;
-            for (int pass = 1; pass >= 0; --pass) {
-                for (int w = 0; w < P.n_win; ++w) {
-                    if (win_fast[w] != pass) continue;
-                    const WinDesc& d = P.win[w];
-                    for (int i = 0; i < d.n_sblk; i += (1 << k)) v.push_back(d.sblk0 + i);
-                }
-                if (pass == 1) n_wl_sblk_fast_full[k] = (int)v.size();
-            }
+            build_sblk_list(nullptr, 1 << k, -1, v, n_wl_sblk_plain_full[k], n_wl_sblk_fgp_full[k]);
             n_wl_sblk_full[k] = (int)v.size();
             if (dmalloc((void**)&d_wl_sblk_full[k], sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
             if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d_wl_sblk_full[k], v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
@@ -293,6 +301,14 @@ struct limo_ba_batch : Executor {
                 }
             }
             schur_T = std::max(t_fast, t_gen);
+            if (any_fast) {
+                int max_nfq = 0;
+                for (int w = 0; w < P.n_win; ++w)
+                    if (win_fast[w]) max_nfq = std::max(max_nfq, (int)P.win[w].nfq);
+                schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_plain<1> : (const void*)k_schur_plain<2>;
+                plain_lds_bytes = schur_plain_lds_bytes(max_nfq);
+                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_plain, hipFuncAttributeMaxDynamicSharedMemorySize, plain_lds_bytes));
+            }
             if (any_fast) {
                 schur_fn_fast = pick_schur(t_fast, true);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_fast, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
@@ -360,7 +376,8 @@ struct limo_ba_batch : Executor {
     int count_blk(size_t i) const { return shard_P > 1 ? rl[i].n_blk : n_wl_blk; }
     int count_lblk(size_t i) const { return shard_P > 1 ? rl[i].n_lblk : n_wl_lblk; }
     int count_sblk(size_t i) const { return shard_P > 1 ? rl[i].n_sblk : n_wl_sblk; }
-    int count_sblk_fast(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_fast : n_wl_sblk_fast; }
+    int count_sblk_plain(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_plain : n_wl_sblk_plain; }
+    int count_sblk_fgp(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_fgp : n_wl_sblk_fgp; }
     int shard_of(size_t i) const { return shard_P > 1 ? local_shards[i] : 0; }
 
     // Exchange step: sum the shards' partial arrays of `point` into the consumer view.
@@ -401,9 +418,11 @@ struct limo_ba_batch : Executor {
         const int k = c.schur_span == 4 ? 2 : c.schur_span == 2 ? 1 : 0;
         d_wl_sblk = d_wl_sblk_full[k];
         n_wl_sblk = n_wl_sblk_full[k];
-        n_wl_sblk_fast = n_wl_sblk_fast_full[k];
+        n_wl_sblk_plain = n_wl_sblk_plain_full[k];
+        n_wl_sblk_fgp = n_wl_sblk_fgp_full[k];
         for (RankLists& r : rl) {
-            r.n_sblk_fast = r.n_full_sblk_fast;
+            r.n_sblk_plain = r.n_full_sblk_plain;
+            r.n_sblk_fgp = r.n_full_sblk_fgp;
             r.blk = r.full_blk;
             r.lblk = r.full_lblk;
             r.sblk = r.full_sblk;
@@ -429,14 +448,7 @@ struct limo_ba_batch : Executor {
             for (int i = 0; i < d.n_lblk; ++i) wlb.push_back(d.lblk0 + i);
         }
         set_span((int)ww.size());
-        for (int pass = 1; pass >= 0; --pass) {
-            for (int w : ww) {
-                if (win_fast[w] != pass) continue;
-                const WinDesc& d = P.win[w];
-                for (int i = 0; i < d.n_sblk; i += c.schur_span) wsb.push_back(d.sblk0 + i);
-            }
-            if (pass == 1) n_wl_sblk_fast = (int)wsb.size();
-        }
+        build_sblk_list(&ww, c.schur_span, -1, wsb, n_wl_sblk_plain, n_wl_sblk_fgp);
         auto up = [&](int32_t* dst, const std::vector<int32_t>& v) {
             if (!v.empty()) note(hipMemcpyAsync(dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s), "upload worklist");
         };
@@ -456,15 +468,7 @@ struct limo_ba_batch : Executor {
                 for (int k = d.lblk0; k < d.lblk0 + d.n_lblk; ++k)
                     if (P.lblk_owner[k] == r) b2.push_back(k);
             }
-            for (int pass = 1; pass >= 0; --pass) {
-                for (int w : ww) {
-                    if (win_fast[w] != pass) continue;
-                    const WinDesc& d = P.win[w];
-                    for (int k = d.sblk0; k < d.sblk0 + d.n_sblk; ++k)
-                        if (P.sblk_owner[k] == r) b3.push_back(k);
-                }
-                if (pass == 1) rl[i].n_sblk_fast = (int)b3.size();
-            }
+            build_sblk_list(&ww, 1, r, b3, rl[i].n_sblk_plain, rl[i].n_sblk_fgp);
             up(rl[i].act_blk, b1);
             up(rl[i].act_lblk, b2);
             up(rl[i].act_sblk, b3);
@@ -574,16 +578,27 @@ struct limo_ba_batch : Executor {
         {
             EventPair* ep = timed(LIMO_KERNEL_SCHUR);
             for (size_t i = 0; i < pv.size(); ++i) {
-                const int n_fast = count_sblk_fast(i), n_gen = count_sblk(i) - n_fast;
+                int n_plain = count_sblk_plain(i), n_fgp = count_sblk_fgp(i);
+                const int n_gen = count_sblk(i) - n_plain - n_fgp;
                 int span = c.schur_span, dbg = c.pad;
-                if (n_fast) {
-                    const int32_t* wlp = list_sblk(i);
+                const int32_t* wlp = list_sblk(i);
+                if (!use_plain_kernel) {  // the general fast kernel takes the plain groups as well
+                    n_fgp += n_plain;
+                    n_plain = 0;
+                }
+                if (n_plain) {
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span};
+                    note(hipLaunchKernel(schur_fn_plain, dim3(n_plain), dim3(64), args, plain_lds_bytes, s), "launch k_schur_plain");
+                    LAUNCH_CHECK("k_schur_plain");
+                    wlp += n_plain;
+                }
+                if (n_fgp) {
                     void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
-                    note(hipLaunchKernel(schur_fn_fast, dim3(n_fast), dim3(64), args, max_ld_bytes, s), "launch k_schur");
+                    note(hipLaunchKernel(schur_fn_fast, dim3(n_fgp), dim3(64), args, max_ld_bytes, s), "launch k_schur");
                     LAUNCH_CHECK("k_schur");
+                    wlp += n_fgp;
                 }
                 if (n_gen) {
-                    const int32_t* wlp = list_sblk(i) + n_fast;
                     void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
                     note(hipLaunchKernel(schur_fn_gen, dim3(n_gen), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
                     LAUNCH_CHECK("k_schur");

@@ -83,8 +83,29 @@ def cross_termination(solve_a, solve_b, end_a, end_b, trimmed):
     return stays_put(solve_a, pb) and stays_put(solve_b, pa) and stays_put(solve_a, pa) and stays_put(solve_b, pb)
 
 
+def well_posed(w, min_obs=8):
+    """Every keyframe sees at least min_obs landmarks.  The sweep also draws windows that lose almost all landmarks to
+    the cheirality filter (depth_prob = 0 with noisy start poses: 0-6 landmarks for up to 11 keyframes); their poses
+    are not determined by the data (seed 123 window 250: both solvers park a keyframe 17-55 km away), so pose / cost
+    parity is not defined for them - they are checked for the properties every solve must have."""
+    if w.n_kf == 0 or w.n_obs == 0:
+        return False
+    return int(np.bincount(w.obs_kf, minlength=w.n_kf).min()) >= min_obs
+
+
 def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, solve_o):
     """x = the implementation under test, o = the oracle.  Returns (ok, detail string, used_cross_termination)."""
+    if not well_posed(w):
+        for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks"):
+            if rep_x[k] != rep_o[k]:
+                return False, "%s: %r != %r" % (k, rep_x[k], rep_o[k]), False
+        if abs(rep_x["initial_cost"] - rep_o["initial_cost"]) > 1e-9 * abs(rep_o["initial_cost"]):
+            return False, "initial cost differs", False
+        if not (rep_x["final_cost"] <= rep_x["initial_cost"] and np.isfinite(end_x.kf_pose).all() and np.isfinite(end_x.lm_pos).all()):
+            return False, "ill-posed window: cost increased or non-finite parameters", False
+        if not np.array_equal(end_x.kf_pose[0], w.kf_pose[0]):
+            return False, "Pose-fixed keyframe moved", False
+        return True, "ill-posed window (weak checks)", False
     for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks", "termination"):
         if rep_x[k] != rep_o[k]:
             return False, "%s: %r != %r" % (k, rep_x[k], rep_o[k]), False
