@@ -59,6 +59,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(view_kf, TV * I, P.view_kf.data());
     KBA_BUF(view_win, TV * I, P.view_win.data());
     KBA_BUF(view_cam, TV * 16 * D, P.view_cam.data());
+    KBA_BUF(view_lin, TV * kViewLin * D, nullptr);
     KBA_BUF(blk_view, NB * I, P.blk_view.data());
     KBA_BUF(blk_obs0, NB * I, P.blk_obs0.data());
     KBA_BUF(blk_n, NB * I, P.blk_n.data());

@@ -38,43 +38,127 @@ struct LinLane {
     double g[6];   // Jp^T r
 };
 
-// Lane t of linearize workgroup b: residuals + Jacobians of one observation at the CURRENT parameters.
-// (ACCUMULATES cost / fail / U / g into `out`: a GPU lane folds kObsPerLane observations before the reduction.)
+// Per-view constants of the current poses (one item per view, before the observations are linearised):
+//   vl[0..8] H = Rc R(q), vl[9..11] h0 = Rc t + tc (camera point = H p + h0), vl[12..20] Rc, vl[21..24] q, vl[25..27] f, cx, cy.
+// In k_linearize a workgroup holds observations of ONE view, so these are wave-uniform (scalar registers).
+KBA_HD void view_consts_item(const BatchView& bv, int view) {
+    const double* cam = bv.view_cam + 16 * (int64_t)view;
+    const double* pose = bv.pose + 7 * (int64_t)bv.view_kf[view];
+    double* vl = bv.view_lin + (int64_t)kViewLin * view;
+    double R[9];
+    quat_R(pose, R);
+    mat3_mul(cam + 4, R, vl);
+    for (int i = 0; i < 3; ++i)
+        vl[9 + i] = cam[4 + 3 * i] * pose[4] + cam[4 + 3 * i + 1] * pose[5] + cam[4 + 3 * i + 2] * pose[6] + cam[13 + i];
+    for (int i = 0; i < 9; ++i) vl[12 + i] = cam[4 + i];
+    for (int i = 0; i < 4; ++i) vl[21 + i] = pose[i];
+    vl[25] = cam[0];
+    vl[26] = cam[1];
+    vl[27] = cam[2];
+}
+
+// Inputs of one observation as the linearisation consumes them (a GPU lane fetches them one observation ahead).
+struct LinIn {
+    double p[3];  // landmark
+    double w;     // landmark weight
+    float u, v, d;
+    int live;     // landmark in the problem
+};
+
+KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
+    in.live = bv.lm_state[gl] != 0;
+    in.p[0] = bv.lm[3 * (int64_t)gl];
+    in.p[1] = bv.lm[3 * (int64_t)gl + 1];
+    in.p[2] = bv.lm[3 * (int64_t)gl + 2];
+    in.w = bv.lm_weight[gl];
+    in.u = bv.obs_u[o];
+    in.v = bv.obs_v[o];
+    in.d = bv.obs_d[o];
+}
+
+// One observation at the CURRENT parameters: residual r (3, loss-corrected), the four scalars c4 = (au, xn, yn, sd) of
+// the factored Jacobian (kba_math.hpp:ft_build) and the camera-side sums U += Jp^T Jp, g += Jp^T r with
+// Jp = Ft [M | I], Ft = c^T Rc.  Same arithmetic as obs_residual_jacobian (kba_math.hpp) with the per-view products
+// taken from vl (view_consts_item) and without the landmark-side Jacobian, which nobody reads here.
+// Returns false where the reference functor fails (|z| < 0.01).
+KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4,
+                    LinLane& out) {
+    const double* H = vl;
+    const double* Rc = vl + 12;
+    const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
+    const double z0 = H[0] * p0 + H[1] * p1 + H[2] * p2 + vl[9];
+    const double z1 = H[3] * p0 + H[4] * p1 + H[5] * p2 + vl[10];
+    const double z2 = H[6] * p0 + H[7] * p1 + H[8] * p2 + vl[11];
+    if (!(fabs(z2) >= 0.01)) return false;
+    const double f = vl[25];
+    const double iz = 1.0 / z2;
+    const double xn = z0 * iz, yn = z1 * iz;
+    const double ru = f * xn + vl[26] - static_cast<double>(in.u);
+    const double rv = f * yn + vl[27] - static_cast<double>(in.v);
+    const bool has_d = in.d > 0.0f;
+    const double rd = has_d ? z2 - static_cast<double>(in.d) : 0.0;
+    const double s_uv = ru * ru + rv * rv, s_d = rd * rd;
+    double su, sd = 0.0, cost = 0.0;
+    if (want_cost) {
+        double rho[3];
+        loss_cauchy(c.a_rep, in.w, s_uv, rho);
+        su = sqrt(rho[1]);
+        cost = 0.5 * rho[0];
+        if (has_d) {
+            loss_cauchy(c.a_dep, in.w, s_d, rho);
+            sd = sqrt(rho[1]);
+            cost += 0.5 * rho[0];
+        }
+    } else {
+        su = sqrt(loss_cauchy_d1(c.a_rep, in.w, s_uv));
+        if (has_d) sd = sqrt(loss_cauchy_d1(c.a_dep, in.w, s_d));
+    }
+    out.cost += cost;
+    const double r0 = su * ru, r1 = su * rv, r2 = sd * rd;
+    r3[0] = r0;
+    r3[1] = r1;
+    r3[2] = r2;
+    const double au = su * (f * iz);
+    c4[0] = au;
+    c4[1] = xn;
+    c4[2] = yn;
+    c4[3] = sd;
+    double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft]
+    for (int j = 0; j < 3; ++j) {
+        J[3 + j] = au * (Rc[0 + j] - xn * Rc[6 + j]);
+        J[9 + j] = au * (Rc[3 + j] - yn * Rc[6 + j]);
+        J[15 + j] = sd * Rc[6 + j];
+    }
+    double M[9];
+    rot_tangent_jac(vl + 21, in.p, M);
+    for (int row = 0; row < 3; ++row)
+        for (int j = 0; j < 3; ++j)
+            J[row * 6 + j] = J[row * 6 + 3] * M[j] + J[row * 6 + 4] * M[3 + j] + J[row * 6 + 5] * M[6 + j];
+    int k = 0;
+    for (int a = 0; a < 6; ++a) {
+        for (int bb = a; bb < 6; ++bb) out.U[k++] += J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
+        out.g[a] += J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
+    }
+    return true;
+}
+
+// Lane t of linearize workgroup b (ACCUMULATES cost / fail / U / g into `out`: a GPU lane folds kObsPerLane
+// observations before the reduction).  Plain form used by the CPU emulation; k_linearize runs the same lin_fetch /
+// lin_obs / stores software-pipelined.
 KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
     if (t >= bv.blk_n[b]) return;
     const int view = bv.blk_view[b];
     const int64_t o = bv.blk_obs0[b] + t;
-    const int gl = bv.obs_lm[o];
-    ObsOut oo;
-    bool live = bv.lm_state[gl] != 0;
-    bool ok = true;
-    if (live) {
-        const double* cam = bv.view_cam + 16 * (int64_t)view;
-        ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                                   bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
-                                   c.a_rep, c.a_dep, true, &oo, want_cost);
+    LinIn in;
+    lin_fetch(bv, o, bv.obs_lm[o], in);
+    double r3[3] = {0.0, 0.0, 0.0}, c4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (in.live && !lin_obs(bv.view_lin + (int64_t)kViewLin * view, c, in, want_cost, r3, c4, out)) {
+        for (int i = 0; i < 3; ++i) r3[i] = 0.0;
+        for (int i = 0; i < 4; ++i) c4[i] = 0.0;
+        out.fail = 1;
     }
-    if (!live || !ok) {
-        for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
-        for (int i = 0; i < 18; ++i) oo.Jp[i] = 0.0;
-        for (int i = 0; i < 9; ++i) oo.Jl[i] = 0.0;
-        for (int i = 0; i < 4; ++i) oo.c[i] = 0.0;
-        oo.cost = 0.0;
-        if (live) out.fail = 1;
-    }
-    if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
-        for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
-        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = oo.c[i];  // see BatchView::obs_c
-    } else if (oo.cost == 1.2345) {
-        bv.obs_r[o] = oo.r[0] + oo.Jp[3] + oo.Jl[4];
-    }
-    out.cost += oo.cost;
-    int k = 0;
-    for (int a = 0; a < 6; ++a) {
-        for (int bb = a; bb < 6; ++bb)
-            out.U[k++] += oo.Jp[a] * oo.Jp[bb] + oo.Jp[6 + a] * oo.Jp[6 + bb] + oo.Jp[12 + a] * oo.Jp[12 + bb];
-        out.g[a] += oo.Jp[a] * oo.r[0] + oo.Jp[6 + a] * oo.r[1] + oo.Jp[12 + a] * oo.r[2];
-    }
+    for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
+    for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
 }
 
 KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
@@ -351,21 +435,22 @@ KBA_HD void schur_load_lm(const BatchView& bv, int gl, double* lmk) {
     for (int i = 0; i < 6; ++i) lmk[i] = bv.lm_Li[i * bv.SL + gl];
 }
 
-// Partial slabs of a window: a wave takes `span` consecutive Schur blocks of ONE class (plain / ground-plane) and
-// writes one slab; plain groups come first.
+// Partial slabs of a window: a wave takes `span` consecutive plain Schur blocks or `span_gp` consecutive ground-plane
+// blocks and writes one slab; the slabs of the plain groups come first.
 KBA_HD int schur_plain_slabs(const WinDesc& wd, int span) { return (wd.n_sblk_plain + span - 1) / span; }
-KBA_HD int schur_slabs(const WinDesc& wd, int span) {
-    return schur_plain_slabs(wd, span) + (wd.n_sblk - wd.n_sblk_plain + span - 1) / span;
+KBA_HD int schur_slabs(const WinDesc& wd, int span, int span_gp) {
+    return schur_plain_slabs(wd, span) + (wd.n_sblk - wd.n_sblk_plain + span_gp - 1) / span_gp;
 }
-KBA_HD int schur_slab_of(const WinDesc& wd, int sb, int span) {
+KBA_HD int schur_slab_of(const WinDesc& wd, int sb, int span, int span_gp) {
     const int i = sb - wd.sblk0;
-    return i < wd.n_sblk_plain ? i / span : schur_plain_slabs(wd, span) + (i - wd.n_sblk_plain) / span;
+    return i < wd.n_sblk_plain ? i / span : schur_plain_slabs(wd, span) + (i - wd.n_sblk_plain) / span_gp;
 }
 // last block (inclusive) of the group that starts at block sb
-KBA_HD int schur_group_last(const WinDesc& wd, int sb, int span) {
+KBA_HD int schur_group_last(const WinDesc& wd, int sb, int span, int span_gp) {
     const int i = sb - wd.sblk0;
-    const int end = i < wd.n_sblk_plain ? wd.n_sblk_plain : wd.n_sblk;
-    return wd.sblk0 + (i + span < end ? i + span : end) - 1;
+    const bool plain = i < wd.n_sblk_plain;
+    const int end = plain ? wd.n_sblk_plain : wd.n_sblk, sp = plain ? span : span_gp;
+    return wd.sblk0 + (i + sp < end ? i + sp : end) - 1;
 }
 
 // Landmark-sharded solve: entry e of slab `shard` of S_red = sum over ALL partial slabs of the window in this shard's
@@ -1011,7 +1096,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     // the same share; a lane sums up to 4 entries at once, 4 slabs each: 16 independent loads in flight (one window
     // alone on the GPU is bound by exactly this latency chain).  Per entry the order of the sum stays q mod 4.
     const int n_need = nf * (nf + 1) / 2 + nf;
-    const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : schur_slabs(wd, c.schur_span);
+    const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : schur_slabs(wd, c.schur_span, c.schur_span_gp);
     for (int i0 = tid; i0 < n_need; i0 += 4 * nt) {
         double s[4], acc[4][4];
         int64_t off[4];

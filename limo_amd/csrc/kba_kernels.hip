@@ -76,13 +76,33 @@ __global__ void k_expire(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ observations
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
+// per-view constants of the current poses (kba_items.hpp:view_consts_item), one lane per view
+__global__ void k_view_consts(BatchView bv) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= bv.TV) return;
+    const WinState& st = bv.st[bv.view_win[v]];
+    if (!st.active || !st.need_lin) return;
+    view_consts_item(bv, v);
+}
+
+// Jacobian evaluation.  A workgroup holds <= 1024 observations of ONE view: the view's constants (H = Rc R, Rc, q,
+// intrinsics: 28 doubles) are wave-uniform and live in scalar registers; a lane takes 4 observations (consecutive lanes
+// -> consecutive observations in every pass) and accumulates the 27 camera-side sums in registers before the one
+// workgroup reduction.  The passes are software-pipelined: the observation index / measurement of pass q + 2 and the
+// gathered landmark of pass q + 1 are in flight while pass q computes (the kernel is bound by the dependent chain
+// index -> landmark gather -> ~450 fp64 operations, not by bytes).
+template <int WAVES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl ? wl[blockIdx.x] : blockIdx.x;
-    const int w = bv.view_win[bv.blk_view[b]];
+    const int view = bv.blk_view[b];
+    const int w = bv.view_win[view];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
     const bool want_cost = st.first != 0;  // workgroup-uniform
     __shared__ double lds[4 * kLinPartial];
+    const double* vl = bv.view_lin + (int64_t)kViewLin * view;
+    const int n = bv.blk_n[b];
+    const int64_t o0 = bv.blk_obs0[b];
     LinLane l;
     l.cost = 0.0;
     l.fail = 0;
@@ -90,9 +110,39 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     for (int i = 0; i < 21; ++i) l.U[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
-#pragma unroll 1
-    for (int q = 0; q < kObsPerLane; ++q)  // consecutive lanes take consecutive observations in every pass
-        linearize_lane_acc(bv, c, b, threadIdx.x + q * kBlock, l, want_cost);
+    const int t0 = threadIdx.x;
+    // stage A: landmark index of the observation (-1 past the end of the block); stage B: the gathered inputs
+    int gl_a = t0 < n ? bv.obs_lm[o0 + t0] : -1;
+    int gl_b = t0 + kBlock < n ? bv.obs_lm[o0 + t0 + kBlock] : -1;
+    LinIn cur;
+    cur.live = 0;
+    if (gl_a >= 0) lin_fetch(bv, o0 + t0, gl_a, cur);
+#pragma unroll
+    for (int q = 0; q < kObsPerLane; ++q) {
+        const int t = t0 + q * kBlock;
+        const int gl_n = gl_b;                     // landmark of pass q + 1
+        if (q + 2 < kObsPerLane) gl_b = t + 2 * kBlock < n ? bv.obs_lm[o0 + t + 2 * kBlock] : -1;
+        LinIn nxt;
+        nxt.live = 0;
+        if (q + 1 < kObsPerLane && gl_n >= 0) lin_fetch(bv, o0 + t + kBlock, gl_n, nxt);
+        if (t < n) {
+            double r3[3] = {0.0, 0.0, 0.0}, c4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (cur.live && !lin_obs(vl, c, cur, want_cost, r3, c4, l)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) r3[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = 0.0;
+                l.fail = 1;
+            }
+            if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o0 + t] = r3[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o0 + t] = c4[i];
+            }
+        }
+        cur = nxt;
+    }
     double vals[kLinPartial];
     vals[0] = l.cost;
 #pragma unroll
@@ -223,7 +273,7 @@ struct SchurPre {
 // FAST: every window of the batch has at most four keyframes with free slots and one view per keyframe (checked on
 // the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
 template <int TM, bool FAST>
-__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span, int dbg) {
+__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span, int span_gp, int dbg) {
     const int sb = wl[blockIdx.x];  // first Schur block of this wave (worklist entry, a multiple of span past wd.sblk0)
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
@@ -270,7 +320,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, kq = lane >> 4;
-    const int sb_last = schur_group_last(wd, sb, span);  // blocks of one class (plain / ground-plane) only
+    const int sb_last = schur_group_last(wd, sb, span, span_gp);  // blocks of one class (plain / ground-plane) only
     const int lm_first = bv.sblk_lm0[sb];
     const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
 
@@ -418,7 +468,7 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
         }
         __syncthreads();
     }
-    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span) * ((int64_t)nfp * nfp);
+    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span, span_gp) * ((int64_t)nfp * nfp);
     int idx = 0;
 #pragma unroll
     for (int tr = 0; tr < TM; ++tr)
@@ -436,45 +486,50 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, i
 }
 
 
-// ------------------------------------------------------------------------------------------ Schur complement, plain blocks
-// k_schur_plain<TQ>: the Schur blocks of landmarks WITHOUT a ground-plane row (about 80 % of a window) of the fast
-// class (WinDesc::schur_fast: <= 4 free keyframes, one view each).  Their tiles only touch the pose columns, so the
-// kernel is sized for exactly that and for OCCUPANCY (the general kernel above runs 2 waves / SIMD on 248 registers and
-// 18.8 KB of LDS; its per-tile chain fill -> LDS -> 12 k-steps is latency-bound):
-//   * Z tile [48][ld] with ld = nfq + 1 (25 columns for four free keyframes, odd): 9.6 KB.  Panel reads past column
-//     nfq run into the next row - finite values that only reach output entries nobody reads (masked to zero at the
-//     store) - so no padding columns exist;
-//   * TQ (1 or 2) panels -> 1 or 3 accumulator tiles (24 AGPRs) instead of 6;
-//   * keyframe constants (R, Rc, q, scale, columns) sit in LDS, the landmark-side inputs of ONE tile in registers: the
-//     loads of the next tile are issued right after the fill and complete under the 36 MFMAs of the current one.
-// One wave per workgroup, no cross-wave synchronisation; `span` consecutive plain blocks of a window per wave.
+// ------------------------------------------------------------------------------------------ Schur complement, lean kernel
+// k_schur_lean<TM, GP>: the Schur blocks of the fast class (WinDesc::schur_fast: <= 4 free keyframes, one view each),
+// sized for OCCUPANCY - the general kernel above runs 2 waves / SIMD on ~250 registers and 18.8 KB of LDS and its
+// per-tile chain fill -> LDS -> 12 k-steps is latency-bound.
+//   GP = false: blocks of landmarks WITHOUT a ground-plane row (about 80 % of a window).  Their tiles only touch the
+//               pose columns [0, nfq]: Z tile [48][nfq + 1] (25 columns for four free keyframes: 9.6 KB), TM <= 2 panels
+//               -> 3 accumulator tiles, 128 registers -> 4 waves / SIMD;
+//   GP = true : blocks of landmarks WITH a ground-plane row: all nf + 1 columns, TM <= 3 panels -> 6 accumulator tiles.
+//   * No padding columns: a panel read past the last column runs into the next row - finite values that only reach
+//     output entries nobody reads (masked to zero at the store).
+//   * Keyframe constants (R, Rc, q, scales, columns) sit in LDS; the landmark-side inputs of ONE tile in registers: the
+//     loads of the next tile are issued right after the fill and complete under the MFMAs of the current one; the
+//     indices (slot, state, ground-plane row) are fetched two tiles ahead.
+// One wave per workgroup, no cross-wave synchronisation; `span` consecutive blocks of one class per wave.
 constexpr int kSpBatch = 4;  // k-steps whose panel reads are in flight together
-constexpr int kSpKf = 28;  // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of the pose slots (6)
+constexpr int kSpKf = 32;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots
 
-__host__ __device__ inline int schur_plain_lds_bytes(int nfq) {
-    return (3 * kSchurLm * (nfq + 1) + 16 + 4 * kSpKf) * (int)sizeof(double) + 4 * 8 * (int)sizeof(int);
+__host__ __device__ inline int schur_lean_ld(int ncol) { return ncol | 1; }  // odd row stride: conflict-free fill
+__host__ __device__ inline int schur_lean_lds_bytes(int ncol) {
+    return (3 * kSchurLm * schur_lean_ld(ncol) + 16 + 4 * kSpKf) * (int)sizeof(double) + 4 * 12 * (int)sizeof(int);
 }
 
-template <int TQ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_schur_plain(BatchView bv, const int32_t* wl, int span) {
+template <int TM, bool GP, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(BatchView bv, const int32_t* wl, int span, int span_gp) {
     const int sb = wl[blockIdx.x];
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
-    const int nfq = wd.nfq, nfp = wd.nf_pad, ld = nfq + 1;  // nfq is a multiple of 6: ld is odd
-    const int Tq = (nfq + 16) / 16;
+    const int nfq = wd.nfq, nfp = wd.nf_pad;
+    const int ncol = GP ? wd.nf + 1 : nfq + 1;  // columns of the tile, the rhs (column nfq) included
+    const int ld = schur_lean_ld(ncol);
+    const int Tt = (ncol + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Z = smem;                                   // [48][ld] + 16 zeros (the last row's panel overrun)
     double* kc = Z + 3 * kSchurLm * ld + 16;            // [4][kSpKf]
-    int* zcs = reinterpret_cast<int*>(kc + 4 * kSpKf);  // [4][8] tile column of the pose slots (or -1)
+    int* zcs = reinterpret_cast<int*>(kc + 4 * kSpKf);  // [4][12] tile column of the keyframe's slots (or -1)
     const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
     const int n_fk = wd.n_fk;
-    int my_view = -1;
+    int my_view = -1, my_kl = -1;
     if (kq < n_fk) {
-        const int kl = wd.fk[kq];
+        my_kl = wd.fk[kq];
         my_view = wd.fk_view[kq];
         double* mine = kc + kq * kSpKf;
-        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + kl);
+        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + my_kl);
         if (li == 0) {
             double R[9];
             quat_R(pose, R);
@@ -484,47 +539,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int i = 0; i < 4; ++i) mine[18 + i] = pose[i];
         } else if (li < 10) {
             mine[9 + li - 1] = my_view >= 0 ? bv.view_cam[16 * (int64_t)my_view + 4 + li - 1] : 0.0;
-        } else {
-            const int a = li - 10, slot = wd.cam0 + kl * kCamSlots + a;
-            mine[22 + a] = bv.scale_c[slot];
-            zcs[kq * 8 + a] = bv.cslot[slot];  // pose slots: compact index == tile column (< nfq)
+        }
+        if (li < kCamSlots) {
+            const int slot = wd.cam0 + my_kl * kCamSlots + li;
+            mine[22 + li] = bv.scale_c[slot];
+            const int ci = bv.cslot[slot];
+            zcs[kq * 12 + li] = ci < 0 ? -1 : schur_col(ci, nfq);
         }
     }
     if (lane < 16) Z[3 * kSchurLm * ld + lane] = 0.0;
     __syncthreads();
-    const bool have = kq < n_fk && zcs[kq * 8] >= 0 && my_view >= 0;
+    const bool have = kq < n_fk && zcs[kq * 12] >= 0;  // the keyframe's pose block is free (its six slots together)
     const double* mine = kc + (kq < n_fk ? kq : 0) * kSpKf;
     const int32_t* my_slots = bv.lm_slot + (int64_t)(my_view >= 0 ? my_view - wd.view0 : 0) * bv.SL;
-    const int sb_last = schur_group_last(wd, sb, span);
+    const int sb_last = schur_group_last(wd, sb, span, span_gp);
     const int lm_first = bv.sblk_lm0[sb];
     const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
 
-    constexpr int NT = TQ * (TQ + 1) / 2;
+    constexpr int NT = TM * (TM + 1) / 2;
     v4f64 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    // software pipeline: slot / state of the tile after next, inputs of the next tile
-    auto fetch_index = [&](int l0, int& st, int& slot) {
+    // ---- software pipeline
+    // stage 1 (two tiles ahead): landmark state, observation slot in this lane's keyframe, ground-plane row attached to it
+    auto fetch_index = [&](int l0, int& st, int& slot, int& gg) {
         st = 0;
         slot = -1;
+        gg = -1;
         if (l0 + li < n_lm_blk) {
             const int gl = lm_first + l0 + li;
             st = bv.lm_state[gl];
-            if (have) slot = my_slots[gl];
+            if (have && my_view >= 0) slot = my_slots[gl];
+            if (GP && have && st == 1) {
+                const int g = bv.lm_gp[gl];
+                if (g >= 0 && bv.gp_kf[g] - wd.kf0 == my_kl) gg = g;
+            }
         }
     };
-    double c4[4], p[3], Bt[6], t3[3];
-    bool live = false, seen = false;
-    auto fetch_data = [&](int l0, int st, int slot) {
+    // stage 2 (one tile ahead): the landmark-side inputs
+    double c4[4], p[3], Bt[6], t3[3], gE[3], gF[kCamSlots];
+    bool live = false, seen = false, att = false;
+    auto fetch_data = [&](int l0, int st, int slot, int gg) {
         const int gl = lm_first + l0 + li;
         live = st == 1;
         seen = live && slot >= 0;
+        att = GP && live && gg >= 0;
         if (seen) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + slot];
 #pragma unroll
             for (int i = 0; i < 3; ++i) p[i] = bv.lm[3 * (int64_t)gl + i];
+        }
+        if (seen || att) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];
         }
@@ -532,49 +599,80 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
             for (int i = 0; i < 3; ++i) t3[i] = bv.lm_t[i * bv.SL + gl];
         }
+        if constexpr (GP) {
+            if (att) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gE[i] = bv.gp_E[i * bv.SG + gg];
+#pragma unroll
+                for (int i = 0; i < kCamSlots; ++i) gF[i] = bv.gp_F[i * bv.SG + gg];
+            }
+        }
     };
-    int n_st, n_slot;
+    int n_st, n_slot, n_gg;
     {
-        int st0, slot0;
-        fetch_index(0, st0, slot0);
-        fetch_index(kSchurLm, n_st, n_slot);
-        fetch_data(0, st0, slot0);
+        int st0, slot0, gg0;
+        fetch_index(0, st0, slot0, gg0);
+        fetch_index(kSchurLm, n_st, n_slot, n_gg);
+        fetch_data(0, st0, slot0, gg0);
     }
+    constexpr int NS = GP ? kCamSlots : 6;  // slots of a keyframe this kernel fills
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
-        // ---- fill: this lane's 3 x 6 block of Y' (zeros where the landmark is not observed by the keyframe)
+        // ---- fill: this lane's 3 x NS block of Y' (zeros where the landmark has no row with the keyframe)
         if (kq == 0) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? t3[cc] : 0.0;
         }
         if (have) {
-            double Y[18];
+            double Y[3 * NS];
 #pragma unroll
-            for (int i = 0; i < 18; ++i) Y[i] = 0.0;
+            for (int i = 0; i < 3 * NS; ++i) Y[i] = 0.0;
             if (seen) {
                 double M[9], Ft[9];
                 rot_tangent_jac(mine + 18, p, M);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block(Ft, mine, M, Bt, mine + 22, Y);
             }
-            const int zc0 = zcs[kq * 8];  // the six pose slots of a keyframe are consecutive columns
-            double* zrow = Z + 3 * li * ld + zc0;
+            if constexpr (GP) {
+                if (att) {  // the landmark's ground-plane row hangs on this keyframe: rank-one term over its free slots
+                    const double y0 = gE[0] * Bt[0], y1 = gE[0] * Bt[1] + gE[1] * Bt[2], y2 = gE[0] * Bt[3] + gE[1] * Bt[4] + gE[2] * Bt[5];
+#pragma unroll
+                    for (int a = 0; a < kCamSlots; ++a) {
+                        const double fa = zcs[kq * 12 + a] >= 0 ? gF[a] * mine[22 + a] : 0.0;
+                        Y[a * 3 + 0] += fa * y0;
+                        Y[a * 3 + 1] += fa * y1;
+                        Y[a * 3 + 2] += fa * y2;
+                    }
+                }
+            }
+            double* zrow = Z + 3 * li * ld + zcs[kq * 12];  // the six pose slots of a keyframe are consecutive columns
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 zrow[a] = Y[a * 3 + 0];
                 zrow[ld + a] = Y[a * 3 + 1];
                 zrow[2 * ld + a] = Y[a * 3 + 2];
             }
+            if constexpr (GP) {
+#pragma unroll
+                for (int a = 6; a < kCamSlots; ++a) {
+                    const int zc = zcs[kq * 12 + a];
+                    if (zc >= 0) {
+                        Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
+                        Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
+                        Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
+                    }
+                }
+            }
         }
-        // ---- loads of the next tile (complete under the MFMAs below), indices of the one after
+        // ---- loads of the next tile (they complete under the MFMAs below), indices of the one after
         {
-            const int st = n_st, slot = n_slot;
-            fetch_index(l0 + 2 * kSchurLm, n_st, n_slot);
-            fetch_data(l0 + kSchurLm, st, slot);
+            const int st = n_st, slot = n_slot, gg = n_gg;
+            fetch_index(l0 + 2 * kSchurLm, n_st, n_slot, n_gg);
+            fetch_data(l0 + kSchurLm, st, slot, gg);
         }
         __syncthreads();
-        // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps
+        // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps, upper tiles
         const double* zp = Z + kq * ld + li;
-        if (TQ == 1 || Tq == 1) {  // wave-uniform
+        if (TM == 1 || Tt == 1) {  // wave-uniform
 #pragma unroll
             for (int h = 0; h < 12; h += kSpBatch) {
                 double pa[kSpBatch];
@@ -583,46 +681,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
                 for (int j = 0; j < kSpBatch; ++j) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
             }
-        } else if constexpr (TQ > 1) {
-            // the panel reads of kSpBatch k-steps are issued together, the 3 * kSpBatch MFMAs follow back to back
+        } else if (TM == 2 || Tt == 2) {
+            if constexpr (TM >= 2) {
+                // tile order of acc for TM panels: (0,0) (0,1) .. (0,TM-1) (1,1) ..
+                constexpr int i11 = TM;
 #pragma unroll
-            for (int h = 0; h < 12; h += kSpBatch) {
-                double pa[kSpBatch], pb[kSpBatch];
+                for (int h = 0; h < 12; h += kSpBatch) {
+                    double pa[kSpBatch], pb[kSpBatch];
 #pragma unroll
-                for (int j = 0; j < kSpBatch; ++j) {
-                    pa[j] = zp[(h + j) * 4 * ld];
-                    pb[j] = zp[(h + j) * 4 * ld + 16];
+                    for (int j = 0; j < kSpBatch; ++j) {
+                        pa[j] = zp[(h + j) * 4 * ld];
+                        pb[j] = zp[(h + j) * 4 * ld + 16];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSpBatch; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pb[j], acc[1], 0, 0, 0);
+                        acc[i11] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[j], pb[j], acc[i11], 0, 0, 0);
+                    }
                 }
+            }
+        } else {
+            if constexpr (TM >= 3) {
 #pragma unroll
-                for (int j = 0; j < kSpBatch; ++j) {
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pb[j], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[j], pb[j], acc[2], 0, 0, 0);
+                for (int h = 0; h < 12; h += 2) {
+                    double pn[2][3];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) pn[j][t] = zp[(h + j) * 4 * ld + 16 * t];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][0], pn[j][0], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][0], pn[j][1], acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][0], pn[j][2], acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][1], pn[j][1], acc[3], 0, 0, 0);
+                        acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][1], pn[j][2], acc[4], 0, 0, 0);
+                        acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[j][2], pn[j][2], acc[5], 0, 0, 0);
+                    }
                 }
             }
         }
         __syncthreads();
     }
-    // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix; entries outside [0, nfq]^2 are zero for plain
-    //      landmarks (and must be written: a slab may have belonged to a ground-plane group at another granularity)
-    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span) * ((int64_t)nfp * nfp);
+    // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix.  Entries outside the tile's columns are zero
+    //      for these landmarks and must be written: the slab may have belonged to a group of the other class at
+    //      another granularity.
+    double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span, span_gp) * ((int64_t)nfp * nfp);
     const int T = nfp / 16;
     int idx = 0;
 #pragma unroll
-    for (int tr = 0; tr < TQ; ++tr)
+    for (int tr = 0; tr < TM; ++tr)
 #pragma unroll
-        for (int tc = tr; tc < TQ; ++tc) {
+        for (int tc = tr; tc < TM; ++tc) {
             if (tc < T) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
                     const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
-                    out[row * nfp + col] = (row <= nfq && col <= nfq) ? acc[idx][r] : 0.0;
+                    out[row * nfp + col] = (row < ncol && col < ncol) ? acc[idx][r] : 0.0;
                 }
             }
             ++idx;
         }
-    for (int tc = TQ; tc < T; ++tc)
+    for (int tc = TM; tc < T; ++tc)
         for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;

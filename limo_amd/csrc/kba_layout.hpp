@@ -19,6 +19,7 @@ namespace kba {
 
 constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimization_window of the KITTI launch = 12)
 constexpr int kMaxViews = 64;     // max (keyframe, camera) views per window (LDS tables of the Schur kernels)
+constexpr int kViewLin = 32;      // doubles per view in BatchView::view_lin
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
@@ -103,7 +104,8 @@ struct SolveConsts {  // subset of limo_ba_options the kernels need
     int32_t max_invalid, jacobi_scaling;
     double depth_quantile, reprojection_quantile;
     int32_t min_groups, pad;
-    int32_t schur_span;   // Schur blocks per wave in this iteration (slab q of a window covers blocks [q*span, ..))
+    int32_t schur_span;   // plain Schur blocks per wave in this iteration (kba_items.hpp:schur_slab_of)
+    int32_t schur_span_gp;  // ground-plane Schur blocks per wave
     int32_t schur_nslab;  // > 0: landmark-sharded solve - k_cam_solve sums this many per-shard slabs from S_red instead
 };
 
@@ -135,6 +137,8 @@ struct BatchView {
     const int32_t* view_kf;     // [TV] global keyframe index
     const int32_t* view_win;    // [TV]
     const double* view_cam;     // [TV*16] f,cx,cy,pad, Rc[9], tc[3]
+    double* view_lin;           // [TV*kViewLin] per-view constants of the CURRENT poses (k_view_consts): H = Rc R(q) (9),
+                                // h0 = Rc t + tc (3), Rc (9), q (4), f, cx, cy - wave-uniform operands of k_linearize
     const int32_t* blk_view;    // [n_blk]
     const int32_t* blk_obs0;    // [n_blk]
     const int32_t* blk_n;       // [n_blk]

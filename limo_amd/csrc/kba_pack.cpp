@@ -42,6 +42,7 @@ SolveConsts make_consts(const limo_ba_options& o) {
     c.reprojection_quantile = o.reprojection_quantile;
     c.min_groups = o.minimum_number_residual_groups;
     c.schur_span = 1;
+    c.schur_span_gp = 1;
     if (const char* e = std::getenv("KBA_DEBUG_STAGE")) c.pad = std::atoi(e);  // profiling aid only
     return c;
 }

@@ -62,15 +62,19 @@ struct limo_ba_batch : Executor {
     // active set has halved, so late LM iterations only launch the workgroups that have work
     int32_t *d_wl_blk = nullptr, *d_wl_lblk = nullptr, *d_wl_sblk = nullptr, *d_wl_win = nullptr, *d_flags = nullptr;
     int32_t* d_wl_sblk_part = nullptr;                          // Schur worklist of a re-batched active set
-    int32_t* d_wl_sblk_full[3] = {nullptr, nullptr, nullptr};   // ... of every window, for spans 1, 2, 4
+    struct FullSblk {  // Schur worklist of every window for one (span, span_gp), built on first use
+        int32_t* d = nullptr;
+        int n = 0, n_plain = 0, n_fgp = 0;
+    };
+    std::map<std::pair<int, int>, FullSblk> wl_sblk_full;
     // Schur worklists are ordered [plain groups of fast windows | ground-plane groups of fast windows | generic windows]
-    int n_wl_sblk_full[3] = {0, 0, 0};
-    int n_wl_sblk_plain_full[3] = {0, 0, 0};  // leading entries: plain groups of fast-class windows (k_schur_plain)
-    int n_wl_sblk_fgp_full[3] = {0, 0, 0};    // then: ground-plane groups of fast-class windows (k_schur<T, true>)
     int n_wl_sblk_plain = 0, n_wl_sblk_fgp = 0;
     bool use_plain_kernel = true;             // KBA_SCHUR_PLAIN=0: plain groups go through k_schur<T, true> too (A/B timing)
     const void* schur_fn_plain = nullptr;
     int plain_lds_bytes = 0;
+    bool use_lean_gp = true;                  // KBA_SCHUR_GP_LEAN=0: ground-plane groups through k_schur<T, true> (A/B timing)
+    const void* schur_fn_leangp = nullptr;
+    int leangp_lds_bytes = 0;
     std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
     int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
@@ -149,7 +153,7 @@ struct limo_ba_batch : Executor {
     // Schur worklist over `windows` (all of them when null): first block of every group of `span` blocks of one class,
     // ordered [plain groups of fast windows | ground-plane groups of fast windows | groups of generic windows];
     // owner >= 0 keeps the blocks of that shard only.
-    void build_sblk_list(const std::vector<int32_t>* windows, int span, int owner, std::vector<int32_t>& v, int& n_plain, int& n_fgp) const {
+    void build_sblk_list(const std::vector<int32_t>* windows, int span, int span_gp, int owner, std::vector<int32_t>& v, int& n_plain, int& n_fgp) const {
         v.clear();
         n_plain = n_fgp = 0;
         const int nw = windows ? (int)windows->size() : P.n_win;
@@ -158,12 +162,12 @@ struct limo_ba_batch : Executor {
                 const int w = windows ? (*windows)[q] : q;
                 const WinDesc& d = P.win[w];
                 if ((cls < 2) != (win_fast[w] != 0)) continue;
-                auto groups = [&](int i0, int i1) {
-                    for (int i = i0; i < i1; i += span)
+                auto groups = [&](int i0, int i1, int sp) {
+                    for (int i = i0; i < i1; i += sp)
                         if (owner < 0 || P.sblk_owner[d.sblk0 + i] == owner) v.push_back(d.sblk0 + i);
                 };
-                if (cls != 1) groups(0, d.n_sblk_plain);
-                if (cls != 0) groups(d.n_sblk_plain, d.n_sblk);
+                if (cls != 1) groups(0, d.n_sblk_plain, span);
+                if (cls != 0) groups(d.n_sblk_plain, d.n_sblk, span_gp);
             }
             if (cls == 0) n_plain = (int)v.size();
             if (cls == 1) n_fgp = (int)v.size() - n_plain;
@@ -254,7 +258,7 @@ struct limo_ba_batch : Executor {
                 if (make(P.lblk_owner, &rl[i].full_lblk, &rl[i].act_lblk, &rl[i].n_full_lblk)) return LIMO_ERR_RUNTIME;
                 {   // Schur blocks (span 1)
                     std::vector<int32_t> v;
-                    build_sblk_list(nullptr, 1, r, v, rl[i].n_full_sblk_plain, rl[i].n_full_sblk_fgp);
+                    build_sblk_list(nullptr, 1, 1, r, v, rl[i].n_full_sblk_plain, rl[i].n_full_sblk_fgp);
                     rl[i].n_full_sblk = (int)v.size();
                     if (dmalloc((void**)&rl[i].full_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
                     if (dmalloc((void**)&rl[i].act_sblk, sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
@@ -274,13 +278,6 @@ struct limo_ba_batch : Executor {
         if (dmalloc((void**)&d_wl_lblk, sizeof(int32_t) * std::max(1, P.n_lblk))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_wl_sblk_part, sizeof(int32_t) * std::max(1, P.n_sblk))) return LIMO_ERR_RUNTIME;
         avg_sblk = P.n_win ? (P.n_sblk + P.n_win - 1) / P.n_win : 0;
-        for (int k = 0; k < 3; ++k) {  // every window listed, for spans 1, 2, 4
-            std::vector<int32_t> v;
-            build_sblk_list(nullptr, 1 << k, -1, v, n_wl_sblk_plain_full[k], n_wl_sblk_fgp_full[k]);
-            n_wl_sblk_full[k] = (int)v.size();
-            if (dmalloc((void**)&d_wl_sblk_full[k], sizeof(int32_t) * std::max<size_t>(1, v.size()))) return LIMO_ERR_RUNTIME;
-            if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d_wl_sblk_full[k], v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
-        }
         if (dmalloc((void**)&d_wl_win, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_flags, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
@@ -305,9 +302,17 @@ struct limo_ba_batch : Executor {
                 int max_nfq = 0;
                 for (int w = 0; w < P.n_win; ++w)
                     if (win_fast[w]) max_nfq = std::max(max_nfq, (int)P.win[w].nfq);
-                schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_plain<1> : (const void*)k_schur_plain<2>;
-                plain_lds_bytes = schur_plain_lds_bytes(max_nfq);
+                int max_nf = 0;
+                for (int w = 0; w < P.n_win; ++w)
+                    if (win_fast[w]) max_nf = std::max(max_nf, (int)P.win[w].nf);
+                schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_lean<1, false, 4> : (const void*)k_schur_lean<2, false, 4>;
+                plain_lds_bytes = schur_lean_lds_bytes(max_nfq + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_plain, hipFuncAttributeMaxDynamicSharedMemorySize, plain_lds_bytes));
+                const int tg = (max_nf + 16) / 16;
+                schur_fn_leangp = tg <= 1 ? (const void*)k_schur_lean<1, true, 3> : tg == 2 ? (const void*)k_schur_lean<2, true, 2> : (const void*)k_schur_lean<3, true, 2>;
+                leangp_lds_bytes = schur_lean_lds_bytes(max_nf + 1);
+                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_leangp, hipFuncAttributeMaxDynamicSharedMemorySize, leangp_lds_bytes));
+                if (const char* e = std::getenv("KBA_SCHUR_GP_LEAN")) use_lean_gp = std::atoi(e) != 0;
             }
             if (any_fast) {
                 schur_fn_fast = pick_schur(t_fast, true);
@@ -365,7 +370,11 @@ struct limo_ba_batch : Executor {
     void set_span(int n_windows_listed) {
         const int64_t coarse_waves = (int64_t)n_windows_listed * std::max(1, avg_sblk) / 4;
         c.schur_span = coarse_waves >= 2048 ? 4 : coarse_waves >= 1024 ? 2 : 1;
-        if (shard_P > 1) c.schur_span = 1;  // Schur blocks are cut at shard boundaries
+        // ground-plane groups: a fifth of the landmarks, twice the MFMA work per tile, at 2 waves / SIMD in the general
+        // kernel: keep them fine-grained (many short waves) unless the chip is very full
+        c.schur_span_gp = coarse_waves >= 8192 ? 2 : 1;
+        if (const char* e = std::getenv("KBA_SPAN_GP")) c.schur_span_gp = std::max(1, std::atoi(e));
+        if (shard_P > 1) c.schur_span = c.schur_span_gp = 1;  // Schur blocks are cut at shard boundaries
         c.schur_nslab = shard_P > 1 ? shard_P : 0;
     }
 
@@ -415,11 +424,18 @@ struct limo_ba_batch : Executor {
         n_wl_win = P.n_win;
         listed = P.n_win;
         set_span(P.n_win);
-        const int k = c.schur_span == 4 ? 2 : c.schur_span == 2 ? 1 : 0;
-        d_wl_sblk = d_wl_sblk_full[k];
-        n_wl_sblk = n_wl_sblk_full[k];
-        n_wl_sblk_plain = n_wl_sblk_plain_full[k];
-        n_wl_sblk_fgp = n_wl_sblk_fgp_full[k];
+        FullSblk& fl = wl_sblk_full[{c.schur_span, c.schur_span_gp}];
+        if (!fl.d) {
+            std::vector<int32_t> v;
+            build_sblk_list(nullptr, c.schur_span, c.schur_span_gp, -1, v, fl.n_plain, fl.n_fgp);
+            fl.n = (int)v.size();
+            if (dmalloc((void**)&fl.d, sizeof(int32_t) * std::max<size_t>(1, v.size())) == LIMO_OK && !v.empty())
+                note(hipMemcpy(fl.d, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice), "upload Schur worklist");
+        }
+        d_wl_sblk = fl.d;
+        n_wl_sblk = fl.n;
+        n_wl_sblk_plain = fl.n_plain;
+        n_wl_sblk_fgp = fl.n_fgp;
         for (RankLists& r : rl) {
             r.n_sblk_plain = r.n_full_sblk_plain;
             r.n_sblk_fgp = r.n_full_sblk_fgp;
@@ -448,7 +464,7 @@ struct limo_ba_batch : Executor {
             for (int i = 0; i < d.n_lblk; ++i) wlb.push_back(d.lblk0 + i);
         }
         set_span((int)ww.size());
-        build_sblk_list(&ww, c.schur_span, -1, wsb, n_wl_sblk_plain, n_wl_sblk_fgp);
+        build_sblk_list(&ww, c.schur_span, c.schur_span_gp, -1, wsb, n_wl_sblk_plain, n_wl_sblk_fgp);
         auto up = [&](int32_t* dst, const std::vector<int32_t>& v) {
             if (!v.empty()) note(hipMemcpyAsync(dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, s), "upload worklist");
         };
@@ -468,7 +484,7 @@ struct limo_ba_batch : Executor {
                 for (int k = d.lblk0; k < d.lblk0 + d.n_lblk; ++k)
                     if (P.lblk_owner[k] == r) b2.push_back(k);
             }
-            build_sblk_list(&ww, 1, r, b3, rl[i].n_sblk_plain, rl[i].n_sblk_fgp);
+            build_sblk_list(&ww, 1, 1, r, b3, rl[i].n_sblk_plain, rl[i].n_sblk_fgp);
             up(rl[i].act_blk, b1);
             up(rl[i].act_lblk, b2);
             up(rl[i].act_sblk, b3);
@@ -517,10 +533,20 @@ struct limo_ba_batch : Executor {
     void linearize() override {
         hipStream_t s = ctx->stream;
         {
+            if (P.TV) {
+                hipLaunchKernelGGL(k_view_consts, dim3(cdiv(P.TV, 256)), dim3(256), 0, s, bv);
+                LAUNCH_CHECK("k_view_consts");
+            }
             EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
+            static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;  // A/B timing aid
             for (size_t i = 0; i < pv.size(); ++i)
                 if (count_blk(i)) {
-                    hipLaunchKernelGGL(k_linearize, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
+                    if (lin_waves == 2)
+                        hipLaunchKernelGGL(k_linearize<2>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
+                    else if (lin_waves == 4)
+                        hipLaunchKernelGGL(k_linearize<4>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
+                    else
+                        hipLaunchKernelGGL(k_linearize<3>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
                     LAUNCH_CHECK("k_linearize");
                 }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
@@ -580,26 +606,31 @@ struct limo_ba_batch : Executor {
             for (size_t i = 0; i < pv.size(); ++i) {
                 int n_plain = count_sblk_plain(i), n_fgp = count_sblk_fgp(i);
                 const int n_gen = count_sblk(i) - n_plain - n_fgp;
-                int span = c.schur_span, dbg = c.pad;
+                int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
                 const int32_t* wlp = list_sblk(i);
                 if (!use_plain_kernel) {  // the general fast kernel takes the plain groups as well
                     n_fgp += n_plain;
                     n_plain = 0;
                 }
                 if (n_plain) {
-                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span};
-                    note(hipLaunchKernel(schur_fn_plain, dim3(n_plain), dim3(64), args, plain_lds_bytes, s), "launch k_schur_plain");
-                    LAUNCH_CHECK("k_schur_plain");
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp};
+                    note(hipLaunchKernel(schur_fn_plain, dim3(n_plain), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
+                    LAUNCH_CHECK("k_schur_lean");
                     wlp += n_plain;
                 }
-                if (n_fgp) {
-                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
+                if (n_fgp && use_lean_gp && use_plain_kernel) {
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp};
+                    note(hipLaunchKernel(schur_fn_leangp, dim3(n_fgp), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");
+                    LAUNCH_CHECK("k_schur_lean (gp)");
+                    wlp += n_fgp;
+                } else if (n_fgp) {
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
                     note(hipLaunchKernel(schur_fn_fast, dim3(n_fgp), dim3(64), args, max_ld_bytes, s), "launch k_schur");
                     LAUNCH_CHECK("k_schur");
                     wlp += n_fgp;
                 }
                 if (n_gen) {
-                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&dbg};
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
                     note(hipLaunchKernel(schur_fn_gen, dim3(n_gen), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
                     LAUNCH_CHECK("k_schur");
                 }

@@ -109,6 +109,10 @@ struct EmuBatch : Executor {
     }
 
     void linearize() override {
+        for (int view = 0; view < bv.TV; ++view) {  // per-view constants of the current poses (k_view_consts)
+            const WinState& s = bv.st[bv.view_win[view]];
+            if (s.active && s.need_lin) view_consts_item(bv, view);
+        }
         for (size_t si = 0; si < pv.size(); ++si) {
             BatchView& v = pv[si];
             // K1: observations
