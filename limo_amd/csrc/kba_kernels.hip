@@ -52,6 +52,91 @@ __device__ __forceinline__ void block_sum(const double* vals, double* lds /* [4*
     }
 }
 
+// ---- 28 per-lane values summed over the 256-lane workgroup (k_linearize: cost | U 21 | g 6).
+// Reduce-scatter instead of 28 butterflies: every exchange step halves the number of values a lane carries, so the
+// wave reduction costs 28/2 + 14/2 + 4 + 2 + 1 + 1 = 29 exchange-adds instead of 28 * 6 = 168 (the butterflies via
+// ds_bpermute were a quarter of the kernel).  Strides 32 / 16 use gfx950's v_permlane32_swap / v_permlane16_swap (one
+// instruction moves the two halves both ways), strides 8 / 4 / 2 / 1 DPP row operations.  Fixed order: deterministic.
+__device__ __forceinline__ double dpp_mov(double x, int ctrl_sel) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    switch (ctrl_sel) {  // compile-time constant after inlining
+        case 0:  // row_ror:8  (lane ^ 8 within a row of 16)
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false);
+            break;
+        case 1:  // row_half_mirror (lane -> 7 - lane within 8: the partner differs in bit 2)
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
+            break;
+        case 2:  // quad_perm [2,3,0,1]  (lane ^ 2)
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+            break;
+        default:  // quad_perm [1,0,3,2]  (lane ^ 1)
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+            break;
+    }
+    return __hiloint2double(hi, lo);
+}
+// a + (a's other half), b likewise: lanes 0-31 end with sum pairs of a, lanes 32-63 with sum pairs of b
+__device__ __forceinline__ double swap32_add(double a, double b) {
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// even rows (of 16 lanes) end with pair sums of a, odd rows with pair sums of b
+__device__ __forceinline__ double swap16_add(double a, double b) {
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// lanes whose `bit` is clear keep a (and receive the partner's a), the others keep b
+template <int CTRL>
+__device__ __forceinline__ double halve_dpp(double a, double b, bool bit) {
+    const double keep = bit ? b : a, send = bit ? a : b;
+    return keep + dpp_mov(send, CTRL);
+}
+// Index of the value whose wave total lane `lane` holds after wave_reduce_scatter28 (even lanes; -1: duplicate).
+__device__ __forceinline__ int rs28_index(int lane) {
+    const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1, b1 = (lane >> 1) & 1;
+    int j;
+    if (!b1 && !b2) j = b3 ? 4 : 0;
+    else if (!b1 && b2) j = b3 ? 6 : 2;
+    else if (b1 && !b2) j = b3 ? 5 : 1;
+    else j = b3 ? -1 : 3;
+    return (lane & 1) || j < 0 ? -1 : 7 * row + j;
+}
+__device__ __forceinline__ double wave_reduce_scatter28(const double* v, int lane) {
+    double s[14], u[7];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) s[i] = swap32_add(v[i], v[i + 14]);  // lanes < 32: values 0..13, lanes >= 32: 14..27
+#pragma unroll
+    for (int i = 0; i < 7; ++i) u[i] = swap16_add(s[i], s[i + 7]);     // row r of 16 lanes: values 7 r + i
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    const double w0 = halve_dpp<0>(u[0], u[4], b3), w1 = halve_dpp<0>(u[1], u[5], b3), w2 = halve_dpp<0>(u[2], u[6], b3);
+    const double w3 = u[3] + dpp_mov(u[3], 0);
+    const double x0 = halve_dpp<1>(w0, w2, b2), x1 = halve_dpp<1>(w1, w3, b2);
+    const double y = halve_dpp<2>(x0, x1, b1);
+    return y + dpp_mov(y, 3);
+}
+// out_global[i] = sum over the workgroup of vals[i], i < 28;  lds: 4 * 28 doubles
+__device__ __forceinline__ void block_sum28(const double* vals, double* lds, double* out_global) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double tot = wave_reduce_scatter28(vals, lane);
+    const int idx = rs28_index(lane);
+    if (idx >= 0) lds[wave * 28 + idx] = tot;
+    __syncthreads();
+    if (threadIdx.x < 28) out_global[threadIdx.x] = (lds[threadIdx.x] + lds[28 + threadIdx.x]) + (lds[56 + threadIdx.x] + lds[84 + threadIdx.x]);
+}
+
+// Worklist entry i: plain lists (lock-step solve; null = the identity) or counted lists rebuilt by k_sched every round
+// (streaming solve: the launch grid is the list's capacity, entry [-1] its length).  -1 = nothing to do.
+__device__ __forceinline__ int wl_at(const BatchView& bv, const int32_t* wl, int i) {
+    if (bv.counted) return i < wl[-1] ? wl[i] : -1;
+    return wl ? wl[i] : i;
+}
+
 // ------------------------------------------------------------------------------------------ LM control
 __global__ void k_solve_init(BatchView bv, SolveConsts c, int max_iter, int select) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,11 +160,131 @@ __global__ void k_expire(BatchView bv) {
     if (bv.st[w].active) lm_terminate(bv.st[w], LIMO_NO_CONVERGENCE);
 }
 
+// ------------------------------------------------------------------------------------------ streaming solve: scheduler
+// One workgroup, one lane per slot (<= 1024 windows in flight), at the start of every round:
+//   1. a window whose solve ended moves on in its schedule (kba_lm.hpp:sched_advance); finished windows leave their
+//      slot and the next pending window of the batch moves in - the windows of a batch converge after 5 .. 100
+//      iterations, so in a lock-step solve most launch rounds work on a fraction of the batch;
+//   2. the worklists of the round (observation / landmark / Schur workgroups and windows that take part, plus the ones
+//      being trimmed) are rebuilt with a workgroup scan.  Kernels are launched over the lists' capacities and return
+//      where blockIdx is past the count (wl_at).
+// Which slot a window lands in does not influence any result: every per-window quantity lives at the window's own
+// offsets.
+constexpr int kSchedThreads = 1024;
+__global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveConsts c, int round) {
+    __shared__ int wave_tot[16][SL_COUNT];
+    __shared__ int base[SL_COUNT];
+    const int s = threadIdx.x, lane = s & 63, wave = s >> 6;
+    int cnt[SL_COUNT];
+#pragma unroll
+    for (int k = 0; k < SL_COUNT; ++k) cnt[k] = 0;
+    int w = -1, listed = 0, trimming = 0, generic = 0;
+    if (s < bv.n_slots) {
+        w = bv.slot_win[s];
+        for (int tries = 0; tries < 2; ++tries) {
+            if (w < 0) {  // free slot: next pending window of the batch
+                const int nxt = atomicAdd(bv.sched_ctl, 1);
+                if (nxt >= bv.n_win) break;
+                w = nxt;
+                bv.st[w].phase = PH_IDLE;
+            }
+            const int r = sched_advance(bv.st[w], bv.win[w], c);
+            if (r == 2) {
+                atomicAdd(bv.sched_ctl + 1, 1);
+                w = -1;
+                continue;  // the slot is free again: refill it in this round
+            }
+            listed = r == 1;
+            break;
+        }
+        bv.slot_win[s] = w;
+        if (w >= 0 && listed) {
+            const WinDesc& wd = bv.win[w];
+            trimming = bv.st[w].phase == PH_TRIM;
+            generic = !wd.schur_fast;
+            cnt[SL_BLK] = wd.n_blk;
+            cnt[SL_LBLK] = wd.n_lblk;
+            const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+            const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
+            cnt[SL_SPLAIN] = generic ? 0 : pl_groups;
+            cnt[SL_SFGP] = generic ? 0 : gp_groups;
+            cnt[SL_SGEN] = generic ? pl_groups + gp_groups : 0;
+            cnt[SL_WIN] = 1;
+            cnt[SL_TBLK] = trimming ? wd.n_blk : 0;
+            cnt[SL_TLBLK] = trimming ? wd.n_lblk : 0;
+            cnt[SL_TWIN] = trimming ? 1 : 0;
+        }
+    }
+    // exclusive scan of the nine counts over the slots
+    int off[SL_COUNT];
+#pragma unroll
+    for (int k = 0; k < SL_COUNT; ++k) {
+        int x = cnt[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        off[k] = x - cnt[k];
+        if (lane == 63) wave_tot[wave][k] = x;
+    }
+    __syncthreads();
+    if (s < SL_COUNT) {
+        int run = 0;
+        for (int q = 0; q < 16; ++q) {
+            const int t = wave_tot[q][s];
+            wave_tot[q][s] = run;
+            run += t;
+        }
+        base[s] = run;
+        bv.sched_lists[bv.sched_off[s]] = run;  // the list's count word
+    }
+    __syncthreads();
+    if (w >= 0 && listed) {
+        const WinDesc& wd = bv.win[w];
+        int32_t* L[SL_COUNT];
+#pragma unroll
+        for (int k = 0; k < SL_COUNT; ++k) L[k] = bv.sched_lists + bv.sched_off[k] + 1 + wave_tot[wave][k] + off[k];
+        for (int i = 0; i < wd.n_blk; ++i) L[SL_BLK][i] = wd.blk0 + i;
+        for (int i = 0; i < wd.n_lblk; ++i) L[SL_LBLK][i] = wd.lblk0 + i;
+        {
+            int32_t* lp = generic ? L[SL_SGEN] : L[SL_SPLAIN];
+            int n = 0;
+            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) lp[n++] = wd.sblk0 + i;
+            int32_t* lg = generic ? lp + n : L[SL_SFGP];
+            n = 0;
+            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) lg[n++] = wd.sblk0 + i;
+        }
+        L[SL_WIN][0] = w;
+        if (trimming) {
+            for (int i = 0; i < wd.n_blk; ++i) L[SL_TBLK][i] = wd.blk0 + i;
+            for (int i = 0; i < wd.n_lblk; ++i) L[SL_TLBLK][i] = wd.lblk0 + i;
+            L[SL_TWIN][0] = w;
+        }
+    }
+    if (s == 0) {
+        __threadfence();
+        const int done = atomicAdd(bv.sched_ctl + 1, 0);
+        *(volatile int32_t*)(bv.sched_done_host + (round & 3)) = done;
+        __threadfence_system();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ observations
 // per-view constants of the current poses (kba_items.hpp:view_consts_item), one lane per view
+// (streaming solve: one 64-lane workgroup per listed window, lanes over its <= kMaxViews views)
 __global__ void k_view_consts(BatchView bv) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= bv.TV) return;
+    int v;
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_WIN] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        const WinDesc& wd = bv.win[wl[blockIdx.x]];
+        if ((int)threadIdx.x >= wd.n_view) return;
+        v = wd.view0 + threadIdx.x;
+    } else {
+        v = blockIdx.x * blockDim.x + threadIdx.x;
+        if (v >= bv.TV) return;
+    }
     const WinState& st = bv.st[bv.view_win[v]];
     if (!st.active || !st.need_lin) return;
     view_consts_item(bv, v);
@@ -93,7 +298,8 @@ __global__ void k_view_consts(BatchView bv) {
 // index -> landmark gather -> ~450 fp64 operations, not by bytes).
 template <int WAVES>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int view = bv.blk_view[b];
     const int w = bv.view_win[view];
     const WinState& st = bv.st[w];
@@ -154,13 +360,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     if (c.pad == 21) {  // profiling aid: skip the workgroup reduction
         if (threadIdx.x < kLinPartial) bv.blk_part[(int64_t)b * kLinPartial + threadIdx.x] = vals[0];
     } else {
-        block_sum<kLinPartial>(vals, lds, bv.blk_part + (int64_t)b * kLinPartial);
+        static_assert(kLinPartial == 28, "block_sum28");
+        block_sum28(vals, lds, bv.blk_part + (int64_t)b * kLinPartial);
     }
     if (threadIdx.x == 0) bv.blk_fail[b] = any_fail;
 }
 
 __global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.st[w].active) return;
     __shared__ double lds[4];
@@ -179,9 +387,20 @@ __global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, co
 }
 
 // shard / n_shards: landmark sharding - a shard evaluates only the rows of its own landmarks.
+// (streaming solve: grid = (listed windows, chunks of 256 rows of a window))
 __global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= bv.TG) return;
+    int g;
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_WIN] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        const WinDesc& wd = bv.win[wl[blockIdx.x]];
+        const int i = blockIdx.y * blockDim.x + threadIdx.x;
+        if (i >= wd.n_gp) return;
+        g = wd.gp0 + i;
+    } else {
+        g = blockIdx.x * blockDim.x + threadIdx.x;
+        if (g >= bv.TG) return;
+    }
     if (n_shards > 1 && bv.lm_id[bv.gp_lm[g]] % n_shards != shard) return;
     const int w = bv.lm_win[bv.gp_lm[g]];
     const WinState& st = bv.st[w];
@@ -192,7 +411,8 @@ __global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
 
 // ------------------------------------------------------------------------------------------ landmarks
 __global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
@@ -214,7 +434,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c
 }
 
 __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     int fail = 0;
@@ -224,7 +445,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c,
 }
 
 __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     __shared__ double lds[12];
@@ -274,7 +496,8 @@ struct SchurPre {
 // the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
 template <int TM, bool FAST>
 __global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span, int span_gp, int dbg) {
-    const int sb = wl[blockIdx.x];  // first Schur block of this wave (worklist entry, a multiple of span past wd.sblk0)
+    const int sb = wl_at(bv, wl, blockIdx.x);  // first Schur block of this wave's group
+    if (sb < 0) return;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
@@ -510,7 +733,8 @@ __host__ __device__ inline int schur_lean_lds_bytes(int ncol) {
 
 template <int TM, bool GP, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(BatchView bv, const int32_t* wl, int span, int span_gp) {
-    const int sb = wl[blockIdx.x];
+    const int sb = wl_at(bv, wl, blockIdx.x);
+    if (sb < 0) return;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
@@ -753,7 +977,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
 // ------------------------------------------------------------------------------------------ camera system
 __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int w = wl_at(bv, wl, blockIdx.x);
+    if (w < 0) return;
     WinState& st = bv.st[w];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (st.active && st.need_lin) {
@@ -772,7 +997,7 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
     // Count the windows that go on iterating; the workgroup that finishes last publishes the count straight into
     // pinned host memory (the host polls it one iteration behind) and re-arms the counters - no memset / copy
     // commands between the kernels of an iteration.
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !bv.counted) {
         if (st.active) atomicAdd(bv.n_active, 1);
         __threadfence();
         if (atomicAdd(bv.n_active + 1, 1) == (int)gridDim.x - 1) {
@@ -787,7 +1012,8 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
 }
 
 __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int w = wl_at(bv, wl, blockIdx.x);
+    if (w < 0) return;
     if (!bv.st[w].active) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
@@ -803,7 +1029,8 @@ __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts 
 }
 
 __global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int w = wl_at(bv, wl, blockIdx.x);
+    if (w < 0) return;
     if (!bv.st[w].active) return;
     __shared__ double red[64];
     reduce_step(bv, w, threadIdx.x, blockDim.x, red);
@@ -812,7 +1039,26 @@ __global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c,
 }
 
 // candidate -> current for accepted windows (keyframe part: first TK threads, landmark part: the rest)
+// (streaming solve: one workgroup per listed landmark workgroup; the window's first one also moves its keyframes)
 __global__ void k_accept(BatchView bv) {
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_LBLK] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        const int b = wl[blockIdx.x], w = bv.lblk_win[b];
+        if (!bv.st[w].accept) return;
+        if ((int)threadIdx.x < bv.lblk_n[b]) {
+            const int64_t l = bv.lblk_lm0[b] + threadIdx.x;
+            for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
+        }
+        const WinDesc& wd = bv.win[w];
+        if (b == wd.lblk0 && (int)threadIdx.x < wd.n_kf) {
+            const int64_t i = wd.kf0 + threadIdx.x;
+            for (int q = 0; q < 7; ++q) bv.pose[7 * i + q] = bv.pose_c[7 * i + q];
+            for (int q = 0; q < 3; ++q) bv.pdir[3 * i + q] = bv.pdir_c[3 * i + q];
+            bv.pdist[i] = bv.pdist_c[i];
+        }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < bv.TK) {
         if (!bv.st[bv.kf_win[i]].accept) return;
@@ -829,14 +1075,25 @@ __global__ void k_accept(BatchView bv) {
 
 // ------------------------------------------------------------------------------------------ trimming
 __global__ __launch_bounds__(kBlock) void k_trim_residual(BatchView bv, double* plane_rep, double* plane_dep, const int32_t* wl) {
-    const int b = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
     const int w = bv.view_win[bv.blk_view[b]];
     if (!bv.win[w].do_trim) return;
     for (int q = 0; q < kObsPerLane; ++q) trim_residual_lane(bv, b, threadIdx.x + q * kBlock, plane_rep, plane_dep);
 }
 
+// (streaming solve: one 256-lane workgroup per landmark workgroup of the windows being trimmed this round)
 __global__ void k_trim_max(BatchView bv, const double* plane_rep, const double* plane_dep, int shard, int n_shards) {
-    const int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    int gl;
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_TLBLK] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        const int b = wl[blockIdx.x];
+        if ((int)threadIdx.x >= bv.lblk_n[b]) return;
+        gl = bv.lblk_lm0[b] + threadIdx.x;
+    } else {
+        gl = blockIdx.x * blockDim.x + threadIdx.x;
+    }
     if (gl >= bv.TL) return;
     if (n_shards > 1 && bv.lm_id[gl] % n_shards != shard) return;
     if (!bv.win[bv.lm_win[gl]].do_trim) return;
@@ -852,8 +1109,14 @@ __device__ __forceinline__ bool trim_less(double ka, int ia, double kb, int ib) 
     return ka < kb || (ka == kb && ia < ib);
 }
 
+// (streaming solve: the windows whose trimming solve ended this round; afterwards their next solve is armed)
 __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConsts c) {
-    const int w = blockIdx.x;
+    int w = blockIdx.x;
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_TWIN] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        w = wl[blockIdx.x];
+    }
     const WinDesc& wd = bv.win[w];
     if (!wd.do_trim) return;
     const int n = wd.n_lm;
@@ -927,6 +1190,10 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
         }
     }
     if (removed) atomicAdd(&bv.st[w].n_trimmed, removed);
+    if (bv.counted) {
+        __syncthreads();
+        if (threadIdx.x == 0) sched_after_trim(bv.st[w], c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ landmark sharding
@@ -947,7 +1214,8 @@ __global__ void k_sum_shards(T* dst, ShardPtrs src, int n_shards, int64_t n) {
 
 // One slab per (window, shard) before the exchange: 74 KB instead of 9 MB on the wire for a C4 window.
 __global__ __launch_bounds__(kBlock) void k_slab_reduce(BatchView bv, const int32_t* wl, int shard) {
-    const int w = wl ? wl[blockIdx.x] : blockIdx.x;
+    const int w = wl_at(bv, wl, blockIdx.x);
+    if (w < 0) return;
     if (!bv.st[w].active) return;
     const int n = bv.win[w].nf_pad * bv.win[w].nf_pad;
     for (int e = blockIdx.y * kBlock + threadIdx.x; e < n; e += gridDim.y * kBlock) slab_reduce_entry(bv, w, shard, e);

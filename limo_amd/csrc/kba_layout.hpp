@@ -77,6 +77,7 @@ struct WinState {
     int32_t n_success, n_unsuccess;
     int32_t acc_solves, acc_iters, acc_success, last_iters;
     int32_t n_trimmed, acc_lin;
+    int32_t phase, trim_round;  // streaming solve (kba_lm.hpp:sched_advance): where the window is in the solveTrimmed schedule
     double radius, decrease_factor;
     double x_cost, x_norm, fixed_cost;
     double solve_initial_cost, solve_final_cost;
@@ -97,6 +98,15 @@ struct WinRed {
     int32_t lin_fail, chol_fail, cand_fail, pad;
 };
 
+// Phases of one window in the solveTrimmed schedule (robust_solving.cpp:160-248) when every window advances on its own
+// (streaming solve): trimming solve -> [retry with 3x the iterations if the cost did not decrease] -> trim -> ... ->
+// final solve.
+enum SchedPhase { PH_IDLE = 0, PH_TRIM_SOLVE = 1, PH_RETRY = 2, PH_TRIM = 3, PH_FINAL = 4, PH_DONE = 5 };
+
+// Worklists the device-side scheduler rebuilds every round (streaming solve).  List k lives at
+// sched_lists + sched_off[k]: element [0] = number of entries, entries from [1].
+enum SchedList { SL_BLK = 0, SL_LBLK, SL_SPLAIN, SL_SFGP, SL_SGEN, SL_WIN, SL_TBLK, SL_TLBLK, SL_TWIN, SL_COUNT };
+
 struct SolveConsts {  // subset of limo_ba_options the kernels need
     double a_rep, a_dep;
     double function_tolerance, gradient_tolerance, parameter_tolerance;
@@ -106,6 +116,7 @@ struct SolveConsts {  // subset of limo_ba_options the kernels need
     int32_t min_groups, pad;
     int32_t schur_span;   // plain Schur blocks per wave in this iteration (kba_items.hpp:schur_slab_of)
     int32_t schur_span_gp;  // ground-plane Schur blocks per wave
+    int32_t num_trim_rounds, trim_iters, max_iters;  // the schedule, for the device-side scheduler
     int32_t schur_nslab;  // > 0: landmark-sharded solve - k_cam_solve sums this many per-shard slabs from S_red instead
 };
 
@@ -185,6 +196,14 @@ struct BatchView {
     double *trim_rep, *trim_dep;   // [TL] max un-robustified residual norm per landmark, <0 = no block
     int32_t* n_active;          // [2] {windows still iterating, workgroups of k_cam_assemble done} of this iteration
     int32_t* n_active_host;     // pinned host word the last workgroup publishes the count to (not a batch buffer)
+    // --- streaming solve (device-side scheduler, k_sched): not batch buffers, set by the library when it streams
+    int32_t counted;            // 1: worklists are counted (entry [-1] of a list = its length; grids are capacities)
+    int32_t n_slots;            // windows in flight at most
+    int32_t* slot_win;          // [n_slots] window in the slot or -1
+    int32_t* sched_ctl;         // [0] next pending window, [1] windows finished
+    int32_t* sched_lists;       // the worklists, back to back
+    int32_t sched_off[SL_COUNT];  // offset of list k's count word inside sched_lists
+    int32_t* sched_done_host;   // pinned ring (4 words): windows finished as of round r at [r & 3]
 };
 
 }  // namespace kba

@@ -53,6 +53,55 @@ KBA_HD void lm_finalize_unsuccessful(WinState& s, const SolveConsts& c) {
     }
 }
 
+// Streaming solve: advance window w in the solveTrimmed schedule at the start of a round (the lock-step form of the
+// same schedule is kba_pack.cpp:run_schedule).  Returns 0 = nothing to do this round (cannot happen for a window in a
+// slot), 1 = the window takes part in this round (iterating, or waiting for the trimming kernels of this round, which
+// re-arm it), 2 = finished: the slot is free.
+KBA_HD int sched_advance(WinState& s, const WinDesc& wd, const SolveConsts& c) {
+    if (s.phase == PH_IDLE) {  // just moved into a slot
+        s.trim_round = 0;
+        if (wd.do_trim && c.num_trim_rounds > 0) {
+            s.phase = PH_TRIM_SOLVE;
+            lm_solve_init(s, true, c.trim_iters, c);
+        } else {
+            s.phase = PH_FINAL;
+            lm_solve_init(s, true, c.max_iters, c);
+        }
+        return 1;
+    }
+    if (s.active || s.phase == PH_TRIM) return 1;
+    if (s.phase == PH_TRIM_SOLVE) {
+        if (s.solve_initial_cost - s.solve_final_cost <= 0.0) {  // robust_solving.cpp:172-181
+            s.phase = PH_RETRY;
+            lm_solve_init(s, true, 3 * c.trim_iters, c);
+        } else {
+            s.phase = PH_TRIM;
+        }
+        return 1;
+    }
+    if (s.phase == PH_RETRY) {
+        s.phase = PH_TRIM;
+        return 1;
+    }
+    if (s.phase == PH_FINAL) {
+        s.phase = PH_DONE;
+        return 2;
+    }
+    return 0;
+}
+
+// After the trimming kernels of a round have removed the outliers of window w: start its next solve.
+KBA_HD void sched_after_trim(WinState& s, const SolveConsts& c) {
+    s.trim_round += 1;
+    if (s.trim_round < c.num_trim_rounds) {
+        s.phase = PH_TRIM_SOLVE;
+        lm_solve_init(s, true, c.trim_iters, c);
+    } else {
+        s.phase = PH_FINAL;
+        lm_solve_init(s, true, c.max_iters, c);
+    }
+}
+
 // After (re)linearisation at the current point: IterationZero or the tail of HandleSuccessfulStep, then Finalize.
 KBA_HD void lm_decide_lin(WinState& s, const WinRed& r, double fixed_cost, const SolveConsts& c) {
     if (!s.active || !s.need_lin) return;

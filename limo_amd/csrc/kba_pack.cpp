@@ -43,6 +43,9 @@ SolveConsts make_consts(const limo_ba_options& o) {
     c.min_groups = o.minimum_number_residual_groups;
     c.schur_span = 1;
     c.schur_span_gp = 1;
+    c.num_trim_rounds = o.num_trim_rounds;
+    c.trim_iters = o.trim_solver_iterations;
+    c.max_iters = o.max_num_iterations;
     if (const char* e = std::getenv("KBA_DEBUG_STAGE")) c.pad = std::atoi(e);  // profiling aid only
     return c;
 }

@@ -94,6 +94,16 @@ struct limo_ba_batch : Executor {
              : T <= 4 ? (const void*)k_schur<4, false> : T <= 6 ? (const void*)k_schur<6, false> : (const void*)k_schur<8, false>;
     }
     int rc = LIMO_OK;
+    // ---- streaming solve (device-side scheduler k_sched): windows move through n_slots slots, a finished window is
+    // replaced by the next pending one, so every launch round works on a full set (kba_kernels.hip:k_sched)
+    bool stream_ready = false;
+    int n_slots = 0;
+    int cap[SL_COUNT] = {0};          // capacity (= launch grid) of every worklist
+    int max_gp_chunks = 1;
+    int32_t *d_slot_win = nullptr, *d_sched_ctl = nullptr, *d_sched_lists = nullptr;
+    int32_t* h_done = nullptr;        // pinned ring of 4
+    int32_t* d_h_done = nullptr;
+    hipEvent_t round_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // ---- landmark sharding.  shard_P == 1: everything below is inert (pv = {bv}).
     // Every shard holds the same global layout and owns the observation / landmark / Schur workgroups of its
     // landmarks (rank lists); the per-workgroup partial arrays it produces live in its own "producer view" pv[i] and
@@ -126,6 +136,9 @@ struct limo_ba_batch : Executor {
         for (auto& a : allocs) ctx->pool_free(a.first, a.second);
         if (h_active) ctx->host_free(h_active, 64);
         if (h_flags) ctx->host_free(h_flags, h_flags_bytes);
+        if (h_done) ctx->host_free(h_done, 64);
+        for (auto& e : round_ev)
+            if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -364,16 +377,15 @@ struct limo_ba_batch : Executor {
 #define LAUNCH_CHECK(what) note(hipGetLastError(), what)
 
     // ---- Executor
-    // Schur granularity: coarse waves (4 blocks = 256 landmarks, fewer partial slabs) while there are enough of them
-    // to fill the chip (8 waves per CU), finer ones for small active sets where the serial tile chain of a wave is
-    // the latency floor of the iteration.
-    void set_span(int n_windows_listed) {
-        const int64_t coarse_waves = (int64_t)n_windows_listed * std::max(1, avg_sblk) / 4;
-        c.schur_span = coarse_waves >= 2048 ? 4 : coarse_waves >= 1024 ? 2 : 1;
-        // ground-plane groups: a fifth of the landmarks, twice the MFMA work per tile, at 2 waves / SIMD in the general
-        // kernel: keep them fine-grained (many short waves) unless the chip is very full
-        c.schur_span_gp = coarse_waves >= 8192 ? 2 : 1;
+    // Schur granularity: a wave takes two plain Schur blocks (128 landmarks, 8 tiles) or one ground-plane block.  Fixed
+    // (not a function of how many windows are in flight): the partial-slab layout of a window, and with it the order in
+    // which its Schur complement is summed, is then the same alone and inside any batch - single-window and batched
+    // solves give the same bits.  (Measured at 1024 C2 windows: span 2 is as fast as 4, span 1 costs 2 %.)
+    void set_span(int) {
+        c.schur_span = 2;
+        c.schur_span_gp = 1;
         if (const char* e = std::getenv("KBA_SPAN_GP")) c.schur_span_gp = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("KBA_SPAN")) c.schur_span = std::max(1, std::atoi(e));  // A/B timing aids
         if (shard_P > 1) c.schur_span = c.schur_span_gp = 1;  // Schur blocks are cut at shard boundaries
         c.schur_nslab = shard_P > 1 ? shard_P : 0;
     }
@@ -692,6 +704,136 @@ struct limo_ba_batch : Executor {
         LAUNCH_CHECK("k_trim_select");
     }
 
+    // ------------------------------------------------------------------------------------------ streaming solve
+    int stream_setup() {
+        if (stream_ready) return LIMO_OK;
+        n_slots = std::min(P.n_win, kSchedThreads);
+        if (const char* e = std::getenv("KBA_SLOTS")) n_slots = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedThreads}));
+        set_span(P.n_win);
+        int mx[SL_COUNT] = {0};
+        int max_gp = 0;
+        for (const WinDesc& d : P.win) {
+            const int plg = (d.n_sblk_plain + c.schur_span - 1) / c.schur_span, gpg = (d.n_sblk - d.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+            mx[SL_BLK] = std::max(mx[SL_BLK], (int)d.n_blk);
+            mx[SL_LBLK] = std::max(mx[SL_LBLK], (int)d.n_lblk);
+            mx[SL_SPLAIN] = std::max(mx[SL_SPLAIN], d.schur_fast ? plg : 0);
+            mx[SL_SFGP] = std::max(mx[SL_SFGP], d.schur_fast ? gpg : 0);
+            mx[SL_SGEN] = std::max(mx[SL_SGEN], d.schur_fast ? 0 : plg + gpg);
+            max_gp = std::max(max_gp, (int)d.n_gp);
+        }
+        mx[SL_WIN] = 1;
+        mx[SL_TBLK] = mx[SL_BLK];
+        mx[SL_TLBLK] = mx[SL_LBLK];
+        mx[SL_TWIN] = 1;
+        max_gp_chunks = std::max(1, cdiv(max_gp, 256));
+        size_t total = 0;
+        for (int k = 0; k < SL_COUNT; ++k) {
+            cap[k] = n_slots * mx[k];
+            bv.sched_off[k] = (int32_t)total;
+            total += 1 + (size_t)std::max(1, cap[k]);
+        }
+        if (dmalloc((void**)&d_sched_lists, sizeof(int32_t) * total)) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_slot_win, sizeof(int32_t) * n_slots)) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_sched_ctl, sizeof(int32_t) * 8)) return LIMO_ERR_RUNTIME;
+        HIP_TRY(ctx, hipMemsetAsync(d_sched_lists, 0, sizeof(int32_t) * total, ctx->stream));
+        HIP_TRY(ctx, ctx->host_alloc((void**)&h_done, 64));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_h_done, h_done, 0));
+        for (auto& e : round_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        stream_ready = true;
+        return LIMO_OK;
+    }
+
+    // One round = scheduler + trimming kernels (of the windows whose trimming solve just ended) + one LM iteration of
+    // every window in a slot.  The host only enqueues; it learns that all windows are done from a pinned word the
+    // scheduler writes, two rounds late (so the stream never drains inside a solve).
+    int solve_streaming() {
+        if (stream_setup() != LIMO_OK) return LIMO_ERR_RUNTIME;
+        hipStream_t s = ctx->stream;
+        set_span(P.n_win);
+        BatchView sv = bv;
+        sv.counted = 1;
+        sv.n_slots = n_slots;
+        sv.slot_win = d_slot_win;
+        sv.sched_ctl = d_sched_ctl;
+        sv.sched_lists = d_sched_lists;
+        sv.sched_done_host = d_h_done;
+        sv.n_active_host = nullptr;
+        HIP_TRY(ctx, hipMemsetAsync(d_slot_win, 0xFF, sizeof(int32_t) * n_slots, s));
+        HIP_TRY(ctx, hipMemsetAsync(d_sched_ctl, 0, sizeof(int32_t) * 8, s));
+        for (int i = 0; i < 4; ++i) h_done[i] = 0;
+        auto L = [&](int k) { return (const int32_t*)(d_sched_lists + sv.sched_off[k] + 1); };
+        static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
+        constexpr int kLag = 2;
+        for (int round = 0;; ++round) {
+            hipLaunchKernelGGL(k_sched, dim3(1), dim3(kSchedThreads), 0, s, sv, c, round);
+            LAUNCH_CHECK("k_sched");
+            // ---- trimming of the windows in PH_TRIM; k_trim_select arms their next solve
+            if (cap[SL_TBLK]) hipLaunchKernelGGL(k_trim_residual, dim3(cap[SL_TBLK]), dim3(kBlock), 0, s, sv, d_plane_rep, d_plane_dep, L(SL_TBLK));
+            if (cap[SL_TLBLK]) hipLaunchKernelGGL(k_trim_max, dim3(cap[SL_TLBLK]), dim3(kBlock), 0, s, sv, (const double*)d_plane_rep, (const double*)d_plane_dep, 0, 1);
+            hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, s, sv, c);
+            LAUNCH_CHECK("trim kernels");
+            // ---- linearisation of the windows that need it
+            hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
+            {
+                EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
+                if (cap[SL_BLK]) {
+                    if (lin_waves == 2)
+                        hipLaunchKernelGGL(k_linearize<2>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+                    else if (lin_waves == 4)
+                        hipLaunchKernelGGL(k_linearize<4>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+                    else
+                        hipLaunchKernelGGL(k_linearize<3>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+                }
+                if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+            }
+            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
+            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_accum, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+            hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
+            LAUNCH_CHECK("linearisation kernels");
+            // ---- trust-region step of the windows that iterate
+            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+            {
+                EventPair* ep = timed(LIMO_KERNEL_SCHUR);
+                int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
+                if (cap[SL_SPLAIN]) {
+                    const int32_t* wlp = L(SL_SPLAIN);
+                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
+                    note(hipLaunchKernel(schur_fn_plain, dim3(cap[SL_SPLAIN]), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
+                }
+                if (cap[SL_SFGP]) {
+                    const int32_t* wlp = L(SL_SFGP);
+                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
+                    note(hipLaunchKernel(schur_fn_leangp, dim3(cap[SL_SFGP]), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");
+                }
+                if (cap[SL_SGEN]) {
+                    const int32_t* wlp = L(SL_SGEN);
+                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
+                    note(hipLaunchKernel(schur_fn_gen, dim3(cap[SL_SGEN]), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
+                }
+                if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+            }
+            hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
+            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, L(SL_LBLK));
+            if (cap[SL_BLK]) hipLaunchKernelGGL(k_cost, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 1, 0, 1);
+            hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
+            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
+            LAUNCH_CHECK("step kernels");
+            note(hipEventRecord(round_ev[round & 3], s), "record round");
+            if (rc != LIMO_OK) break;
+            if (round >= kLag) {
+                note(hipEventSynchronize(round_ev[(round - kLag) & 3]), "sync round");
+                if (rc != LIMO_OK || h_done[(round - kLag) & 3] >= P.n_win) break;
+            }
+            if (round > 100000) {
+                rc = LIMO_ERR_RUNTIME;
+                ctx->err = "streaming solve did not terminate";
+                break;
+            }
+        }
+        return rc;
+    }
+
     int collect_linearize_events() {
         if (ev_used) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -841,7 +983,14 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     b->rc = LIMO_OK;
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(b->ev_total_a, ctx->stream));
-    run_schedule(*b, b->opts);
+    // Windows of a batch converge after very different numbers of iterations: from a few windows on they stream through
+    // slots (k_sched) instead of advancing in lock-step.  Not for sharded solves (exchange steps between the kernels)
+    // and not with a wall-clock cap (a per-solve clock, run_schedule keeps it).
+    static const int stream_min = std::getenv("KBA_STREAM_MIN") ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;
+    if (b->shard_P == 1 && b->opts.max_solver_time_sec <= 0.0 && b->P.n_win >= stream_min && !b->P.evaluate_only)
+        b->solve_streaming();
+    else
+        run_schedule(*b, b->opts);
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
         hipLaunchKernelGGL(k_lm_owned, dim3(cdiv(b->P.TL, 256)), dim3(256), 0, ctx->stream, b->bv, b->d_lm_tmp, b->shard_rank, b->shard_P,
                            ctx->comm_world);

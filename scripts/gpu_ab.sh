@@ -3,7 +3,8 @@
 # TESTS=1 runs the GPU tests first (fuzz at LIMO_FUZZ_SCALE, default a tenth); PROF=TAG adds a rocprofv3 kernel table of that config.
 mkdir -p gpurun_out
 export LIMO_FUZZ_SCALE=${LIMO_FUZZ_SCALE:-0.1}
-if [ "${TESTS:-0}" = "1" ]; then ( time timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} ) 2>&1 | tail -8; fi
+if [ -n "${MICRO:-}" ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -w scripts/micro/$MICRO.hip -o /tmp/micro_$MICRO && /tmp/micro_$MICRO; fi
+if [ "${TESTS:-0}" = "1" ]; then ( time timeout 1500 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -x -q ) > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error|Error|assert|real" gpurun_out/pytest_gpu.log | tail -12; fi
 for cfg in "$@"; do
   tag=${cfg%%:*}; envs=${cfg#*:}
   env $envs timeout 300 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err || { echo "$tag FAILED"; tail -5 gpurun_out/ab_$tag.err; continue; }

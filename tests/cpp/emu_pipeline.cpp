@@ -344,6 +344,58 @@ struct EmuBatch : Executor {
         }
     }
 
+    // ---- streaming solve (mirrors k_sched + the list-driven launches of limo_hip.hip:solve_streaming)
+    // Trimming of ONE window (the lock-step trim() above handles every do_trim window at once); unsharded only.
+    void trim_window(int w) {
+        const WinDesc& wd = bv.win[w];
+        if (!wd.do_trim) return;
+        for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b)
+            for (int t = 0; t < kObsBlock; ++t) trim_residual_lane(bv, b, t, plane_rep.data(), plane_dep.data());
+        for (int l = 0; l < wd.n_lm; ++l) trim_max_lane(bv, wd.lm0 + l, plane_rep.data(), plane_dep.data());
+        std::vector<uint8_t> out(wd.n_lm, 0);
+        for (int l = 0; l < wd.n_lm; ++l)
+            out[l] = trim_is_outlier(bv.trim_dep + wd.lm0, bv.lm_id + wd.lm0, wd.n_lm, l, c.depth_quantile, c.min_groups) ||
+                     trim_is_outlier(bv.trim_rep + wd.lm0, bv.lm_id + wd.lm0, wd.n_lm, l, c.reprojection_quantile, c.min_groups);
+        for (int l = 0; l < wd.n_lm; ++l)
+            if (out[l] && bv.lm_state[wd.lm0 + l]) {
+                bv.lm_state[wd.lm0 + l] = 0;
+                bv.st[w].n_trimmed++;
+            }
+    }
+    // Windows move through n_slots slots; per round: scheduler, trimming of the windows whose trimming solve ended,
+    // one LM iteration of every window in a slot.  Returns the number of rounds.
+    int run_streaming(int n_slots) {
+        std::vector<int> slot(n_slots, -1);
+        int cursor = 0, done = 0, rounds = 0;
+        while (done < bv.n_win) {
+            for (int s = 0; s < n_slots; ++s) {
+                for (int tries = 0; tries < 2; ++tries) {
+                    if (slot[s] < 0) {
+                        if (cursor >= bv.n_win) break;
+                        slot[s] = cursor++;
+                        bv.st[slot[s]].phase = PH_IDLE;
+                    }
+                    const int r = sched_advance(bv.st[slot[s]], bv.win[slot[s]], c);
+                    if (r == 2) {
+                        ++done;
+                        slot[s] = -1;
+                        continue;
+                    }
+                    break;
+                }
+            }
+            for (int s = 0; s < n_slots; ++s)
+                if (slot[s] >= 0 && bv.st[slot[s]].phase == PH_TRIM) {
+                    trim_window(slot[s]);
+                    sched_after_trim(bv.st[slot[s]], c);
+                }
+            linearize();  // every kernel item looks at the window's own state: windows outside the slots are idle
+            step();
+            if (++rounds > 100000) break;
+        }
+        return rounds;
+    }
+
     // rank mode: make every rank hold every landmark (sum of "owned, else zero")
     void gather_landmarks() {
         if (shard_P == 1 || !cb) return;
@@ -412,6 +464,22 @@ int emu_ba_solve_batch(int32_t n, limo_ba_window* windows, const limo_ba_options
     B.c = make_consts(*o);
     B.alloc();
     run_schedule(B, *o);
+    write_back(B, windows);
+    record_trimmed(B);
+    if (reports)
+        for (int w = 0; w < n; ++w) fill_report(B, w, reports + w);
+    return LIMO_OK;
+}
+
+// The same batch through the streaming schedule (n_slots windows in flight); the per-window results must not depend on it.
+int emu_ba_solve_batch_streaming(int32_t n, limo_ba_window* windows, const limo_ba_options* o, limo_ba_report* reports, int n_slots) {
+    EmuBatch B;
+    std::string err;
+    int rc = pack_windows(n, windows, *o, PackOptions(), B.P, err);
+    if (rc != LIMO_OK) return rc;
+    B.c = make_consts(*o);
+    B.alloc();
+    B.run_streaming(n_slots < 1 ? 1 : n_slots);
     write_back(B, windows);
     record_trimmed(B);
     if (reports)

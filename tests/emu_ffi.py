@@ -89,6 +89,7 @@ def load():
         dp, u8p = _ffi.c_double_p, _ffi.c_uint8_p
         lib.emu_ba_solve_batch.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int, C.POINTER(_ffi.SpeedPrior)]
         lib.emu_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+        lib.emu_ba_solve_batch_streaming.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int]
         lib.emu_last_trimmed.argtypes = [C.c_int, _ffi.c_int32_p, C.c_int]
         lib.emu_ba_solve_sharded.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, C.POINTER(_ffi.BaReport)]
         _lib = lib
@@ -104,6 +105,19 @@ def solve_batch(windows, opts, pose_only=False, prior=None):
     rc = lib.emu_ba_solve_batch(len(windows), arr, C.byref(opts), reps, int(pose_only), None if prior is None else C.byref(prior))
     if rc != 0:
         raise RuntimeError("emu_ba_solve_batch rc=%d" % rc)
+    return [r.as_dict() for r in reps]
+
+
+def solve_batch_streaming(windows, opts, n_slots):
+    """The batch through the streaming schedule (device-side scheduler emulated): n_slots windows in flight."""
+    from limo_amd.window import struct_array
+
+    lib = load()
+    arr = struct_array(windows)
+    reps = (_ffi.BaReport * len(windows))()
+    rc = lib.emu_ba_solve_batch_streaming(len(windows), arr, C.byref(opts), reps, int(n_slots))
+    if rc != 0:
+        raise RuntimeError("emu_ba_solve_batch_streaming rc=%d" % rc)
     return [r.as_dict() for r in reps]
 
 

@@ -248,3 +248,25 @@ def check_time_cap(solve, solve_oracle, last_trimmed, last_trimmed_oracle):
 
 def test_solver_time_cap(oracle, emu):
     check_time_cap(lambda w, o: emu.solve_batch([w], o)[0], lambda w, o: oracle.solve(w, o)[0], lambda: emu.last_trimmed(0), oracle.last_trimmed)
+
+
+def test_streaming_schedule_gives_the_lock_step_results(emu):
+    """Streaming solve (windows move through slots, every window advances through solveTrimmed's phases on its own;
+    kba_lm.hpp:sched_advance, kba_kernels.hip:k_sched) against the lock-step schedule (kba_pack.cpp:run_schedule): the
+    same bits per window whatever the number of slots, and the same reports."""
+    ws = [synth.make_window(300 + i, n_kf=3 + (i % 4), n_lm=[60, 150, 400, 900][i % 4], outlier_frac=0.05 * (i % 3)) for i in range(10)]
+    o = default_options()
+    ref = [w.copy() for w in ws]
+    r_ref = emu.solve_batch(ref, o)
+    for n_slots in (1, 3, 16):
+        got = [w.copy() for w in ws]
+        r_got = emu.solve_batch_streaming(got, o, n_slots)
+        for a, b, ra, rb in zip(ref, got, r_ref, r_got):
+            assert np.array_equal(a.kf_pose, b.kf_pose) and np.array_equal(a.lm_pos, b.lm_pos) and np.array_equal(a.kf_plane_dist, b.kf_plane_dist)
+            for k in ("termination", "num_solves", "iterations_total", "iterations_final", "successful_steps", "n_trimmed_landmarks", "num_linearizations", "initial_cost", "final_cost"):
+                assert ra[k] == rb[k], k
+    two = default_options(num_trim_rounds=2)  # more than one trimming round
+    a, b = [w.copy() for w in ws[:4]], [w.copy() for w in ws[:4]]
+    ra, rb = emu.solve_batch(a, two), emu.solve_batch_streaming(b, two, 2)
+    for x, y, p, q in zip(a, b, ra, rb):
+        assert np.array_equal(x.kf_pose, y.kf_pose) and p["n_trimmed_landmarks"] == q["n_trimmed_landmarks"] and p["num_solves"] == q["num_solves"]
