@@ -58,10 +58,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="independent windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIMO_BENCH_BATCH", "1024")), help="independent windows per GPU per step")
     ap.add_argument("--n-kf", type=int, default=5)
     ap.add_argument("--n-lm", type=int, default=2000)
-    ap.add_argument("--distinct", type=int, default=0, help="distinct windows generated per rank (0 = every window of the batch is different)")
+    ap.add_argument("--distinct", type=int, default=int(os.environ.get("LIMO_BENCH_DISTINCT", "0")), help="distinct windows generated per rank (0 = every window of the batch is different)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=8)
     ap.add_argument("--selftest-dist", action="store_true",

@@ -161,28 +161,48 @@ __global__ void k_expire(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ streaming solve: scheduler
-// One workgroup, one lane per slot (<= 1024 windows in flight), at the start of every round:
+// One workgroup, up to four slots per lane (<= 4096 windows in flight), at the start of every round:
 //   1. a window whose solve ended moves on in its schedule (kba_lm.hpp:sched_advance); finished windows leave their
 //      slot and the next pending window of the batch moves in - the windows of a batch converge after 5 .. 100
 //      iterations, so in a lock-step solve most launch rounds work on a fraction of the batch;
-//   2. the worklists of the round (observation / landmark / Schur workgroups and windows that take part, plus the ones
-//      being trimmed) are rebuilt with a workgroup scan.  Kernels are launched over the lists' capacities and return
+//   2. the worklists of the round are rebuilt with a workgroup scan: observation / landmark / Schur workgroups and
+//      windows that iterate, and - separately - the ones whose trimming solve just ended: those are trimmed on a side
+//      stream during this round (k_trim_select is a latency-bound sort) and iterate again from the next round on.  Kernels are launched over the lists' capacities and return
 //      where blockIdx is past the count (wl_at).
 // Which slot a window lands in does not influence any result: every per-window quantity lives at the window's own
 // offsets.
 constexpr int kSchedThreads = 1024;
+constexpr int kSchedSlotsPerLane = 4;
+constexpr int kSchedMaxSlots = kSchedThreads * kSchedSlotsPerLane;
+
+// (what a lane notes about one of its slots between the two phases of k_sched)
+struct SchedSlot {
+    int w;         // window in the slot (-1: empty)
+    int kind;      // 0 = nothing to launch for it, 1 = iterates this round, 2 = is trimmed this round
+};
+
 __global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveConsts c, int round) {
     __shared__ int wave_tot[16][SL_COUNT];
-    __shared__ int base[SL_COUNT];
-    const int s = threadIdx.x, lane = s & 63, wave = s >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int cnt[SL_COUNT];
 #pragma unroll
     for (int k = 0; k < SL_COUNT; ++k) cnt[k] = 0;
-    int w = -1, listed = 0, trimming = 0, generic = 0;
-    if (s < bv.n_slots) {
-        w = bv.slot_win[s];
+    SchedSlot sl[kSchedSlotsPerLane];
+    // pending windows left?  (plain read first: once the batch is handed out, thousands of empty slots would otherwise
+    // hammer the cursor with atomics every round)
+    const bool pending = *(volatile int32_t*)bv.sched_ctl < bv.n_win;
+    int n_fin = 0;
+#pragma unroll
+    for (int q = 0; q < kSchedSlotsPerLane; ++q) {
+        const int s = t * kSchedSlotsPerLane + q;
+        sl[q].w = -1;
+        sl[q].kind = 0;
+        if (s >= bv.n_slots) continue;
+        int w = bv.slot_win[s];
+        const int w_in = w;
         for (int tries = 0; tries < 2; ++tries) {
             if (w < 0) {  // free slot: next pending window of the batch
+                if (!pending) break;
                 const int nxt = atomicAdd(bv.sched_ctl, 1);
                 if (nxt >= bv.n_win) break;
                 w = nxt;
@@ -190,32 +210,38 @@ __global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveCons
             }
             const int r = sched_advance(bv.st[w], bv.win[w], c);
             if (r == 2) {
-                atomicAdd(bv.sched_ctl + 1, 1);
+                ++n_fin;
                 w = -1;
                 continue;  // the slot is free again: refill it in this round
             }
-            listed = r == 1;
+            sl[q].kind = r == 1 ? (bv.st[w].phase == PH_TRIM ? 2 : 1) : 0;
             break;
         }
-        bv.slot_win[s] = w;
-        if (w >= 0 && listed) {
+        if (w != w_in) bv.slot_win[s] = w;
+        sl[q].w = w;
+        if (w >= 0 && sl[q].kind) {
             const WinDesc& wd = bv.win[w];
-            trimming = bv.st[w].phase == PH_TRIM;
-            generic = !wd.schur_fast;
-            cnt[SL_BLK] = wd.n_blk;
-            cnt[SL_LBLK] = wd.n_lblk;
-            const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
-            const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
-            cnt[SL_SPLAIN] = generic ? 0 : pl_groups;
-            cnt[SL_SFGP] = generic ? 0 : gp_groups;
-            cnt[SL_SGEN] = generic ? pl_groups + gp_groups : 0;
-            cnt[SL_WIN] = 1;
-            cnt[SL_TBLK] = trimming ? wd.n_blk : 0;
-            cnt[SL_TLBLK] = trimming ? wd.n_lblk : 0;
-            cnt[SL_TWIN] = trimming ? 1 : 0;
+            if (sl[q].kind == 2) {
+                cnt[SL_TBLK] += wd.n_blk;
+                cnt[SL_TLBLK] += wd.n_lblk;
+                cnt[SL_TWIN] += 1;
+            } else {
+                const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+                const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
+                cnt[SL_BLK] += wd.n_blk;
+                cnt[SL_LBLK] += wd.n_lblk;
+                if (wd.schur_fast) {
+                    cnt[SL_SPLAIN] += pl_groups;
+                    cnt[SL_SFGP] += gp_groups;
+                } else {
+                    cnt[SL_SGEN] += pl_groups + gp_groups;
+                }
+                cnt[SL_WIN] += 1;
+            }
         }
     }
-    // exclusive scan of the nine counts over the slots
+    if (n_fin) atomicAdd(bv.sched_ctl + 1, n_fin);
+    // exclusive scan of the nine counts over the lanes
     int off[SL_COUNT];
 #pragma unroll
     for (int k = 0; k < SL_COUNT; ++k) {
@@ -229,40 +255,42 @@ __global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveCons
         if (lane == 63) wave_tot[wave][k] = x;
     }
     __syncthreads();
-    if (s < SL_COUNT) {
+    if (t < SL_COUNT) {
         int run = 0;
         for (int q = 0; q < 16; ++q) {
-            const int t = wave_tot[q][s];
-            wave_tot[q][s] = run;
-            run += t;
+            const int v = wave_tot[q][t];
+            wave_tot[q][t] = run;
+            run += v;
         }
-        base[s] = run;
-        bv.sched_lists[bv.sched_off[s]] = run;  // the list's count word
+        bv.sched_lists[bv.sched_off[t]] = run;  // the list's count word
     }
     __syncthreads();
-    if (w >= 0 && listed) {
-        const WinDesc& wd = bv.win[w];
-        int32_t* L[SL_COUNT];
+    int32_t* L[SL_COUNT];
 #pragma unroll
-        for (int k = 0; k < SL_COUNT; ++k) L[k] = bv.sched_lists + bv.sched_off[k] + 1 + wave_tot[wave][k] + off[k];
-        for (int i = 0; i < wd.n_blk; ++i) L[SL_BLK][i] = wd.blk0 + i;
-        for (int i = 0; i < wd.n_lblk; ++i) L[SL_LBLK][i] = wd.lblk0 + i;
-        {
-            int32_t* lp = generic ? L[SL_SGEN] : L[SL_SPLAIN];
-            int n = 0;
-            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) lp[n++] = wd.sblk0 + i;
-            int32_t* lg = generic ? lp + n : L[SL_SFGP];
-            n = 0;
-            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) lg[n++] = wd.sblk0 + i;
+    for (int k = 0; k < SL_COUNT; ++k) L[k] = bv.sched_lists + bv.sched_off[k] + 1 + wave_tot[wave][k] + off[k];
+#pragma unroll
+    for (int q = 0; q < kSchedSlotsPerLane; ++q) {
+        const int w = sl[q].w;
+        if (w < 0 || !sl[q].kind) continue;
+        const WinDesc& wd = bv.win[w];
+        if (sl[q].kind == 2) {
+            for (int i = 0; i < wd.n_blk; ++i) *L[SL_TBLK]++ = wd.blk0 + i;
+            for (int i = 0; i < wd.n_lblk; ++i) *L[SL_TLBLK]++ = wd.lblk0 + i;
+            *L[SL_TWIN]++ = w;
+            continue;
         }
-        L[SL_WIN][0] = w;
-        if (trimming) {
-            for (int i = 0; i < wd.n_blk; ++i) L[SL_TBLK][i] = wd.blk0 + i;
-            for (int i = 0; i < wd.n_lblk; ++i) L[SL_TLBLK][i] = wd.lblk0 + i;
-            L[SL_TWIN][0] = w;
+        for (int i = 0; i < wd.n_blk; ++i) *L[SL_BLK]++ = wd.blk0 + i;
+        for (int i = 0; i < wd.n_lblk; ++i) *L[SL_LBLK]++ = wd.lblk0 + i;
+        if (wd.schur_fast) {
+            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) *L[SL_SPLAIN]++ = wd.sblk0 + i;
+            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) *L[SL_SFGP]++ = wd.sblk0 + i;
+        } else {
+            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) *L[SL_SGEN]++ = wd.sblk0 + i;
+            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) *L[SL_SGEN]++ = wd.sblk0 + i;
         }
+        *L[SL_WIN]++ = w;
     }
-    if (s == 0) {
+    if (t == 0) {
         __threadfence();
         const int done = atomicAdd(bv.sched_ctl + 1, 0);
         *(volatile int32_t*)(bv.sched_done_host + (round & 3)) = done;

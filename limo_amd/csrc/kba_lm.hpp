@@ -55,8 +55,8 @@ KBA_HD void lm_finalize_unsuccessful(WinState& s, const SolveConsts& c) {
 
 // Streaming solve: advance window w in the solveTrimmed schedule at the start of a round (the lock-step form of the
 // same schedule is kba_pack.cpp:run_schedule).  Returns 0 = nothing to do this round (cannot happen for a window in a
-// slot), 1 = the window takes part in this round (iterating, or waiting for the trimming kernels of this round, which
-// re-arm it), 2 = finished: the slot is free.
+// slot), 1 = the window takes part in this round - it iterates, or (phase == PH_TRIM) it is trimmed during this round
+// and re-armed by sched_after_trim for the next one, 2 = finished: the slot is free.
 KBA_HD int sched_advance(WinState& s, const WinDesc& wd, const SolveConsts& c) {
     if (s.phase == PH_IDLE) {  // just moved into a slot
         s.trim_round = 0;

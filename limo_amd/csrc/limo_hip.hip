@@ -104,6 +104,8 @@ struct limo_ba_batch : Executor {
     int32_t* h_done = nullptr;        // pinned ring of 4
     int32_t* d_h_done = nullptr;
     hipEvent_t round_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t trim_stream = nullptr;  // side stream: trimming of the windows whose trimming solve ended, during the round
+    hipEvent_t sched_ev = nullptr, trim_ev = nullptr;
     // ---- landmark sharding.  shard_P == 1: everything below is inert (pv = {bv}).
     // Every shard holds the same global layout and owns the observation / landmark / Schur workgroups of its
     // landmarks (rank lists); the per-workgroup partial arrays it produces live in its own "producer view" pv[i] and
@@ -137,6 +139,9 @@ struct limo_ba_batch : Executor {
         if (h_active) ctx->host_free(h_active, 64);
         if (h_flags) ctx->host_free(h_flags, h_flags_bytes);
         if (h_done) ctx->host_free(h_done, 64);
+        if (trim_stream) (void)hipStreamDestroy(trim_stream);
+        if (sched_ev) (void)hipEventDestroy(sched_ev);
+        if (trim_ev) (void)hipEventDestroy(trim_ev);
         for (auto& e : round_ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_pool) {
@@ -707,8 +712,10 @@ struct limo_ba_batch : Executor {
     // ------------------------------------------------------------------------------------------ streaming solve
     int stream_setup() {
         if (stream_ready) return LIMO_OK;
-        n_slots = std::min(P.n_win, kSchedThreads);
-        if (const char* e = std::getenv("KBA_SLOTS")) n_slots = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedThreads}));
+        // windows in flight: a quarter of the batch (so that the ramp-down at the end of the batch is a small part of the
+        // solve), at least 1024 (a round of fewer windows is bound by the latency of its window-level kernels)
+        n_slots = std::min((int)P.n_win, std::max(1024, std::min(kSchedMaxSlots, (int)P.n_win / 4)));
+        if (const char* e = std::getenv("KBA_SLOTS")) n_slots = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedMaxSlots}));
         set_span(P.n_win);
         int mx[SL_COUNT] = {0};
         int max_gp = 0;
@@ -739,6 +746,9 @@ struct limo_ba_batch : Executor {
         HIP_TRY(ctx, ctx->host_alloc((void**)&h_done, 64));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_h_done, h_done, 0));
         for (auto& e : round_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&trim_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&sched_ev, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&trim_ev, hipEventDisableTiming));
         stream_ready = true;
         return LIMO_OK;
     }
@@ -765,13 +775,19 @@ struct limo_ba_batch : Executor {
         static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
         constexpr int kLag = 2;
         for (int round = 0;; ++round) {
+            if (round > 0) note(hipStreamWaitEvent(s, trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
             hipLaunchKernelGGL(k_sched, dim3(1), dim3(kSchedThreads), 0, s, sv, c, round);
             LAUNCH_CHECK("k_sched");
-            // ---- trimming of the windows in PH_TRIM; k_trim_select arms their next solve
-            if (cap[SL_TBLK]) hipLaunchKernelGGL(k_trim_residual, dim3(cap[SL_TBLK]), dim3(kBlock), 0, s, sv, d_plane_rep, d_plane_dep, L(SL_TBLK));
-            if (cap[SL_TLBLK]) hipLaunchKernelGGL(k_trim_max, dim3(cap[SL_TLBLK]), dim3(kBlock), 0, s, sv, (const double*)d_plane_rep, (const double*)d_plane_dep, 0, 1);
-            hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, s, sv, c);
+            // ---- trimming of the windows whose trimming solve just ended, on the side stream: k_trim_select is a
+            //      latency-bound sort (one workgroup per window, ~0.3 ms) - the other windows iterate meanwhile, the
+            //      trimmed ones join again in the next round (k_trim_select arms their next solve)
+            note(hipEventRecord(sched_ev, s), "record sched");
+            note(hipStreamWaitEvent(trim_stream, sched_ev, 0), "wait sched");
+            if (cap[SL_TBLK]) hipLaunchKernelGGL(k_trim_residual, dim3(cap[SL_TBLK]), dim3(kBlock), 0, trim_stream, sv, d_plane_rep, d_plane_dep, L(SL_TBLK));
+            if (cap[SL_TLBLK]) hipLaunchKernelGGL(k_trim_max, dim3(cap[SL_TLBLK]), dim3(kBlock), 0, trim_stream, sv, (const double*)d_plane_rep, (const double*)d_plane_dep, 0, 1);
+            hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, trim_stream, sv, c);
             LAUNCH_CHECK("trim kernels");
+            note(hipEventRecord(trim_ev, trim_stream), "record trim");
             // ---- linearisation of the windows that need it
             hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
             {
@@ -831,6 +847,7 @@ struct limo_ba_batch : Executor {
                 break;
             }
         }
+        note(hipStreamWaitEvent(s, trim_ev, 0), "wait trim");
         return rc;
     }
 

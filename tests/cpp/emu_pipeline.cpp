@@ -384,13 +384,15 @@ struct EmuBatch : Executor {
                     break;
                 }
             }
+            linearize();  // every kernel item looks at the window's own state: windows outside the slots are idle
+            step();
+            // the windows whose trimming solve ended are trimmed during the round (side stream on the GPU) and iterate
+            // again from the next one
             for (int s = 0; s < n_slots; ++s)
                 if (slot[s] >= 0 && bv.st[slot[s]].phase == PH_TRIM) {
                     trim_window(slot[s]);
                     sched_after_trim(bv.st[slot[s]], c);
                 }
-            linearize();  // every kernel item looks at the window's own state: windows outside the slots are idle
-            step();
             if (++rounds > 100000) break;
         }
         return rounds;
