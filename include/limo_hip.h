@@ -230,6 +230,12 @@ int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_o
 int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_options* opts, int apply_loss,
                      double* cost, double* residuals, double* jac_pose, double* jac_lm, uint8_t* valid);
 
+/* Measurement aid (bench.py `roofline_evaluate`): the same evaluation (apply_loss = 1) over a batch of windows kept on
+ * the device, `reps` launches timed with HIP events on the context's stream; nothing is downloaded.
+ * device_ms = average time of one launch over all windows. */
+int limo_ba_evaluate_batch_time(limo_ctx* ctx, int32_t n_windows, const limo_ba_window* windows, const limo_ba_options* opts,
+                                int32_t reps, double* device_ms);
+
 /*
  * Motion-only adjustment of ONE new keyframe against fixed landmarks (adjustPoseOnly).
  * window: n_kf == 1 (the new keyframe; its pose is optimised in place), landmarks constant.

@@ -168,6 +168,7 @@ ABI_SYMBOLS = [
     "limo_ctx_comm_init",
     "limo_ba_solve_sharded",
     "limo_ba_evaluate",
+    "limo_ba_evaluate_batch_time",
     "limo_ba_adjust_pose_only",
     "limo_landmark_init",
     "limo_trim_quantile",
@@ -212,6 +213,7 @@ def load():
     lib.limo_comm_unique_id.argtypes = [C.c_char_p]
     lib.limo_ctx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     lib.limo_ba_solve_sharded.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int, C.POINTER(BaReport)]
+    lib.limo_ba_evaluate_batch_time.argtypes = [vp, C.c_int32, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int32, C.POINTER(C.c_double)]
     lib.limo_ba_evaluate.argtypes = [
         vp,
         C.POINTER(BaWindow),

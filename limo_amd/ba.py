@@ -162,6 +162,14 @@ class Batch:
             pass
 
 
+def evaluate_batch_time(ctx, windows, opts, reps=10):
+    """limo_ba_evaluate_batch_time: device ms of one k_evaluate launch over `windows`; returns (ms, n_obs, n_depth_obs)."""
+    arr = struct_array(windows)
+    ms = C.c_double()
+    _check(ctx.lib.limo_ba_evaluate_batch_time(ctx.ptr, len(windows), arr, C.byref(opts), int(reps), C.byref(ms)), ctx.ptr, "limo_ba_evaluate_batch_time")
+    return ms.value, int(sum(w.n_obs for w in windows)), int(sum((w.obs_d > 0).sum() for w in windows))
+
+
 def depth_default_params():
     p = _ffi.DepthParams()
     _ffi.load().limo_depth_default_params(C.byref(p))

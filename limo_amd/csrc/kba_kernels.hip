@@ -161,7 +161,7 @@ __global__ void k_expire(BatchView bv) {
 }
 
 // ------------------------------------------------------------------------------------------ streaming solve: scheduler
-// One workgroup, up to four slots per lane (<= 4096 windows in flight), at the start of every round:
+// At the start of every round (<= 4096 windows in flight):
 //   1. a window whose solve ended moves on in its schedule (kba_lm.hpp:sched_advance); finished windows leave their
 //      slot and the next pending window of the batch moves in - the windows of a batch converge after 5 .. 100
 //      iterations, so in a lock-step solve most launch rounds work on a fraction of the batch;
@@ -171,87 +171,94 @@ __global__ void k_expire(BatchView bv) {
 //      where blockIdx is past the count (wl_at).
 // Which slot a window lands in does not influence any result: every per-window quantity lives at the window's own
 // offsets.
+// Three small kernels (one serial workgroup doing all of it took 0.2 ms per round at 4096 slots):
+//   k_sched_advance  one lane per slot: phase machine, slot refill, the slot's nine list counts
+//   k_sched_scan     one workgroup: exclusive scan of the counts over the slots -> offsets, list lengths, progress word
+//   k_sched_fill     one wave per slot: writes the slot's entries at its offsets
 constexpr int kSchedThreads = 1024;
 constexpr int kSchedSlotsPerLane = 4;
 constexpr int kSchedMaxSlots = kSchedThreads * kSchedSlotsPerLane;
 
-// (what a lane notes about one of its slots between the two phases of k_sched)
-struct SchedSlot {
-    int w;         // window in the slot (-1: empty)
-    int kind;      // 0 = nothing to launch for it, 1 = iterates this round, 2 = is trimmed this round
-};
-
-__global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveConsts c, int round) {
-    __shared__ int wave_tot[16][SL_COUNT];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int cnt[SL_COUNT];
+// bv.slot_cnt: [n_slots][SL_COUNT + 1] - counts of the slot's window per list, [SL_COUNT] = kind (0 nothing, 1 iterates,
+// 2 is trimmed this round); overwritten with the offsets by k_sched_scan.
+__global__ void k_sched_advance(BatchView bv, SolveConsts c) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bv.n_slots) return;
+    int32_t* cnt = bv.slot_cnt + (int64_t)s * (SL_COUNT + 1);
 #pragma unroll
-    for (int k = 0; k < SL_COUNT; ++k) cnt[k] = 0;
-    SchedSlot sl[kSchedSlotsPerLane];
+    for (int k = 0; k <= SL_COUNT; ++k) cnt[k] = 0;
     // pending windows left?  (plain read first: once the batch is handed out, thousands of empty slots would otherwise
     // hammer the cursor with atomics every round)
     const bool pending = *(volatile int32_t*)bv.sched_ctl < bv.n_win;
-    int n_fin = 0;
+    int w = bv.slot_win[s];
+    const int w_in = w;
+    int kind = 0, n_fin = 0;
+    for (int tries = 0; tries < 2; ++tries) {
+        if (w < 0) {  // free slot: next pending window of the batch
+            if (!pending) break;
+            const int nxt = atomicAdd(bv.sched_ctl, 1);
+            if (nxt >= bv.n_win) break;
+            w = nxt;
+            bv.st[w].phase = PH_IDLE;
+        }
+        const int r = sched_advance(bv.st[w], bv.win[w], c);
+        if (r == 2) {
+            ++n_fin;
+            w = -1;
+            continue;  // the slot is free again: refill it in this round
+        }
+        kind = r == 1 ? (bv.st[w].phase == PH_TRIM ? 2 : 1) : 0;
+        break;
+    }
+    if (n_fin) atomicAdd(bv.sched_ctl + 1, n_fin);
+    if (w != w_in) bv.slot_win[s] = w;
+    if (w < 0 || !kind) return;
+    const WinDesc& wd = bv.win[w];
+    cnt[SL_COUNT] = kind;
+    if (kind == 2) {
+        cnt[SL_TBLK] = wd.n_blk;
+        cnt[SL_TLBLK] = wd.n_lblk;
+        cnt[SL_TWIN] = 1;
+        return;
+    }
+    const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+    const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
+    cnt[SL_BLK] = wd.n_blk;
+    cnt[SL_LBLK] = wd.n_lblk;
+    if (wd.schur_fast) {
+        cnt[SL_SPLAIN] = pl_groups;
+        cnt[SL_SFGP] = gp_groups;
+    } else {
+        cnt[SL_SGEN] = pl_groups + gp_groups;
+    }
+    cnt[SL_WIN] = 1;
+}
+
+__global__ __launch_bounds__(kSchedThreads) void k_sched_scan(BatchView bv, int round) {
+    __shared__ int wave_tot[16][SL_COUNT];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int cnt[kSchedSlotsPerLane][SL_COUNT], tot[SL_COUNT];
+#pragma unroll
+    for (int k = 0; k < SL_COUNT; ++k) tot[k] = 0;
 #pragma unroll
     for (int q = 0; q < kSchedSlotsPerLane; ++q) {
         const int s = t * kSchedSlotsPerLane + q;
-        sl[q].w = -1;
-        sl[q].kind = 0;
-        if (s >= bv.n_slots) continue;
-        int w = bv.slot_win[s];
-        const int w_in = w;
-        for (int tries = 0; tries < 2; ++tries) {
-            if (w < 0) {  // free slot: next pending window of the batch
-                if (!pending) break;
-                const int nxt = atomicAdd(bv.sched_ctl, 1);
-                if (nxt >= bv.n_win) break;
-                w = nxt;
-                bv.st[w].phase = PH_IDLE;
-            }
-            const int r = sched_advance(bv.st[w], bv.win[w], c);
-            if (r == 2) {
-                ++n_fin;
-                w = -1;
-                continue;  // the slot is free again: refill it in this round
-            }
-            sl[q].kind = r == 1 ? (bv.st[w].phase == PH_TRIM ? 2 : 1) : 0;
-            break;
-        }
-        if (w != w_in) bv.slot_win[s] = w;
-        sl[q].w = w;
-        if (w >= 0 && sl[q].kind) {
-            const WinDesc& wd = bv.win[w];
-            if (sl[q].kind == 2) {
-                cnt[SL_TBLK] += wd.n_blk;
-                cnt[SL_TLBLK] += wd.n_lblk;
-                cnt[SL_TWIN] += 1;
-            } else {
-                const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
-                const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
-                cnt[SL_BLK] += wd.n_blk;
-                cnt[SL_LBLK] += wd.n_lblk;
-                if (wd.schur_fast) {
-                    cnt[SL_SPLAIN] += pl_groups;
-                    cnt[SL_SFGP] += gp_groups;
-                } else {
-                    cnt[SL_SGEN] += pl_groups + gp_groups;
-                }
-                cnt[SL_WIN] += 1;
-            }
+#pragma unroll
+        for (int k = 0; k < SL_COUNT; ++k) {
+            cnt[q][k] = s < bv.n_slots ? bv.slot_cnt[(int64_t)s * (SL_COUNT + 1) + k] : 0;
+            tot[k] += cnt[q][k];
         }
     }
-    if (n_fin) atomicAdd(bv.sched_ctl + 1, n_fin);
-    // exclusive scan of the nine counts over the lanes
     int off[SL_COUNT];
 #pragma unroll
     for (int k = 0; k < SL_COUNT; ++k) {
-        int x = cnt[k];
+        int x = tot[k];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int y = __shfl_up(x, d, 64);
             if (lane >= d) x += y;
         }
-        off[k] = x - cnt[k];
+        off[k] = x - tot[k];
         if (lane == 63) wave_tot[wave][k] = x;
     }
     __syncthreads();
@@ -265,37 +272,47 @@ __global__ __launch_bounds__(kSchedThreads) void k_sched(BatchView bv, SolveCons
         bv.sched_lists[bv.sched_off[t]] = run;  // the list's count word
     }
     __syncthreads();
-    int32_t* L[SL_COUNT];
-#pragma unroll
-    for (int k = 0; k < SL_COUNT; ++k) L[k] = bv.sched_lists + bv.sched_off[k] + 1 + wave_tot[wave][k] + off[k];
 #pragma unroll
     for (int q = 0; q < kSchedSlotsPerLane; ++q) {
-        const int w = sl[q].w;
-        if (w < 0 || !sl[q].kind) continue;
-        const WinDesc& wd = bv.win[w];
-        if (sl[q].kind == 2) {
-            for (int i = 0; i < wd.n_blk; ++i) *L[SL_TBLK]++ = wd.blk0 + i;
-            for (int i = 0; i < wd.n_lblk; ++i) *L[SL_TLBLK]++ = wd.lblk0 + i;
-            *L[SL_TWIN]++ = w;
-            continue;
+        const int s = t * kSchedSlotsPerLane + q;
+        if (s >= bv.n_slots) continue;
+#pragma unroll
+        for (int k = 0; k < SL_COUNT; ++k) {
+            bv.slot_cnt[(int64_t)s * (SL_COUNT + 1) + k] = wave_tot[wave][k] + off[k];
+            off[k] += cnt[q][k];
         }
-        for (int i = 0; i < wd.n_blk; ++i) *L[SL_BLK]++ = wd.blk0 + i;
-        for (int i = 0; i < wd.n_lblk; ++i) *L[SL_LBLK]++ = wd.lblk0 + i;
-        if (wd.schur_fast) {
-            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) *L[SL_SPLAIN]++ = wd.sblk0 + i;
-            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) *L[SL_SFGP]++ = wd.sblk0 + i;
-        } else {
-            for (int i = 0; i < wd.n_sblk_plain; i += c.schur_span) *L[SL_SGEN]++ = wd.sblk0 + i;
-            for (int i = wd.n_sblk_plain; i < wd.n_sblk; i += c.schur_span_gp) *L[SL_SGEN]++ = wd.sblk0 + i;
-        }
-        *L[SL_WIN]++ = w;
     }
     if (t == 0) {
-        __threadfence();
-        const int done = atomicAdd(bv.sched_ctl + 1, 0);
+        const int done = bv.sched_ctl[1];
         *(volatile int32_t*)(bv.sched_done_host + (round & 3)) = done;
         __threadfence_system();
     }
+}
+
+__global__ __launch_bounds__(256) void k_sched_fill(BatchView bv, SolveConsts c) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= bv.n_slots) return;
+    const int32_t* off = bv.slot_cnt + (int64_t)s * (SL_COUNT + 1);
+    const int kind = off[SL_COUNT];
+    if (!kind) return;
+    const int w = bv.slot_win[s];
+    const WinDesc& wd = bv.win[w];
+    auto L = [&](int k) { return bv.sched_lists + bv.sched_off[k] + 1 + off[k]; };
+    if (kind == 2) {
+        for (int i = lane; i < wd.n_blk; i += 64) L(SL_TBLK)[i] = wd.blk0 + i;
+        for (int i = lane; i < wd.n_lblk; i += 64) L(SL_TLBLK)[i] = wd.lblk0 + i;
+        if (lane == 0) L(SL_TWIN)[0] = w;
+        return;
+    }
+    for (int i = lane; i < wd.n_blk; i += 64) L(SL_BLK)[i] = wd.blk0 + i;
+    for (int i = lane; i < wd.n_lblk; i += 64) L(SL_LBLK)[i] = wd.lblk0 + i;
+    const int n_pg = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
+    const int n_gg = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+    int32_t* lp = wd.schur_fast ? L(SL_SPLAIN) : L(SL_SGEN);
+    int32_t* lg = wd.schur_fast ? L(SL_SFGP) : L(SL_SGEN) + n_pg;
+    for (int i = lane; i < n_pg; i += 64) lp[i] = wd.sblk0 + i * c.schur_span;
+    for (int i = lane; i < n_gg; i += 64) lg[i] = wd.sblk0 + wd.n_sblk_plain + i * c.schur_span_gp;
+    if (lane == 0) L(SL_WIN)[0] = w;
 }
 
 // ------------------------------------------------------------------------------------------ observations

@@ -201,6 +201,7 @@ struct BatchView {
     int32_t n_slots;            // windows in flight at most
     int32_t* slot_win;          // [n_slots] window in the slot or -1
     int32_t* sched_ctl;         // [0] next pending window, [1] windows finished
+    int32_t* slot_cnt;          // [n_slots][SL_COUNT + 1] list counts (then offsets) of the slot's window, [SL_COUNT] = kind
     int32_t* sched_lists;       // the worklists, back to back
     int32_t sched_off[SL_COUNT];  // offset of list k's count word inside sched_lists
     int32_t* sched_done_host;   // pinned ring (4 words): windows finished as of round r at [r & 3]

@@ -100,7 +100,7 @@ struct limo_ba_batch : Executor {
     int n_slots = 0;
     int cap[SL_COUNT] = {0};          // capacity (= launch grid) of every worklist
     int max_gp_chunks = 1;
-    int32_t *d_slot_win = nullptr, *d_sched_ctl = nullptr, *d_sched_lists = nullptr;
+    int32_t *d_slot_win = nullptr, *d_sched_ctl = nullptr, *d_sched_lists = nullptr, *d_slot_cnt = nullptr;
     int32_t* h_done = nullptr;        // pinned ring of 4
     int32_t* d_h_done = nullptr;
     hipEvent_t round_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -742,6 +742,7 @@ struct limo_ba_batch : Executor {
         if (dmalloc((void**)&d_sched_lists, sizeof(int32_t) * total)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_slot_win, sizeof(int32_t) * n_slots)) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_sched_ctl, sizeof(int32_t) * 8)) return LIMO_ERR_RUNTIME;
+        if (dmalloc((void**)&d_slot_cnt, sizeof(int32_t) * (SL_COUNT + 1) * n_slots)) return LIMO_ERR_RUNTIME;
         HIP_TRY(ctx, hipMemsetAsync(d_sched_lists, 0, sizeof(int32_t) * total, ctx->stream));
         HIP_TRY(ctx, ctx->host_alloc((void**)&h_done, 64));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_h_done, h_done, 0));
@@ -765,6 +766,7 @@ struct limo_ba_batch : Executor {
         sv.n_slots = n_slots;
         sv.slot_win = d_slot_win;
         sv.sched_ctl = d_sched_ctl;
+        sv.slot_cnt = d_slot_cnt;
         sv.sched_lists = d_sched_lists;
         sv.sched_done_host = d_h_done;
         sv.n_active_host = nullptr;
@@ -776,8 +778,10 @@ struct limo_ba_batch : Executor {
         constexpr int kLag = 2;
         for (int round = 0;; ++round) {
             if (round > 0) note(hipStreamWaitEvent(s, trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
-            hipLaunchKernelGGL(k_sched, dim3(1), dim3(kSchedThreads), 0, s, sv, c, round);
-            LAUNCH_CHECK("k_sched");
+            hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, sv, c);
+            hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(kSchedThreads), 0, s, sv, round);
+            hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, sv, c);
+            LAUNCH_CHECK("scheduler kernels");
             // ---- trimming of the windows whose trimming solve just ended, on the side stream: k_trim_select is a
             //      latency-bound sort (one workgroup per window, ~0.3 ms) - the other windows iterate meanwhile, the
             //      trimmed ones join again in the next round (k_trim_select arms their next solve)
@@ -1256,6 +1260,40 @@ int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_
         }
         if (cost) *cost = total;
     }
+    limo_ba_batch_destroy(b);
+    return rc;
+}
+
+int limo_ba_evaluate_batch_time(limo_ctx* ctx, int32_t n, const limo_ba_window* windows, const limo_ba_options* opts, int32_t reps,
+                                double* device_ms) {
+    if (!ctx || !windows || n <= 0 || reps <= 0 || !device_ms) return LIMO_ERR_INVALID;
+    PackOptions po;
+    po.evaluate_only = true;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, n, windows, opts, po, &b);
+    if (rc != LIMO_OK) return rc;
+    const int M = b->P.TO;
+    double* d_cost = nullptr;
+    uint8_t* d_valid = nullptr;
+    rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, M));
+    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, std::max(1, M));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rc == LIMO_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = LIMO_ERR_RUNTIME;
+    if (rc == LIMO_OK && b->P.n_blk) {
+        hipStream_t s = ctx->stream;
+        hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);  // warm-up
+        (void)hipEventRecord(e0, s);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);
+        (void)hipEventRecord(e1, s);
+        float ms = 0.f;
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+            ctx->err = "limo_ba_evaluate_batch_time: launch failed";
+            rc = LIMO_ERR_RUNTIME;
+        }
+        *device_ms = ms / reps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     limo_ba_batch_destroy(b);
     return rc;
 }

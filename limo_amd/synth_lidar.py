@@ -96,3 +96,16 @@ def make_frame(seed, n_feat=1500):
         "is_ground": is_ground,
         "z_true": z_true,
     }
+
+
+def visible_points(frame):
+    """Number of sweep points in front of the camera that project into the image (the 20-byte records of SURVEY §8d D1)."""
+    from .synth import pose_to_Rt
+
+    R, t = pose_to_Rt(frame["T_cam_lidar"])
+    pc = frame["cloud"][:, :3].astype(np.float64) @ R.T + t
+    z = pc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = frame["f"] * pc[:, 0] / z + frame["cx"]
+        v = frame["f"] * pc[:, 1] / z + frame["cy"]
+    return int(((z > 0) & (u >= 0) & (u < frame["w"]) & (v >= 0) & (v < frame["h"])).sum())
