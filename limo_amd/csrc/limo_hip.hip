@@ -96,16 +96,9 @@ struct limo_ba_batch : Executor {
     int rc = LIMO_OK;
     // ---- streaming solve (device-side scheduler k_sched): windows move through n_slots slots, a finished window is
     // replaced by the next pending one, so every launch round works on a full set (kba_kernels.hip:k_sched)
-    bool stream_ready = false;
     int n_slots = 0;
-    int cap[SL_COUNT] = {0};          // capacity (= launch grid) of every worklist
     int max_gp_chunks = 1;
-    int32_t *d_slot_win = nullptr, *d_sched_ctl = nullptr, *d_sched_lists = nullptr, *d_slot_cnt = nullptr;
-    int32_t* h_done = nullptr;        // pinned ring of 4
-    int32_t* d_h_done = nullptr;
-    hipEvent_t round_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t trim_stream = nullptr;  // side stream: trimming of the windows whose trimming solve ended, during the round
-    hipEvent_t sched_ev = nullptr, trim_ev = nullptr;
+    int32_t* d_sched_ctl = nullptr;   // [0] cursor over the batch's windows, [1] windows finished (shared by the groups)
     // ---- landmark sharding.  shard_P == 1: everything below is inert (pv = {bv}).
     // Every shard holds the same global layout and owns the observation / landmark / Schur workgroups of its
     // landmarks (rank lists); the per-workgroup partial arrays it produces live in its own "producer view" pv[i] and
@@ -138,12 +131,7 @@ struct limo_ba_batch : Executor {
         for (auto& a : allocs) ctx->pool_free(a.first, a.second);
         if (h_active) ctx->host_free(h_active, 64);
         if (h_flags) ctx->host_free(h_flags, h_flags_bytes);
-        if (h_done) ctx->host_free(h_done, 64);
-        if (trim_stream) (void)hipStreamDestroy(trim_stream);
-        if (sched_ev) (void)hipEventDestroy(sched_ev);
-        if (trim_ev) (void)hipEventDestroy(trim_ev);
-        for (auto& e : round_ev)
-            if (e) (void)hipEventDestroy(e);
+        stream_teardown();
         for (auto& e : ev_pool) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -532,7 +520,7 @@ struct limo_ba_batch : Executor {
     }
 
     // Event pair around one launch of a timed kernel (nullptr once the pool is exhausted).
-    EventPair* timed(int kernel) {
+    EventPair* timed(int kernel, hipStream_t on = nullptr) {
         if (ev_used >= 16384) return nullptr;
         if (ev_used == ev_pool.size()) {
             EventPair e;
@@ -543,7 +531,7 @@ struct limo_ba_batch : Executor {
         }
         EventPair* ep = &ev_pool[ev_used++];
         ep->kernel = kernel;
-        note(hipEventRecord(ep->a, ctx->stream), "hipEventRecord");
+        note(hipEventRecord(ep->a, on ? on : ctx->stream), "hipEventRecord");
         return ep;
     }
 
@@ -710,8 +698,41 @@ struct limo_ba_batch : Executor {
     }
 
     // ------------------------------------------------------------------------------------------ streaming solve
-    int stream_setup() {
-        if (stream_ready) return LIMO_OK;
+    // Slot groups: the slots are split into `n_groups` groups, each with its own stream, worklists and scheduler state;
+    // they take their windows from one shared cursor.  The groups run the same round sequence out of phase, so the
+    // MFMA-bound Schur kernels and the latency-bound window-level kernels of one group overlap with the HBM-bound
+    // scans of the other.
+    struct StreamGroup {
+        hipStream_t stream = nullptr, trim_stream = nullptr;
+        bool own_stream = false;
+        hipEvent_t sched_ev = nullptr, trim_ev = nullptr, done_ev = nullptr, round_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        int32_t *d_slot_win = nullptr, *d_lists = nullptr, *d_slot_cnt = nullptr;
+        int32_t *h_done = nullptr, *d_h_done = nullptr;  // pinned ring of 4
+        int n_slots = 0;
+        int cap[SL_COUNT] = {0};
+        BatchView sv;
+    };
+    std::vector<StreamGroup> groups;
+    int stream_groups_built = 0;
+    hipEvent_t start_ev = nullptr;
+
+    void stream_teardown() {
+        for (StreamGroup& g : groups) {
+            if (g.own_stream && g.stream) (void)hipStreamDestroy(g.stream);
+            if (g.trim_stream) (void)hipStreamDestroy(g.trim_stream);
+            for (hipEvent_t e : {g.sched_ev, g.trim_ev, g.done_ev, g.round_ev[0], g.round_ev[1], g.round_ev[2], g.round_ev[3]})
+                if (e) (void)hipEventDestroy(e);
+            if (g.h_done) ctx->host_free(g.h_done, 64);
+        }
+        groups.clear();
+        if (start_ev) (void)hipEventDestroy(start_ev);
+        start_ev = nullptr;
+    }
+
+    int stream_setup(int n_groups) {
+        if (stream_groups_built == n_groups) return LIMO_OK;
+        (void)hipStreamSynchronize(ctx->stream);
+        stream_teardown();  // (device blocks of an earlier layout stay with the batch until it is destroyed)
         // windows in flight: a quarter of the batch (so that the ramp-down at the end of the batch is a small part of the
         // solve), at least 1024 (a round of fewer windows is bound by the latency of its window-level kernels)
         n_slots = std::min((int)P.n_win, std::max(1024, std::min(kSchedMaxSlots, (int)P.n_win / 4)));
@@ -733,125 +754,166 @@ struct limo_ba_batch : Executor {
         mx[SL_TLBLK] = mx[SL_LBLK];
         mx[SL_TWIN] = 1;
         max_gp_chunks = std::max(1, cdiv(max_gp, 256));
-        size_t total = 0;
-        for (int k = 0; k < SL_COUNT; ++k) {
-            cap[k] = n_slots * mx[k];
-            bv.sched_off[k] = (int32_t)total;
-            total += 1 + (size_t)std::max(1, cap[k]);
+        if (!d_sched_ctl && dmalloc((void**)&d_sched_ctl, sizeof(int32_t) * 8)) return LIMO_ERR_RUNTIME;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
+        groups.resize(n_groups);
+        for (int gi = 0; gi < n_groups; ++gi) {
+            StreamGroup& g = groups[gi];
+            g.n_slots = n_slots / n_groups + (gi < n_slots % n_groups ? 1 : 0);
+            g.sv = bv;
+            size_t total = 0;
+            for (int k = 0; k < SL_COUNT; ++k) {
+                g.cap[k] = g.n_slots * mx[k];
+                g.sv.sched_off[k] = (int32_t)total;
+                total += 1 + (size_t)std::max(1, g.cap[k]);
+            }
+            if (dmalloc((void**)&g.d_lists, sizeof(int32_t) * total)) return LIMO_ERR_RUNTIME;
+            if (dmalloc((void**)&g.d_slot_win, sizeof(int32_t) * std::max(1, g.n_slots))) return LIMO_ERR_RUNTIME;
+            if (dmalloc((void**)&g.d_slot_cnt, sizeof(int32_t) * (SL_COUNT + 1) * std::max(1, g.n_slots))) return LIMO_ERR_RUNTIME;
+            HIP_TRY(ctx, hipMemsetAsync(g.d_lists, 0, sizeof(int32_t) * total, ctx->stream));
+            HIP_TRY(ctx, ctx->host_alloc((void**)&g.h_done, 64));
+            HIP_TRY(ctx, hipHostGetDevicePointer((void**)&g.d_h_done, g.h_done, 0));
+            for (auto& e : g.round_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&g.sched_ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&g.trim_ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&g.done_ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&g.trim_stream, hipStreamNonBlocking));
+            if (gi == 0) {
+                g.stream = nullptr;  // the context's stream, looked up at solve time (limo_ctx_set_stream)
+            } else {
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+                g.own_stream = true;
+            }
+            g.sv.counted = 1;
+            g.sv.n_slots = g.n_slots;
+            g.sv.slot_win = g.d_slot_win;
+            g.sv.sched_ctl = d_sched_ctl;
+            g.sv.slot_cnt = g.d_slot_cnt;
+            g.sv.sched_lists = g.d_lists;
+            g.sv.sched_done_host = g.d_h_done;
+            g.sv.n_active_host = nullptr;
         }
-        if (dmalloc((void**)&d_sched_lists, sizeof(int32_t) * total)) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_slot_win, sizeof(int32_t) * n_slots)) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_sched_ctl, sizeof(int32_t) * 8)) return LIMO_ERR_RUNTIME;
-        if (dmalloc((void**)&d_slot_cnt, sizeof(int32_t) * (SL_COUNT + 1) * n_slots)) return LIMO_ERR_RUNTIME;
-        HIP_TRY(ctx, hipMemsetAsync(d_sched_lists, 0, sizeof(int32_t) * total, ctx->stream));
-        HIP_TRY(ctx, ctx->host_alloc((void**)&h_done, 64));
-        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_h_done, h_done, 0));
-        for (auto& e : round_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&trim_stream, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&sched_ev, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&trim_ev, hipEventDisableTiming));
-        stream_ready = true;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        stream_groups_built = n_groups;
         return LIMO_OK;
     }
 
-    // One round = scheduler + trimming kernels (of the windows whose trimming solve just ended) + one LM iteration of
-    // every window in a slot.  The host only enqueues; it learns that all windows are done from a pinned word the
-    // scheduler writes, two rounds late (so the stream never drains inside a solve).
-    int solve_streaming() {
-        if (stream_setup() != LIMO_OK) return LIMO_ERR_RUNTIME;
-        hipStream_t s = ctx->stream;
-        set_span(P.n_win);
-        BatchView sv = bv;
-        sv.counted = 1;
-        sv.n_slots = n_slots;
-        sv.slot_win = d_slot_win;
-        sv.sched_ctl = d_sched_ctl;
-        sv.slot_cnt = d_slot_cnt;
-        sv.sched_lists = d_sched_lists;
-        sv.sched_done_host = d_h_done;
-        sv.n_active_host = nullptr;
-        HIP_TRY(ctx, hipMemsetAsync(d_slot_win, 0xFF, sizeof(int32_t) * n_slots, s));
-        HIP_TRY(ctx, hipMemsetAsync(d_sched_ctl, 0, sizeof(int32_t) * 8, s));
-        for (int i = 0; i < 4; ++i) h_done[i] = 0;
-        auto L = [&](int k) { return (const int32_t*)(d_sched_lists + sv.sched_off[k] + 1); };
+    // One round of one group = scheduler + (side stream) trimming of the windows whose trimming solve just ended + one LM
+    // iteration of every window in the group's slots.
+    void enqueue_round(StreamGroup& g, int round, bool time_kernels) {
+        hipStream_t s = g.stream;
+        const BatchView& sv = g.sv;
+        const int* cap = g.cap;
+        auto L = [&](int k) { return (const int32_t*)(g.d_lists + sv.sched_off[k] + 1); };
         static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
+        if (round > 0) note(hipStreamWaitEvent(s, g.trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
+        hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(g.n_slots, 256)), dim3(256), 0, s, sv, c);
+        hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(kSchedThreads), 0, s, sv, round);
+        hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(g.n_slots, 4)), dim3(256), 0, s, sv, c);
+        LAUNCH_CHECK("scheduler kernels");
+        // ---- trimming of the windows whose trimming solve just ended, on the side stream: k_trim_select is a
+        //      latency-bound sort (one workgroup per window, ~0.3 ms) - the other windows iterate meanwhile, the
+        //      trimmed ones join again in the next round (k_trim_select arms their next solve)
+        note(hipEventRecord(g.sched_ev, s), "record sched");
+        note(hipStreamWaitEvent(g.trim_stream, g.sched_ev, 0), "wait sched");
+        if (cap[SL_TBLK]) hipLaunchKernelGGL(k_trim_residual, dim3(cap[SL_TBLK]), dim3(kBlock), 0, g.trim_stream, sv, d_plane_rep, d_plane_dep, L(SL_TBLK));
+        if (cap[SL_TLBLK]) hipLaunchKernelGGL(k_trim_max, dim3(cap[SL_TLBLK]), dim3(kBlock), 0, g.trim_stream, sv, (const double*)d_plane_rep, (const double*)d_plane_dep, 0, 1);
+        hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, g.trim_stream, sv, c);
+        LAUNCH_CHECK("trim kernels");
+        note(hipEventRecord(g.trim_ev, g.trim_stream), "record trim");
+        // ---- linearisation of the windows that need it
+        hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
+        {
+            EventPair* ep = time_kernels ? timed(LIMO_KERNEL_LINEARIZE, s) : nullptr;
+            if (cap[SL_BLK]) {
+                if (lin_waves == 2)
+                    hipLaunchKernelGGL(k_linearize<2>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+                else if (lin_waves == 4)
+                    hipLaunchKernelGGL(k_linearize<4>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+                else
+                    hipLaunchKernelGGL(k_linearize<3>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+            }
+            if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+        }
+        if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
+        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_accum, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+        hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
+        LAUNCH_CHECK("linearisation kernels");
+        // ---- trust-region step of the windows that iterate
+        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+        {
+            EventPair* ep = time_kernels ? timed(LIMO_KERNEL_SCHUR, s) : nullptr;
+            int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
+            if (cap[SL_SPLAIN]) {
+                const int32_t* wlp = L(SL_SPLAIN);
+                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
+                note(hipLaunchKernel(schur_fn_plain, dim3(cap[SL_SPLAIN]), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
+            }
+            if (cap[SL_SFGP]) {
+                const int32_t* wlp = L(SL_SFGP);
+                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
+                note(hipLaunchKernel(schur_fn_leangp, dim3(cap[SL_SFGP]), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");
+            }
+            if (cap[SL_SGEN]) {
+                const int32_t* wlp = L(SL_SGEN);
+                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
+                note(hipLaunchKernel(schur_fn_gen, dim3(cap[SL_SGEN]), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
+            }
+            if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
+        }
+        hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
+        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, L(SL_LBLK));
+        if (cap[SL_BLK]) hipLaunchKernelGGL(k_cost, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+        if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 1, 0, 1);
+        hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
+        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
+        LAUNCH_CHECK("step kernels");
+        note(hipEventRecord(g.round_ev[round & 3], s), "record round");
+    }
+
+    // The host only enqueues; it learns that all windows are done from a pinned word the scheduler writes, two rounds
+    // late (so the streams never drain inside a solve).
+    int solve_streaming() {
+        int n_groups = P.n_win >= 2048 ? 2 : 1;
+        if (const char* e = std::getenv("KBA_GROUPS")) n_groups = std::max(1, std::min(4, std::atoi(e)));
+        if (stream_setup(n_groups) != LIMO_OK) return LIMO_ERR_RUNTIME;
+        set_span(P.n_win);
+        hipStream_t s0 = ctx->stream;
+        groups[0].stream = s0;
+        HIP_TRY(ctx, hipMemsetAsync(d_sched_ctl, 0, sizeof(int32_t) * 8, s0));
+        for (StreamGroup& g : groups) {
+            HIP_TRY(ctx, hipMemsetAsync(g.d_slot_win, 0xFF, sizeof(int32_t) * std::max(1, g.n_slots), s0));
+            for (int i = 0; i < 4; ++i) g.h_done[i] = 0;
+        }
+        HIP_TRY(ctx, hipEventRecord(start_ev, s0));
+        for (size_t gi = 1; gi < groups.size(); ++gi) HIP_TRY(ctx, hipStreamWaitEvent(groups[gi].stream, start_ev, 0));
+        const bool time_kernels = groups.size() == 1;  // kernel timing by events is only meaningful without overlap
         constexpr int kLag = 2;
-        for (int round = 0;; ++round) {
-            if (round > 0) note(hipStreamWaitEvent(s, trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
-            hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, sv, c);
-            hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(kSchedThreads), 0, s, sv, round);
-            hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(n_slots, 4)), dim3(256), 0, s, sv, c);
-            LAUNCH_CHECK("scheduler kernels");
-            // ---- trimming of the windows whose trimming solve just ended, on the side stream: k_trim_select is a
-            //      latency-bound sort (one workgroup per window, ~0.3 ms) - the other windows iterate meanwhile, the
-            //      trimmed ones join again in the next round (k_trim_select arms their next solve)
-            note(hipEventRecord(sched_ev, s), "record sched");
-            note(hipStreamWaitEvent(trim_stream, sched_ev, 0), "wait sched");
-            if (cap[SL_TBLK]) hipLaunchKernelGGL(k_trim_residual, dim3(cap[SL_TBLK]), dim3(kBlock), 0, trim_stream, sv, d_plane_rep, d_plane_dep, L(SL_TBLK));
-            if (cap[SL_TLBLK]) hipLaunchKernelGGL(k_trim_max, dim3(cap[SL_TLBLK]), dim3(kBlock), 0, trim_stream, sv, (const double*)d_plane_rep, (const double*)d_plane_dep, 0, 1);
-            hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, trim_stream, sv, c);
-            LAUNCH_CHECK("trim kernels");
-            note(hipEventRecord(trim_ev, trim_stream), "record trim");
-            // ---- linearisation of the windows that need it
-            hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
-            {
-                EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
-                if (cap[SL_BLK]) {
-                    if (lin_waves == 2)
-                        hipLaunchKernelGGL(k_linearize<2>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-                    else if (lin_waves == 4)
-                        hipLaunchKernelGGL(k_linearize<4>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-                    else
-                        hipLaunchKernelGGL(k_linearize<3>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-                }
-                if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
-            }
-            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
-            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_accum, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
-            hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
-            LAUNCH_CHECK("linearisation kernels");
-            // ---- trust-region step of the windows that iterate
-            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
-            {
-                EventPair* ep = timed(LIMO_KERNEL_SCHUR);
-                int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
-                if (cap[SL_SPLAIN]) {
-                    const int32_t* wlp = L(SL_SPLAIN);
-                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
-                    note(hipLaunchKernel(schur_fn_plain, dim3(cap[SL_SPLAIN]), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
-                }
-                if (cap[SL_SFGP]) {
-                    const int32_t* wlp = L(SL_SFGP);
-                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
-                    note(hipLaunchKernel(schur_fn_leangp, dim3(cap[SL_SFGP]), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");
-                }
-                if (cap[SL_SGEN]) {
-                    const int32_t* wlp = L(SL_SGEN);
-                    void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
-                    note(hipLaunchKernel(schur_fn_gen, dim3(cap[SL_SGEN]), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
-                }
-                if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
-            }
-            hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
-            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, L(SL_LBLK));
-            if (cap[SL_BLK]) hipLaunchKernelGGL(k_cost, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 1, 0, 1);
-            hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
-            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
-            LAUNCH_CHECK("step kernels");
-            note(hipEventRecord(round_ev[round & 3], s), "record round");
+        bool finished = false;
+        for (int round = 0; !finished; ++round) {
+            for (StreamGroup& g : groups) enqueue_round(g, round, time_kernels);
             if (rc != LIMO_OK) break;
             if (round >= kLag) {
-                note(hipEventSynchronize(round_ev[(round - kLag) & 3]), "sync round");
-                if (rc != LIMO_OK || h_done[(round - kLag) & 3] >= P.n_win) break;
+                finished = true;
+                for (StreamGroup& g : groups) {
+                    note(hipEventSynchronize(g.round_ev[(round - kLag) & 3]), "sync round");
+                    if (rc != LIMO_OK) break;
+                    if (g.h_done[(round - kLag) & 3] < P.n_win) finished = false;
+                }
             }
-            if (round > 100000) {
+            if (round > 200000) {
                 rc = LIMO_ERR_RUNTIME;
                 ctx->err = "streaming solve did not terminate";
                 break;
             }
         }
-        note(hipStreamWaitEvent(s, trim_ev, 0), "wait trim");
+        for (StreamGroup& g : groups) {  // everything joins the context's stream again
+            note(hipStreamWaitEvent(g.stream, g.trim_ev, 0), "wait trim");
+            if (g.stream != s0) {
+                note(hipEventRecord(g.done_ev, g.stream), "record done");
+                note(hipStreamWaitEvent(s0, g.done_ev, 0), "wait group");
+            }
+        }
         return rc;
     }
 
