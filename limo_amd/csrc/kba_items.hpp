@@ -80,7 +80,10 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // the factored Jacobian (kba_math.hpp:ft_build) and the camera-side sums U += Jp^T Jp, g += Jp^T r with
 // Jp = Ft [M | I], Ft = c^T Rc.  Same arithmetic as obs_residual_jacobian (kba_math.hpp) with the per-view products
 // taken from vl (view_consts_item) and without the landmark-side Jacobian, which nobody reads here.
-// Returns false where the reference functor fails (|z| < 0.01).
+// BRANCH-FREE on purpose: a landmark that is out of the problem (!in.live) or a failing functor (|z| < 0.01, returns
+// false when in.live) contributes zeros through a final mask - on the GPU the four passes of a lane are then one
+// straight-line stream and the compiler can keep the loads of the next pass in flight across the stores of this one
+// (with divergent branches around them it drained the memory queue every pass).
 KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4,
                     LinLane& out) {
     const double* H = vl;
@@ -88,8 +91,10 @@ KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, boo
     const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
     const double z0 = H[0] * p0 + H[1] * p1 + H[2] * p2 + vl[9];
     const double z1 = H[3] * p0 + H[4] * p1 + H[5] * p2 + vl[10];
-    const double z2 = H[6] * p0 + H[7] * p1 + H[8] * p2 + vl[11];
-    if (!(fabs(z2) >= 0.01)) return false;
+    const double z2r = H[6] * p0 + H[7] * p1 + H[8] * p2 + vl[11];
+    const bool z_ok = fabs(z2r) >= 0.01;
+    const bool ok = in.live != 0 && z_ok;
+    const double z2 = z_ok ? z2r : 1.0;  // keeps the arithmetic finite; masked below
     const double f = vl[25];
     const double iz = 1.0 / z2;
     const double xn = z0 * iz, yn = z1 * iz;
@@ -98,30 +103,30 @@ KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, boo
     const bool has_d = in.d > 0.0f;
     const double rd = has_d ? z2 - static_cast<double>(in.d) : 0.0;
     const double s_uv = ru * ru + rv * rv, s_d = rd * rd;
-    double su, sd = 0.0, cost = 0.0;
-    if (want_cost) {
+    double su, sd, cost = 0.0;
+    if (want_cost) {  // (uniform over a workgroup)
         double rho[3];
         loss_cauchy(c.a_rep, in.w, s_uv, rho);
         su = sqrt(rho[1]);
         cost = 0.5 * rho[0];
-        if (has_d) {
-            loss_cauchy(c.a_dep, in.w, s_d, rho);
-            sd = sqrt(rho[1]);
-            cost += 0.5 * rho[0];
-        }
+        loss_cauchy(c.a_dep, in.w, s_d, rho);
+        sd = sqrt(rho[1]);
+        cost += has_d ? 0.5 * rho[0] : 0.0;
     } else {
         su = sqrt(loss_cauchy_d1(c.a_rep, in.w, s_uv));
-        if (has_d) sd = sqrt(loss_cauchy_d1(c.a_dep, in.w, s_d));
+        sd = sqrt(loss_cauchy_d1(c.a_dep, in.w, s_d));
     }
-    out.cost += cost;
+    su = ok ? su : 0.0;
+    sd = ok && has_d ? sd : 0.0;
+    out.cost += ok ? cost : 0.0;
     const double r0 = su * ru, r1 = su * rv, r2 = sd * rd;
     r3[0] = r0;
     r3[1] = r1;
     r3[2] = r2;
     const double au = su * (f * iz);
     c4[0] = au;
-    c4[1] = xn;
-    c4[2] = yn;
+    c4[1] = ok ? xn : 0.0;
+    c4[2] = ok ? yn : 0.0;
     c4[3] = sd;
     double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft]
     for (int j = 0; j < 3; ++j) {
@@ -139,7 +144,7 @@ KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, boo
         for (int bb = a; bb < 6; ++bb) out.U[k++] += J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
         out.g[a] += J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
     }
-    return true;
+    return z_ok || in.live == 0;
 }
 
 // Lane t of linearize workgroup b (ACCUMULATES cost / fail / U / g into `out`: a GPU lane folds kObsPerLane
@@ -151,12 +156,8 @@ KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b,
     const int64_t o = bv.blk_obs0[b] + t;
     LinIn in;
     lin_fetch(bv, o, bv.obs_lm[o], in);
-    double r3[3] = {0.0, 0.0, 0.0}, c4[4] = {0.0, 0.0, 0.0, 0.0};
-    if (in.live && !lin_obs(bv.view_lin + (int64_t)kViewLin * view, c, in, want_cost, r3, c4, out)) {
-        for (int i = 0; i < 3; ++i) r3[i] = 0.0;
-        for (int i = 0; i < 4; ++i) c4[i] = 0.0;
-        out.fail = 1;
-    }
+    double r3[3], c4[4];
+    if (!lin_obs(bv.view_lin + (int64_t)kViewLin * view, c, in, want_cost, r3, c4, out)) out.fail = 1;
     for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
     for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
 }

@@ -351,7 +351,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     if (!st.active || !st.need_lin) return;
     const bool want_cost = st.first != 0;  // workgroup-uniform
     __shared__ double lds[4 * kLinPartial];
-    const double* vl = bv.view_lin + (int64_t)kViewLin * view;
+    // the view's constants: uniform loads BEFORE the first store of the kernel, so they are scalar loads into SGPRs
+    double vl[28];
+    {
+        const double* vg = bv.view_lin + (int64_t)kViewLin * view;
+#pragma unroll
+        for (int i = 0; i < 28; ++i) vl[i] = vg[i];
+    }
     const int n = bv.blk_n[b];
     const int64_t o0 = bv.blk_obs0[b];
     LinLane l;
@@ -362,35 +368,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
 #pragma unroll
     for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
     const int t0 = threadIdx.x;
-    // stage A: landmark index of the observation (-1 past the end of the block); stage B: the gathered inputs
-    int gl_a = t0 < n ? bv.obs_lm[o0 + t0] : -1;
-    int gl_b = t0 + kBlock < n ? bv.obs_lm[o0 + t0 + kBlock] : -1;
+    // No divergent branch touches memory: a lane past the end of a partial block (t >= n) loads the block's last
+    // observation, is treated as dead, and stores its zeros into the dump area behind the planes (index TOpad + lane).
+    const int64_t dump = bv.SO - kObsBlock + t0;
+    auto idx = [&](int t) { return o0 + (t < n ? t : n - 1); };
+    // stage A: landmark index of the observation; stage B: the gathered inputs
+    int gl_a = bv.obs_lm[idx(t0)];
+    int gl_b = bv.obs_lm[idx(t0 + kBlock)];
     LinIn cur;
-    cur.live = 0;
-    if (gl_a >= 0) lin_fetch(bv, o0 + t0, gl_a, cur);
+    lin_fetch(bv, idx(t0), gl_a, cur);
+    const int n_pass = (n + kBlock - 1) / kBlock;  // uniform
 #pragma unroll
     for (int q = 0; q < kObsPerLane; ++q) {
+        if (q >= n_pass) break;
         const int t = t0 + q * kBlock;
-        const int gl_n = gl_b;                     // landmark of pass q + 1
-        if (q + 2 < kObsPerLane) gl_b = t + 2 * kBlock < n ? bv.obs_lm[o0 + t + 2 * kBlock] : -1;
-        LinIn nxt;
-        nxt.live = 0;
-        if (q + 1 < kObsPerLane && gl_n >= 0) lin_fetch(bv, o0 + t + kBlock, gl_n, nxt);
-        if (t < n) {
-            double r3[3] = {0.0, 0.0, 0.0}, c4[4] = {0.0, 0.0, 0.0, 0.0};
-            if (cur.live && !lin_obs(vl, c, cur, want_cost, r3, c4, l)) {
+        const int gl_n = gl_b;  // landmark of pass q + 1
+        if (q + 2 < kObsPerLane) gl_b = bv.obs_lm[idx(t + 2 * kBlock)];
+        LinIn nxt = cur;
+        if (q + 1 < kObsPerLane) lin_fetch(bv, idx(t + kBlock), gl_n, nxt);
+        if (t >= n) cur.live = 0;
+        double r3[3], c4[4];
+        if (!lin_obs(vl, c, cur, want_cost, r3, c4, l)) l.fail = 1;
+        if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
+            const int64_t o = t < n ? o0 + t : dump;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) r3[i] = 0.0;
+            for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) c4[i] = 0.0;
-                l.fail = 1;
-            }
-            if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
-#pragma unroll
-                for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o0 + t] = r3[i];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o0 + t] = c4[i];
-            }
+            for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
         }
         cur = nxt;
     }

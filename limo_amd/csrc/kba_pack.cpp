@@ -151,7 +151,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.TV += nv;
         P.TO += W.n_obs;
     }
-    P.SO = pad64(std::max(1, P.TO));
+    P.SO = pad64(std::max(1, P.TO)) + kObsBlock;  // + a dump area: lanes past the end of a partial block store there (k_linearize)
     P.SL = pad64(std::max(1, P.TL));
     P.pose.resize((size_t)P.TK * 7);
     P.pdir.resize((size_t)P.TK * 3);

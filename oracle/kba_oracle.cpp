@@ -666,6 +666,42 @@ int oracle_functor(int kind, const double* consts, const double* p0, const doubl
             if (!SpeedRegularizationVector2::make(consts[0], consts[1], consts[2], a, b, f)) return -2;
             return f(p0, residuals) ? 1 : 0;
         }
+        case 10: {  // MotionModelRegularization (internal/motion_model_regularization.hpp:32-74): NOT on the solve path
+                    // (included at bundle_adjuster_keyframes.cpp:20, never instantiated); restated for its known-answer
+                    // test only (test/keyframe_bundle_adjustment.cpp:1212-1276), plain doubles
+            const Iso<double> p0_ = convert(p1), p1_ = convert(p0);  // operator()(pose_keyframe1_origin, pose_keyframe0_origin)
+            const Iso<double> m = compose(p1_, inverse(p0_));
+            // Eigen::Quaternion(rotation matrix) (Shepperd), then x = y = 0, normalise, yaw = sign(z) 2 acos(w)
+            double q[4];
+            const double* R = m.R;
+            double t = R[0] + R[4] + R[8];
+            if (t > 0.0) {
+                t = std::sqrt(t + 1.0);
+                q[0] = 0.5 * t;
+                t = 0.5 / t;
+                q[1] = (R[7] - R[5]) * t;
+                q[2] = (R[2] - R[6]) * t;
+                q[3] = (R[3] - R[1]) * t;
+            } else {
+                int i = 0;
+                if (R[4] > R[0]) i = 1;
+                if (R[8] > R[4 * i]) i = 2;
+                const int j = (i + 1) % 3, k = (j + 1) % 3;
+                t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+                q[1 + i] = 0.5 * t;
+                t = 0.5 / t;
+                q[0] = (R[3 * k + j] - R[3 * j + k]) * t;
+                q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * t;
+                q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * t;
+            }
+            const double n = std::sqrt(q[0] * q[0] + q[3] * q[3]);
+            const double w = q[0] / n, z = q[3] / n;
+            const double yaw = (z < 0.0 ? -1.0 : 1.0) * 2.0 * std::acos(w);
+            const double dy = std::fabs(yaw) < 1.e-6 ? 0.0 : m.t[0] / std::sin(yaw) * (1.0 - std::cos(yaw));
+            residuals[0] = m.t[1] - dy;
+            residuals[1] = m.t[2];
+            return 1;
+        }
     }
     return -1;
 }

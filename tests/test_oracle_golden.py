@@ -42,6 +42,34 @@ def euler_to_quat(e):
     return np.array([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy])
 
 
+def test_motion_model_regularization(oracle):
+    """CostFunctor.motion_regularization, test/keyframe_bundle_adjustment.cpp:1212-1276 (the live block): a motion on a
+    circle (yaw -10 deg, arc length -1) plus 0.2 of lift gives residual (0, 0.2).  The functor is not on the solve path
+    (never instantiated in the reference); restated for this known answer only."""
+    yaw = -10.0 / 180.0 * np.pi
+    l = -1.0
+    x, y = l / yaw * np.sin(yaw), l / yaw * (1 - np.cos(yaw))
+
+    def rz(a):
+        return np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+
+    def ry(a):
+        return np.array([[np.cos(a), 0, np.sin(a)], [0, 1.0, 0], [-np.sin(a), 0, np.cos(a)]])
+
+    def quat(R):  # (w,x,y,z) of a rotation matrix
+        w = 0.5 * np.sqrt(1 + np.trace(R))
+        return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+
+    R0, t0 = rz(0.2 * yaw), np.array([-50.0, -100.0, 0.1])
+    Rm, tm = rz(yaw) @ ry(yaw / 100.0), np.array([x, y, 0.2])
+    R1, t1 = Rm @ R0, Rm @ t0 + tm  # p1 = motion * p0
+    p0 = np.concatenate([quat(R0), t0])
+    p1 = np.concatenate([quat(R1), t1])
+    ok, r = oracle.functor(10, None, p1, p0, nres=2)
+    assert ok == 1
+    assert abs(r[0]) < 1e-10 and abs(r[1] - 0.2) < 1e-10
+
+
 def test_reprojection_error_point_ray(oracle):
     # KBA:118-175  f=600, c=(200,100), p=(1,1,10), obs=(260,160) -> (0,0) +-1e-5
     ok, r = oracle.functor(0, [260.0, 160.0, 600.0, 200.0, 100.0] + I7, I7, [1.0, 1.0, 10.0], nres=2)
