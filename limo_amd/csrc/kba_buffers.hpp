@@ -102,6 +102,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(delta_c, TK * kCamSlots * D, nullptr);
     KBA_BUF(S_part, (size_t)(P.spart_total > 0 ? P.spart_total : 1) * D, nullptr);
     KBA_BUF(S_red, (size_t)(P.sred_total > 0 ? P.sred_total : 1) * D, nullptr);
+    KBA_BUF(cam_scratch, (size_t)(P.camscr_total > 0 ? P.camscr_total : 1) * D, nullptr);
     KBA_BUF(reg_cost, NW * 2 * D, nullptr);
     KBA_BUF(trim_rep, TL * D, nullptr);
     KBA_BUF(trim_dep, TL * D, nullptr);

@@ -846,6 +846,8 @@ KBA_HD int cam_assemble_scratch(int nc, int nt) {
     const int dense = cam_max_reg_rows(nc) * kRegDense;
     return nc * nc + cam_assemble_union(nc) + (6 * nt > dense ? 6 * nt : dense);
 }
+// Windows whose scratch exceeds this many bytes work in global memory (WinDesc::cam_scr_off) instead of LDS (160 KB / CU).
+constexpr int kCamLdsCapBytes = 150 * 1024;
 KBA_HD int cam_solve_scratch(int nc, int nt) {
     return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + 3 * nt;  // A | y | dl | fl | red, sized for nf == nc
 }

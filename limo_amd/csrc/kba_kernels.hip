@@ -506,257 +506,139 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------ Schur complement (MFMA)
-// One WAVE per Schur workgroup (<= 256 landmarks of one window), no cross-wave synchronisation:
-//   per tile of 16 landmarks   fill:  lane (li = lane&15, kq = lane>>4) builds the 3 x 10 block of Y' of landmark li
-//                                     and free keyframe kq (+4, +8: one pass for up to four free keyframes) from the
-//                                     factored Jacobian planes and WRITES it (zeros included: no clearing, no
-//                                     read-modify-write) into the LDS tile Z[48][ld];
-//                              syrk:  12 k-steps of v_mfma_f64_16x16x4_f64; the 16-column panels of a k-step are read
-//                                     from LDS once and feed every upper tile (tr <= tc) of Z^T Z held in registers.
-//   Tiles of plain landmarks stop at the pose panels (columns [0, nfq]); ground-plane landmarks come last in every
-//   window (kba_pack.cpp), their tiles cover all panels.  The rhs rides along as column nfq (kba_items.hpp).
-// LDS per wave: 48 x (16 T + 1) doubles (18.8 KB at T = 3) -> 8 waves per CU overlap fill (VALU / memory) and syrk
-// (matrix pipe) of different workgroups.  TM = compile-time bound on T = nf_pad / 16.
+//   S -= sum_i Y'_i Y'_i^T  over the landmarks of a window, Y' = S_c F^T E S_l L^-T (kba_items.hpp).  Per tile of 16
+//   landmarks the 48 x (nf + 1) matrix Z (rows = landmark coordinates, columns = free camera slots + the rhs) is built
+//   in LDS and Z^T Z is accumulated with v_mfma_f64_16x16x4_f64 (A and B operands share the lane mapping: lane
+//   (i = lane & 15, k = lane >> 4) supplies Z[4 ks + k][16 t + i]).  Two kernels:
+//     k_schur_lean  windows with <= 4 free keyframes and one view per keyframe (the live configuration): one wave per
+//                   group of blocks, everything sized for occupancy (below);
+//     k_schur_wide  every other window (more free keyframes - up to kMaxKf - or several cameras per keyframe): a
+//                   512-lane workgroup shares one Z tile, its eight waves own the output tiles.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// LDS row stride (doubles) of the Schur tile: odd, so the rows of one MFMA operand (4 consecutive k) and the rows
-// written by neighbouring landmarks (stride 3 rows) spread over the banks.
-__host__ __device__ inline int schur_ld(int nfp) {
-    return nfp + 1;
+// ---- k_schur_wide<NPW>: 8 waves, wave w owns the upper tiles (tr <= tc) number w, w + 8, ... (NPW of them at most).
+//   fill:  thread (li = t & 15, q = t >> 4) builds the 3 x 10 block of landmark li and the q-th free keyframe (q + 32
+//          ... for more than 32) with kba_items.hpp:schur_pair_block (any number of views per keyframe) and writes it,
+//          zeros included, into Z[48][nfp + 1];
+//   syrk:  12 k-steps; per owned tile two panel reads and one MFMA.
+// LDS: 48 (nfp + 1) doubles + the window's scales / columns / view table (98 KB at nfp = 256).
+constexpr int kWideWaves = 8;
+__host__ __device__ inline int schur_wide_lds_bytes(int nfp, int nc, int n_view) {
+    return (3 * kSchurLm * (nfp + 1) + nc) * (int)sizeof(double) + (nc + n_view + kMaxKf + 2 + 2 * 160) * (int)sizeof(int);
 }
 
-constexpr int kSchurMaxViews = kMaxViews;  // checked at pack time (kba_pack.cpp)
-
-__host__ __device__ inline int schur_lds_bytes(int nfp) {
-    return (3 * kSchurLm * schur_ld(nfp) + kMaxNc + 9 * kMaxKf) * (int)sizeof(double) + (kMaxNc + kSchurMaxViews + kMaxKf + 4) * (int)sizeof(int);
-}
-
-// What a lane of the fast path holds one tile ahead (its landmark of the next tile, its keyframe is fixed).
-struct SchurPre {
-    double c[4];    // factored Jacobian of the (landmark, keyframe) observation: (au, xn, yn, sd)
-    double lmk[6];  // Bt = L^-1 S of the landmark (lm_damp_lane)
-    double p[3];    // landmark position
-    double t[3];    // L^-1 S g (lanes kq == 0 only)
-    int gl;
-    bool live, seen;  // landmark in the problem; it has an observation in this lane's keyframe
-};
-
-// FAST: every window of the batch has at most four keyframes with free slots and one view per keyframe (checked on
-// the host): one (landmark, keyframe) pair per lane, loads software-pipelined one tile ahead.
-template <int TM, bool FAST>
-__global__ __launch_bounds__(64) void k_schur(BatchView bv, const int32_t* wl, int span, int span_gp, int dbg) {
-    const int sb = wl_at(bv, wl, blockIdx.x);  // first Schur block of this wave's group
+template <int NPW>
+__global__ __launch_bounds__(64 * kWideWaves) void k_schur_wide(BatchView bv, const int32_t* wl, int span, int span_gp) {
+    const int sb = wl_at(bv, wl, blockIdx.x);  // first Schur block of this workgroup's group
     if (sb < 0) return;
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
-    const int nc = wd.nc, nfp = wd.nf_pad, nfq = wd.nfq, ld = schur_ld(nfp);
-    const int T = nfp / 16, Tq = (nfq + 16) / 16;  // panels of a full tile / of a pose-only tile (columns 0..nfq)
+    const int nc = wd.nc, nfp = wd.nf_pad, nfq = wd.nfq, ld = nfp + 1;  // nfp is a multiple of 16: ld is odd
+    const int T = nfp / 16, Tq = (nfq + 16) / 16;  // panels of a ground-plane tile / of a plain tile (columns 0..nfq)
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Z = smem;                                    // [3*kSchurLm][ld]
-    double* sc_s = Z + 3 * kSchurLm * ld;                // [kMaxNc] Jacobi scale by local slot
-    double* rc_s = sc_s + kMaxNc;                        // [kMaxKf][9] camera extrinsic rotation of the keyframe's view
-    int* zc_s = reinterpret_cast<int*>(rc_s + 9 * kMaxKf);  // [kMaxNc] tile column of a local slot or -1
-    int* vkl = zc_s + kMaxNc;                            // [kSchurMaxViews] local keyframe of each view
-    int* fk = vkl + kSchurMaxViews;                      // [kMaxKf] local keyframes with a free slot; [kMaxKf] count,
-                                                         // [kMaxKf+1] fast-path flag
-    const int lane = threadIdx.x;
-    for (int i = lane; i < nc; i += 64) {
+    double* Z = smem;                                      // [48][ld]
+    double* sc_s = Z + 3 * kSchurLm * ld;                  // [nc] Jacobi scale by local slot
+    int* zc_s = reinterpret_cast<int*>(sc_s + nc);         // [nc] tile column of a local slot or -1
+    int* vkl = zc_s + nc;                                  // [n_view] local keyframe of each view
+    int* fk = vkl + wd.n_view;                             // [kMaxKf] local keyframes with a free slot, [kMaxKf] their number
+    int* ttr = fk + kMaxKf + 2;                            // [<= 160] tile -> panel row / column
+    int* ttc = ttr + 160;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < nc; i += blockDim.x) {
         sc_s[i] = bv.scale_c[wd.cam0 + i];
         const int ci = bv.cslot[wd.cam0 + i];
         zc_s[i] = ci < 0 ? -1 : schur_col(ci, nfq);
     }
-    for (int j = lane; j < wd.n_view; j += 64) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
-    for (int i = lane; i < 3 * kSchurLm * ld; i += 64) Z[i] = 0.0;
-    __syncthreads();
-    for (int i = lane; i < 9 * wd.n_view; i += 64) {  // (one view per keyframe on the fast path; the last one wins otherwise)
-        const int j = i / 9;
-        rc_s[9 * vkl[j] + i % 9] = bv.view_cam[16 * (int64_t)(wd.view0 + j) + 4 + i % 9];
+    for (int j = t; j < wd.n_view; j += blockDim.x) vkl[j] = bv.view_kf[wd.view0 + j] - wd.kf0;
+    for (int i = t; i < 3 * kSchurLm * ld; i += blockDim.x) Z[i] = 0.0;
+    if (t == 0) {
+        int n = 0;
+        for (int tr = 0; tr < T; ++tr)
+            for (int tc = tr; tc < T; ++tc) {
+                ttr[n] = tr;
+                ttc[n] = tc;
+                ++n;
+            }
     }
-    if (lane == 0) {
-        int n = 0, mono = 1;
-        for (int k = 0; k < wd.n_kf; ++k) {
+    __syncthreads();
+    if (t == 0) {
+        int n = 0;
+        for (int k = 0; k < wd.n_kf; ++k)
             if (zc_s[k * kCamSlots] >= 0 || zc_s[k * kCamSlots + 6] >= 0) fk[n++] = k;
-            int nv = 0;
-            for (int j = 0; j < wd.n_view; ++j) nv += vkl[j] == k;
-            if (nv > 1) mono = 0;
-        }
         fk[kMaxKf] = n;
-        fk[kMaxKf + 1] = (n <= 4 && mono) ? 1 : 0;  // one (landmark, keyframe) pair per lane, one view per keyframe
     }
     __syncthreads();
-    const int nfk = fk[kMaxKf];
-    constexpr bool fast = FAST;
-    constexpr int NT = TM * (TM + 1) / 2;
-    v4f64 acc[NT];
+    const int nfk = fk[kMaxKf], n_tiles = T * (T + 1) / 2;
+    v4f64 acc[NPW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int li = lane & 15, kq = lane >> 4;
+    for (int i = 0; i < NPW; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int li = t & 15;
     const int sb_last = schur_group_last(wd, sb, span, span_gp);  // blocks of one class (plain / ground-plane) only
     const int lm_first = bv.sblk_lm0[sb];
     const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
-
-    // ---- fast path: lane constants (its keyframe) and the software pipeline over tiles
-    const int my_kl = (fast && kq < nfk) ? fk[kq] : -1;
-    int my_view = -1;
-    bool pose_free = false;
-    double Rk[9], qk[4];  // keyframe rotation, quaternion
-    if (my_kl >= 0) {
-        for (int j = 0; j < wd.n_view; ++j)
-            if (vkl[j] == my_kl) my_view = j;
-        pose_free = zc_s[my_kl * kCamSlots] >= 0;
-        const double* pose = bv.pose + 7 * (int64_t)(wd.kf0 + my_kl);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qk[i] = pose[i];
-        quat_R(qk, Rk);
-    }
-    const int32_t* my_slots = bv.lm_slot + (int64_t)(my_view >= 0 ? my_view : 0) * bv.SL;
-    auto fetch_index = [&](int l0, int& gl, int& st, int& slot) {
-        gl = lm_first + l0 + li;
-        st = 0;
-        slot = -1;
-        if (l0 + li < n_lm_blk) {
-            st = bv.lm_state[gl];
-            if (my_view >= 0 && pose_free) slot = my_slots[gl];
-        }
-    };
-    auto fetch_data = [&](int gl, int st, int slot, SchurPre& P) {
-        P.gl = gl;
-        P.live = st == 1;
-        P.seen = P.live && slot >= 0;
-        if (P.live && my_kl >= 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) P.lmk[i] = bv.lm_Li[i * bv.SL + gl];
-        }
-        if (P.live && kq == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) P.t[i] = bv.lm_t[i * bv.SL + gl];
-        }
-        if (P.seen && dbg != 35) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) P.p[i] = bv.lm[3 * (int64_t)gl + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) P.c[i] = bv.obs_c[i * bv.SO + slot];
-        }
-    };
-    SchurPre nxt;
-    int n_gl = 0, n_st = 0, n_slot = -1;  // indices of the tile after next
-    if constexpr (FAST) {
-        int gl0, st0, slot0;
-        fetch_index(0, gl0, st0, slot0);
-        fetch_index(kSchurLm, n_gl, n_st, n_slot);
-        fetch_data(gl0, st0, slot0, nxt);
-    }
-
-    for (int l0 = 0; l0 < (dbg == 38 ? 0 : n_lm_blk); l0 += kSchurLm) {
+    const bool tile_gp = sb - wd.sblk0 >= wd.n_sblk_plain;  // workgroup-uniform: the group's class
+    const int Tt = tile_gp ? T : Tq;
+    for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         const int nl = min(kSchurLm, n_lm_blk - l0);
-        const bool tile_gp = lm_first + l0 + nl > wd.lm_gp0;  // wave-uniform
-        const int Tt = tile_gp ? T : Tq;
-        if constexpr (FAST) {
-            const SchurPre cur = nxt;
-            // issue the loads of the next tile (and the indices of the one after) before this tile's arithmetic
-            fetch_data(n_gl, n_st, n_slot, nxt);
-            fetch_index(l0 + 2 * kSchurLm, n_gl, n_st, n_slot);
-            if (kq == 0) {
+        const int gl = lm_first + l0 + li;
+        const bool live = li < nl && bv.lm_state[gl] == 1;
+        double lmk[6];
+        if (live) schur_load_lm(bv, gl, lmk);
+        if (t < kSchurLm) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Z[(3 * li + c) * ld + nfq] = cur.live ? cur.t[c] : 0.0;
-            }
-            if (my_kl >= 0) {
-                double Y[3 * kCamSlots];
+            for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? bv.lm_t[cc * bv.SL + gl] : 0.0;
+        }
+        for (int q = t >> 4; q < nfk; q += (64 * kWideWaves) >> 4) {
+            const int kl = fk[q];
+            double Y[3 * kCamSlots];
+            if (live) {
+                schur_pair_block(bv, wd, gl, kl, lmk, sc_s, vkl, tile_gp, Y);
+            } else {
 #pragma unroll
                 for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
-                if (cur.seen && dbg != 31) {
-                    double M[9];
-                    rot_tangent_jac(qk, cur.p, M);
-                    double Ft[9];
-                    ft_build(cur.c, rc_s + 9 * my_kl, Ft);
-                    schur_pose_block(Ft, Rk, M, cur.lmk, sc_s + my_kl * kCamSlots, Y);
-                }
-                if (tile_gp && cur.live) {
-                    const int gg = bv.lm_gp[cur.gl];
-                    if (gg >= 0 && bv.gp_kf[gg] - wd.kf0 == my_kl)
-                        schur_gp_block(bv, gg, bv.cmask + (int64_t)wd.cam0 + my_kl * kCamSlots, cur.lmk,
-                                       sc_s + my_kl * kCamSlots, Y);
-                }
-#pragma unroll
-                for (int a = 0; a < kCamSlots; ++a) {
-                    if (a < 6 || tile_gp) {
-                        const int zc = zc_s[my_kl * kCamSlots + a];
-                        if (zc >= 0 && dbg != 36) {
-                            Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
-                            Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
-                            Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
-                        }
-                    }
-                }
             }
-        } else {
-            const int gl = lm_first + l0 + li;
-            const bool live = li < nl && bv.lm_state[gl] == 1;
-            double lmk[6];
-            if (live) schur_load_lm(bv, gl, lmk);
-            if (kq == 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Z[(3 * li + c) * ld + nfq] = live ? bv.lm_t[c * bv.SL + gl] : 0.0;
-            }
-            for (int q = kq; q < nfk; q += 4) {
-                const int kl = fk[q];
-                double Y[3 * kCamSlots];
-                if (live) {
-                    schur_pair_block(bv, wd, gl, kl, lmk, sc_s, vkl, tile_gp, Y);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 3 * kCamSlots; ++i) Y[i] = 0.0;
-                }
-#pragma unroll
-                for (int a = 0; a < kCamSlots; ++a) {
-                    if (a < 6 || tile_gp) {
-                        const int zc = zc_s[kl * kCamSlots + a];
-                        if (zc >= 0) {
-                            Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
-                            Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
-                            Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
-                        }
+            for (int a = 0; a < kCamSlots; ++a) {
+                if (a < 6 || tile_gp) {
+                    const int zc = zc_s[kl * kCamSlots + a];
+                    if (zc >= 0) {
+                        Z[(3 * li + 0) * ld + zc] = Y[a * 3 + 0];
+                        Z[(3 * li + 1) * ld + zc] = Y[a * 3 + 1];
+                        Z[(3 * li + 2) * ld + zc] = Y[a * 3 + 2];
                     }
                 }
             }
         }
         __syncthreads();
-        // Z^T Z, upper tiles: D[tr][tc] += sum_k Z[k][16 tr + i] Z[k][16 tc + j]   (A and B share the lane mapping)
-        const int ksteps = (3 * nl + 3) / 4;
-        const double* zp = Z + kq * ld + li;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            double pan[TM];
+        // Z^T Z, upper tiles owned by this wave: D[tr][tc] += sum_k Z[k][16 tr + i] Z[k][16 tc + j]
+        const double* zp = Z + (lane >> 4) * ld + (lane & 15);
 #pragma unroll
-            for (int t = 0; t < TM; ++t) pan[t] = (t < Tt && dbg != 37) ? zp[ks * 4 * ld + 16 * t] : 1.0;
-            int idx = 0;
+        for (int j = 0; j < NPW; ++j) {
+            const int ti = wave + kWideWaves * j;
+            if (ti < n_tiles) {  // wave-uniform
+                const int tr = ttr[ti], tc = ttc[ti];
+                if (tc < Tt) {
 #pragma unroll
-            for (int tr = 0; tr < TM; ++tr)
-#pragma unroll
-                for (int tc = tr; tc < TM; ++tc) {
-                    if (tc < Tt && dbg != 32) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[tr], pan[tc], acc[idx], 0, 0, 0);
-                    ++idx;
+                    for (int ks = 0; ks < 12; ++ks)
+                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zp[ks * 4 * ld + 16 * tr], zp[ks * 4 * ld + 16 * tc], acc[j], 0, 0, 0);
                 }
+            }
         }
         __syncthreads();
     }
     double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span, span_gp) * ((int64_t)nfp * nfp);
-    int idx = 0;
 #pragma unroll
-    for (int tr = 0; tr < TM; ++tr)
+    for (int j = 0; j < NPW; ++j) {
+        const int ti = wave + kWideWaves * j;
+        if (ti < n_tiles) {
+            const int tr = ttr[ti], tc = ttc[ti];
 #pragma unroll
-        for (int tc = tr; tc < TM; ++tc) {
-            if (tc < T) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
-                    out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = acc[idx][r];
-                }
-            }
-            ++idx;
+            for (int r = 0; r < 4; ++r)  // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+                out[(tr * 16 + (lane >> 4) + 4 * r) * nfp + tc * 16 + (lane & 15)] = acc[j][r];
         }
+    }
 }
-
 
 // ------------------------------------------------------------------------------------------ Schur complement, lean kernel
 // k_schur_lean<TM, GP>: the Schur blocks of the fast class (WinDesc::schur_fast: <= 4 free keyframes, one view each),
@@ -1031,7 +913,8 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
     WinState& st = bv.st[w];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (st.active && st.need_lin) {
-        cam_assemble(bv, c, w, threadIdx.x, blockDim.x, smem);
+        const int64_t so = bv.win[w].cam_scr_off;  // large windows (> ~12 keyframes) assemble in global memory
+        cam_assemble(bv, c, w, threadIdx.x, blockDim.x, so >= 0 ? bv.cam_scratch + so : smem);
         __syncthreads();
 #ifdef KBA_PROFILE_TICKS
         if (w == 0 && threadIdx.x == 0)
@@ -1066,7 +949,8 @@ __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts 
     if (!bv.st[w].active) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
-    cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, &flag);
+    const int64_t so = bv.win[w].cam_scr_off;
+    cam_solve(bv, c, w, threadIdx.x, blockDim.x, so >= 0 ? bv.cam_scratch + so : smem, &flag);
 #ifdef KBA_PROFILE_TICKS
     __syncthreads();
     if (w == 0 && threadIdx.x == 0)

@@ -17,7 +17,8 @@
 
 namespace kba {
 
-constexpr int kMaxKf = 12;        // max keyframes per window (max_size_optimization_window of the KITTI launch = 12)
+constexpr int kMaxKf = 20;        // max keyframes per window: the reference's default max_size_optimization_window
+                                  // (bundle_adjuster_keyframes.hpp:129); the KITTI launch runs 12
 constexpr int kMaxViews = 64;     // max (keyframe, camera) views per window (LDS tables of the Schur kernels)
 constexpr int kViewLin = 32;      // doubles per view in BatchView::view_lin
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
@@ -66,6 +67,8 @@ struct WinDesc {
     int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer
     int64_t spart_off;        // offset of this window's Schur partial slabs
     int64_t sred_off;         // offset of this window's per-shard slabs (n_shards x nf_pad^2) in S_red
+    int64_t cam_scr_off;      // >= 0: the window's camera system does not fit into LDS (more than ~12 keyframes): offset of its
+                              // scratch in BatchView::cam_scratch (k_cam_assemble / k_cam_solve work there, in L2, instead)
 };
 
 // Per-window Levenberg-Marquardt state (device resident; see kba_lm.hpp).
@@ -191,6 +194,7 @@ struct BatchView {
     double *scale_c, *yc, *delta_c;  // [TK*10]
     double *S_part;             // Schur partial slabs
     double *S_red;              // landmark-sharded solve: one slab per (window, shard) = sum of the shard's partial slabs
+    double* cam_scratch;        // scratch of the window-level kernels for windows too large for LDS (WinDesc::cam_scr_off)
     double* reg_cost;           // [n_win*2]: free / fixed regulariser cost at the linearisation point
     // --- trimming
     double *trim_rep, *trim_dep;   // [TL] max un-robustified residual norm per landmark, <0 = no block

@@ -101,7 +101,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         if (!po.pose_only && !po.evaluate_only && W.n_kf < 1)
             return fail(LIMO_ERR_NOT_ENOUGH_KF, "window without active keyframes");
         if (po.pose_only && W.n_kf != 1) return fail(LIMO_ERR_INVALID, "pose-only window must hold exactly one keyframe");
-        if (W.n_kf > kMaxKf) return fail(LIMO_ERR_INVALID, "window has more keyframes than kMaxKf (12)");
+        if (W.n_kf > kMaxKf) return fail(LIMO_ERR_INVALID, "window has more keyframes than kMaxKf (20)");
         if ((W.n_kf && (!W.kf_pose || !W.kf_plane_dir || !W.kf_plane_dist || !W.kf_fixation)) ||
             (W.n_lm && (!W.lm_pos || !W.lm_weight || !W.lm_is_ground)) || (W.n_cam && !W.cam) ||
             (W.n_obs && (!W.obs_kf || !W.obs_lm || !W.obs_cam || !W.obs_u || !W.obs_v || !W.obs_d)))
@@ -519,6 +519,14 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
         d.sred_off = P.sred_total;
         if (P.n_shards > 1) P.sred_total += (int64_t)P.n_shards * d.nf_pad * d.nf_pad;
+        {   // camera system too large for LDS: scratch in global memory (kba_items.hpp:kCamLdsCapBytes)
+            const int need = std::max(cam_assemble_scratch(d.nc, kBlock), cam_solve_scratch(d.nc, kBlock));
+            d.cam_scr_off = -1;
+            if (need * (int)sizeof(double) > kCamLdsCapBytes) {
+                d.cam_scr_off = P.camscr_total;
+                P.camscr_total += need;
+            }
+        }
         L = Local();
     }
     if (std::getenv("KBA_PACK_TRACE"))

@@ -69,10 +69,8 @@ struct limo_ba_batch : Executor {
     std::map<std::pair<int, int>, FullSblk> wl_sblk_full;
     // Schur worklists are ordered [plain groups of fast windows | ground-plane groups of fast windows | generic windows]
     int n_wl_sblk_plain = 0, n_wl_sblk_fgp = 0;
-    bool use_plain_kernel = true;             // KBA_SCHUR_PLAIN=0: plain groups go through k_schur<T, true> too (A/B timing)
     const void* schur_fn_plain = nullptr;
     int plain_lds_bytes = 0;
-    bool use_lean_gp = true;                  // KBA_SCHUR_GP_LEAN=0: ground-plane groups through k_schur<T, true> (A/B timing)
     const void* schur_fn_leangp = nullptr;
     int leangp_lds_bytes = 0;
     std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
@@ -81,18 +79,10 @@ struct limo_ba_batch : Executor {
     std::vector<int32_t> h_wl;
     bool use_wl = false;
     int n_wl_blk = 0, n_wl_lblk = 0, n_wl_sblk = 0, n_wl_win = 0, listed = 0;
-    int max_nc = 0, max_ld_bytes = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0, schur_T = 1;
-    const void *schur_fn_fast = nullptr, *schur_fn_gen = nullptr;  // per-window choice: results do not depend on
-                                                                   // what else is in the batch
-
-    static const void* pick_schur(int T, bool fast) {
-        if (fast) {
-            return T <= 2 ? (const void*)k_schur<2, true> : T <= 3 ? (const void*)k_schur<3, true>
-                 : T <= 4 ? (const void*)k_schur<4, true> : T <= 6 ? (const void*)k_schur<6, true> : (const void*)k_schur<8, true>;
-        }
-        return T <= 2 ? (const void*)k_schur<2, false> : T <= 3 ? (const void*)k_schur<3, false>
-             : T <= 4 ? (const void*)k_schur<4, false> : T <= 6 ? (const void*)k_schur<6, false> : (const void*)k_schur<8, false>;
-    }
+    int max_nc = 0, asm_bytes = 0, solve_bytes = 0, trim_bytes = 0;
+    const void* schur_fn_gen = nullptr;  // k_schur_wide<NPW> for the windows outside the fast class (chosen per window: results
+                                         // do not depend on what else is in the batch)
+    int wide_lds_bytes = 0;
     int rc = LIMO_OK;
     // ---- streaming solve (device-side scheduler k_sched): windows move through n_slots slots, a finished window is
     // replaced by the next pending one, so every launch round works on a full set (kba_kernels.hip:k_sched)
@@ -184,7 +174,6 @@ struct limo_ba_batch : Executor {
         std::memset(&bv, 0, sizeof(bv));
         win_fast.assign(P.n_win, 1);
         for (int w = 0; w < P.n_win; ++w) win_fast[w] = P.win[w].schur_fast ? 1 : 0;  // decided at pack time (kba_pack.cpp)
-        if (const char* e = std::getenv("KBA_SCHUR_PLAIN")) use_plain_kernel = std::atoi(e) != 0;
         // Every buffer of the batch view lives in ONE device block: [initialised buffers | zero-filled buffers].
         // Small batches (a single window) stage the initialised part in pinned host memory and upload it with one
         // copy; large ones copy buffer by buffer (no second host copy of hundreds of MB).  One memset for the rest.
@@ -287,30 +276,24 @@ struct limo_ba_batch : Executor {
         if (dmalloc((void**)&d_wl_win, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         if (dmalloc((void**)&d_flags, sizeof(int32_t) * std::max(1, P.n_win))) return LIMO_ERR_RUNTIME;
         for (const WinDesc& d : P.win) max_nc = std::max(max_nc, (int)d.nc);
-        int max_nfp = 16;
-        for (const WinDesc& d : P.win) max_nfp = std::max(max_nfp, (int)d.nf_pad);
-        max_ld_bytes = schur_lds_bytes(max_nfp);
         {
-            int t_fast = 1, t_gen = 1;
             bool any_fast = false, any_gen = false;
+            int t_gen = 1, nfp_gen = 16, nc_gen = kCamSlots, nv_gen = 1, max_nfq = 0, max_nf = 0;
             for (int w = 0; w < P.n_win; ++w) {
-                const int t = P.win[w].nf_pad / 16;
+                const WinDesc& d = P.win[w];
                 if (win_fast[w]) {
                     any_fast = true;
-                    t_fast = std::max(t_fast, t);
-                } else {
+                    max_nfq = std::max(max_nfq, (int)d.nfq);
+                    max_nf = std::max(max_nf, (int)d.nf);
+                } else if (d.n_sblk > 0) {
                     any_gen = true;
-                    t_gen = std::max(t_gen, t);
+                    t_gen = std::max(t_gen, d.nf_pad / 16);
+                    nfp_gen = std::max(nfp_gen, (int)d.nf_pad);
+                    nc_gen = std::max(nc_gen, (int)d.nc);
+                    nv_gen = std::max(nv_gen, (int)d.n_view);
                 }
             }
-            schur_T = std::max(t_fast, t_gen);
             if (any_fast) {
-                int max_nfq = 0;
-                for (int w = 0; w < P.n_win; ++w)
-                    if (win_fast[w]) max_nfq = std::max(max_nfq, (int)P.win[w].nfq);
-                int max_nf = 0;
-                for (int w = 0; w < P.n_win; ++w)
-                    if (win_fast[w]) max_nf = std::max(max_nf, (int)P.win[w].nf);
                 schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_lean<1, false, 4> : (const void*)k_schur_lean<2, false, 4>;
                 plain_lds_bytes = schur_lean_lds_bytes(max_nfq + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_plain, hipFuncAttributeMaxDynamicSharedMemorySize, plain_lds_bytes));
@@ -318,19 +301,26 @@ struct limo_ba_batch : Executor {
                 schur_fn_leangp = tg <= 1 ? (const void*)k_schur_lean<1, true, 3> : tg == 2 ? (const void*)k_schur_lean<2, true, 2> : (const void*)k_schur_lean<3, true, 2>;
                 leangp_lds_bytes = schur_lean_lds_bytes(max_nf + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_leangp, hipFuncAttributeMaxDynamicSharedMemorySize, leangp_lds_bytes));
-                if (const char* e = std::getenv("KBA_SCHUR_GP_LEAN")) use_lean_gp = std::atoi(e) != 0;
-            }
-            if (any_fast) {
-                schur_fn_fast = pick_schur(t_fast, true);
-                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_fast, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
             }
             if (any_gen) {
-                schur_fn_gen = pick_schur(t_gen, false);
-                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_gen, hipFuncAttributeMaxDynamicSharedMemorySize, max_ld_bytes));
+                const int tiles = t_gen * (t_gen + 1) / 2, npw = (tiles + kWideWaves - 1) / kWideWaves;
+                schur_fn_gen = npw <= 1 ? (const void*)k_schur_wide<1> : npw <= 3 ? (const void*)k_schur_wide<3>
+                             : npw <= 6 ? (const void*)k_schur_wide<6> : (const void*)k_schur_wide<12>;
+                if (npw > 12) {
+                    ctx->err = "window with too many free camera slots for k_schur_wide";
+                    return LIMO_ERR_INVALID;
+                }
+                wide_lds_bytes = schur_wide_lds_bytes(nfp_gen, nc_gen, nv_gen);
+                HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_gen, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds_bytes));
             }
         }
-        asm_bytes = cam_assemble_scratch(max_nc, kBlock) * (int)sizeof(double);
-        solve_bytes = cam_solve_scratch(max_nc, kBlock) * (int)sizeof(double);
+        {   // LDS of the window-level kernels: the largest window that still works in LDS (the others: cam_scr_off)
+            int nc_lds = kCamSlots;
+            for (const WinDesc& d : P.win)
+                if (d.cam_scr_off < 0) nc_lds = std::max(nc_lds, (int)d.nc);
+            asm_bytes = cam_assemble_scratch(nc_lds, kBlock) * (int)sizeof(double);
+            solve_bytes = cam_solve_scratch(nc_lds, kBlock) * (int)sizeof(double);
+        }
         int max_lm = 1;
         for (const WinDesc& d : P.win) max_lm = std::max(max_lm, (int)d.n_lm);
         {
@@ -611,33 +601,24 @@ struct limo_ba_batch : Executor {
             for (size_t i = 0; i < pv.size(); ++i) {
                 int n_plain = count_sblk_plain(i), n_fgp = count_sblk_fgp(i);
                 const int n_gen = count_sblk(i) - n_plain - n_fgp;
-                int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
+                int span = c.schur_span, span_gp = c.schur_span_gp;
                 const int32_t* wlp = list_sblk(i);
-                if (!use_plain_kernel) {  // the general fast kernel takes the plain groups as well
-                    n_fgp += n_plain;
-                    n_plain = 0;
-                }
                 if (n_plain) {
                     void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp};
                     note(hipLaunchKernel(schur_fn_plain, dim3(n_plain), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
                     LAUNCH_CHECK("k_schur_lean");
                     wlp += n_plain;
                 }
-                if (n_fgp && use_lean_gp && use_plain_kernel) {
+                if (n_fgp) {
                     void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp};
                     note(hipLaunchKernel(schur_fn_leangp, dim3(n_fgp), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");
                     LAUNCH_CHECK("k_schur_lean (gp)");
                     wlp += n_fgp;
-                } else if (n_fgp) {
-                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
-                    note(hipLaunchKernel(schur_fn_fast, dim3(n_fgp), dim3(64), args, max_ld_bytes, s), "launch k_schur");
-                    LAUNCH_CHECK("k_schur");
-                    wlp += n_fgp;
                 }
                 if (n_gen) {
-                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
-                    note(hipLaunchKernel(schur_fn_gen, dim3(n_gen), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
-                    LAUNCH_CHECK("k_schur");
+                    void* args[] = {(void*)&pv[i], (void*)&wlp, (void*)&span, (void*)&span_gp};
+                    note(hipLaunchKernel(schur_fn_gen, dim3(n_gen), dim3(64 * kWideWaves), args, wide_lds_bytes, s), "launch k_schur_wide");
+                    LAUNCH_CHECK("k_schur_wide");
                 }
             }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
@@ -843,7 +824,7 @@ struct limo_ba_batch : Executor {
         if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
         {
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_SCHUR, s) : nullptr;
-            int span = c.schur_span, span_gp = c.schur_span_gp, dbg = c.pad;
+            int span = c.schur_span, span_gp = c.schur_span_gp;
             if (cap[SL_SPLAIN]) {
                 const int32_t* wlp = L(SL_SPLAIN);
                 void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
@@ -856,8 +837,8 @@ struct limo_ba_batch : Executor {
             }
             if (cap[SL_SGEN]) {
                 const int32_t* wlp = L(SL_SGEN);
-                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp, (void*)&dbg};
-                note(hipLaunchKernel(schur_fn_gen, dim3(cap[SL_SGEN]), dim3(64), args, max_ld_bytes, s), "launch k_schur (generic)");
+                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
+                note(hipLaunchKernel(schur_fn_gen, dim3(cap[SL_SGEN]), dim3(64 * kWideWaves), args, wide_lds_bytes, s), "launch k_schur_wide");
             }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }

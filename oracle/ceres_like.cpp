@@ -283,7 +283,7 @@ struct Minimizer {
                 int off, l;
                 double w[10 * 3];
             };
-            WB wb[16];
+            WB wb[72];  // f-blocks touched by one landmark: <= 3 per keyframe (pose, plane normal, plane distance), 20+ keyframes
             int nwb = 0;
             for (int r : prog.e_rows[e]) {
                 const RowInfo& ri = prog.rows[r];

@@ -36,6 +36,9 @@ CASES = [
     dict(seed=47, n_kf=2, n_lm=150),  # TWO active keyframes (deactivateKeyframes(min_conn, 3, max) can leave exactly these,
                                       # mono_lidar.cpp:249; the reference only refuses keyframes_.size() < 3 pushed ones)
     dict(seed=48, n_kf=1, n_lm=120),  # ONE active keyframe, Pose-fixed: landmarks only
+    dict(seed=49, n_kf=20, n_lm=300),  # the reference's default max_size_optimization_window (bundle_adjuster_keyframes.hpp:129):
+                                       # 190 free camera slots - k_schur_wide, camera system in global memory
+    dict(seed=50, n_kf=14, n_lm=250, stereo_baseline=0.54),  # beyond the LDS-resident camera system, two cameras
     dict(seed=46, n_kf=4, n_lm=400, stereo_baseline=0.54),  # two cameras per keyframe (generic Schur path)
     dict(seed=909, n_kf=5, n_lm=2000),  # first solve FAILS at x0 (a reprojection block with |z| < 0.01), trimming removes it
 ]
