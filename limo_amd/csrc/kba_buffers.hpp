@@ -60,6 +60,8 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(view_win, TV * I, P.view_win.data());
     KBA_BUF(view_cam, TV * 16 * D, P.view_cam.data());
     KBA_BUF(view_lin, TV * kViewLin * D, nullptr);
+    KBA_BUF(view_lin_c, TV * kViewLin * D, nullptr);
+    KBA_BUF(kf_dR, TK * 9 * D, nullptr);
     KBA_BUF(blk_view, NB * I, P.blk_view.data());
     KBA_BUF(blk_obs0, NB * I, P.blk_obs0.data());
     KBA_BUF(blk_n, NB * I, P.blk_n.data());
@@ -131,8 +133,6 @@ inline std::vector<PartialArray> partial_arrays(const PackedBatch& P) {
         {offsetof(BatchView, lblk_part), NL * 8, false, 1 | 2 | 4},
         {offsetof(BatchView, S_part), (size_t)std::max<int64_t>(1, P.spart_total), false, 0},  // private per shard, never exchanged
         {offsetof(BatchView, S_red), (size_t)std::max<int64_t>(1, P.sred_total), false, 2},
-        {offsetof(BatchView, blk_cost_c), NB, false, 4},
-        {offsetof(BatchView, blk_fail_c), NB, true, 4},
         {offsetof(BatchView, gp_cost_c), TG, false, 4},
         {offsetof(BatchView, trim_rep), TL, false, 8},
         {offsetof(BatchView, trim_dep), TL, false, 8},

@@ -170,26 +170,6 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
     linearize_lane_acc(bv, c, b, t, out, want_cost);
 }
 
-// Cost of one observation at the CANDIDATE parameters.
-KBA_HD void cost_lane(const BatchView& bv, const SolveConsts& c, int b, int t, double& cost, int& fail) {
-    cost = 0.0;
-    fail = 0;
-    if (t >= bv.blk_n[b]) return;
-    const int view = bv.blk_view[b];
-    const int64_t o = bv.blk_obs0[b] + t;
-    const int gl = bv.obs_lm[o];
-    if (!bv.lm_state[gl]) return;
-    const double* cam = bv.view_cam + 16 * (int64_t)view;
-    double cst;
-    if (!obs_cost(bv.pose_c + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                  bv.lm_c + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl], c.a_rep, c.a_dep,
-                  &cst)) {
-        fail = 1;
-        return;
-    }
-    cost = cst;
-}
-
 // Un-robustified residual norms for trimming (robust_solving.cpp:24-44 with apply_loss = false).
 KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_rep, double* plane_dep) {
     if (t >= bv.blk_n[b]) return;
@@ -471,73 +451,114 @@ KBA_HD int schur_col(int i, int nfq) {
 }
 
 // ======================================================================================= back-substitution
-// y_l = (V'+D^2)^-1 (g' - W'^T y_c);  delta_l = -S_l y_l;  candidate = lm + delta_l.
-// part: [2] model-cost-change part, [3] |x - x_cand|^2, [4] |x_cand|^2
-KBA_HD void backsub_lane(const BatchView& bv, int gl, double* part) {
-    part[2] = part[3] = part[4] = 0.0;
-    double* xc = bv.lm_c + 3 * (int64_t)gl;
-    const double* x = bv.lm + 3 * (int64_t)gl;
-    if (bv.lm_state[gl] != 1) {
-        xc[0] = x[0];
-        xc[1] = x[1];
-        xc[2] = x[2];
+// y_l = (V'+D^2)^-1 (g' - W'^T y_c);  delta_l = -S_l y_l;  candidate = lm + delta_l;  then the cost of the landmark's
+// observations AT THE CANDIDATE (Evaluator cost-only pass): the lane holds the candidate landmark, the candidate
+// poses' per-view constants are in view_lin_c (k_cam_solve), so the measurements (12 B per observation through the slot
+// table) are all that is read - the separate observation-major cost pass read 52 B per observation.
+// part: [2] model-cost-change part, [3] |x - x_cand|^2, [4] |x_cand|^2, [6] candidate cost, [7] 1 = a functor failed
+KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int gl, double* part) {
+    part[2] = part[3] = part[4] = part[6] = part[7] = 0.0;
+    const int state = bv.lm_state[gl];
+    const double* xp = bv.lm + 3 * (int64_t)gl;
+    const double x[3] = {xp[0], xp[1], xp[2]};
+    double xc[3] = {x[0], x[1], x[2]};
+    if (state == 0) {  // out of the problem: the candidate is the point itself, no cost
+        double* o = bv.lm_c + 3 * (int64_t)gl;
+        o[0] = xc[0];
+        o[1] = xc[1];
+        o[2] = xc[2];
         return;
     }
     const int w = bv.lm_win[gl];
     const WinDesc& wd = bv.win[w];
-    double a[3] = {0, 0, 0};
+    if (state == 1) {
+        double a[3] = {0, 0, 0};
+        for (int j = 0; j < wd.n_view; ++j) {
+            const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+            if (s < 0) continue;
+            const int gk = bv.view_kf[wd.view0 + j];
+            const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
+            const double* dR = bv.kf_dR + 9 * (int64_t)gk;
+            const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);  // H = Rc R at [0..8], Rc at [12..20]
+            // F dc = Ft (dR x + d_trans);  E^T (F dc) with E = c^T H
+            double Ft[9], E[9], c4[4], m[3], q[3];
+            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
+            ft_build(c4, vl + 12, Ft);
+            ft_build(c4, vl, E);
+            mat3_vec(dR, x, m);
+            m[0] += dc[3];
+            m[1] += dc[4];
+            m[2] += dc[5];
+            mat3_vec(Ft, m, q);
+            for (int cc = 0; cc < 3; ++cc) a[cc] += E[cc] * q[0] + E[3 + cc] * q[1] + E[6 + cc] * q[2];
+        }
+        const int gg = bv.lm_gp[gl];
+        if (gg >= 0) {
+            const int gk = bv.gp_kf[gg];
+            const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
+            double q = 0.0;
+            for (int k = 0; k < kCamSlots; ++k) q += bv.gp_F[k * bv.SG + gg] * dc[k];
+            for (int cc = 0; cc < 3; ++cc) a[cc] += bv.gp_E[cc * bv.SG + gg] * q;
+        }
+        double Bt[6], t[3], V[6], g[3];
+        for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];  // L^-1 S (lm_damp_lane)
+        for (int i = 0; i < 3; ++i) t[i] = bv.lm_t[i * bv.SL + gl];
+        for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
+        for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
+        // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c):  t' = t + L^-1 S a
+        const double t0 = t[0] + Bt[0] * a[0];
+        const double t1 = t[1] + Bt[1] * a[0] + Bt[2] * a[1];
+        const double t2 = t[2] + Bt[3] * a[0] + Bt[4] * a[1] + Bt[5] * a[2];
+        // delta_l = -S L^-T t'
+        const double d0 = -(Bt[0] * t0 + Bt[1] * t1 + Bt[3] * t2);
+        const double d1 = -(Bt[2] * t1 + Bt[4] * t2);
+        const double d2 = -(Bt[5] * t2);
+        xc[0] = x[0] + d0;
+        xc[1] = x[1] + d1;
+        xc[2] = x[2] + d2;
+        const double Vd0 = V[0] * d0 + V[1] * d1 + V[2] * d2;
+        const double Vd1 = V[1] * d0 + V[3] * d1 + V[4] * d2;
+        const double Vd2 = V[2] * d0 + V[4] * d1 + V[5] * d2;
+        part[2] = -(g[0] * d0 + g[1] * d1 + g[2] * d2) - (a[0] * d0 + a[1] * d1 + a[2] * d2) -
+                  0.5 * (d0 * Vd0 + d1 * Vd1 + d2 * Vd2);
+        const double e0 = x[0] - xc[0], e1 = x[1] - xc[1], e2 = x[2] - xc[2];
+        part[3] = e0 * e0 + e1 * e1 + e2 * e2;
+        part[4] = xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
+    }
+    // ---- cost of this landmark's observations at (candidate poses, candidate point); state 2 = constant landmark of a
+    //      motion-only problem: its point is the candidate
+    const double lw = bv.lm_weight[gl];
+    double cost = 0.0;
+    int fail = 0;
     for (int j = 0; j < wd.n_view; ++j) {
         const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
         if (s < 0) continue;
-        const int gk = bv.view_kf[wd.view0 + j];
-        const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
-        // F dc = Ft (M d_rot + d_trans);  E^T (F dc) = R^T Ft^T (F dc)
-        const double* pose = bv.pose + 7 * (int64_t)gk;
-        double Ft[9], c4[4], R[9], M[9], m[3], q[3], v[3];
-        for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
-        ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
-        quat_R(pose, R);
-        rot_tangent_jac(pose, x, M);
-        mat3_vec(M, dc, m);
-        m[0] += dc[3];
-        m[1] += dc[4];
-        m[2] += dc[5];
-        mat3_vec(Ft, m, q);
-        for (int cc = 0; cc < 3; ++cc) v[cc] = Ft[cc] * q[0] + Ft[3 + cc] * q[1] + Ft[6 + cc] * q[2];
-        for (int cc = 0; cc < 3; ++cc) a[cc] += R[cc] * v[0] + R[3 + cc] * v[1] + R[6 + cc] * v[2];
+        const double* vc = bv.view_lin_c + (int64_t)kViewLin * (wd.view0 + j);
+        const double z0 = vc[0] * xc[0] + vc[1] * xc[1] + vc[2] * xc[2] + vc[9];
+        const double z1 = vc[3] * xc[0] + vc[4] * xc[1] + vc[5] * xc[2] + vc[10];
+        const double z2 = vc[6] * xc[0] + vc[7] * xc[1] + vc[8] * xc[2] + vc[11];
+        if (!(fabs(z2) >= 0.01)) {
+            fail = 1;
+            continue;
+        }
+        const float d = bv.obs_d[s];
+        const double ru = vc[25] * (z0 / z2) + vc[26] - static_cast<double>(bv.obs_u[s]);
+        const double rv = vc[25] * (z1 / z2) + vc[27] - static_cast<double>(bv.obs_v[s]);
+        double rho[3];
+        loss_cauchy(c.a_rep, lw, ru * ru + rv * rv, rho);
+        cost += 0.5 * rho[0];
+        if (d > 0.0f) {
+            const double rd = z2 - static_cast<double>(d);
+            loss_cauchy(c.a_dep, lw, rd * rd, rho);
+            cost += 0.5 * rho[0];
+        }
     }
-    const int gg = bv.lm_gp[gl];
-    if (gg >= 0) {
-        const int gk = bv.gp_kf[gg];
-        const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
-        double q = 0.0;
-        for (int k = 0; k < kCamSlots; ++k) q += bv.gp_F[k * bv.SG + gg] * dc[k];
-        for (int cc = 0; cc < 3; ++cc) a[cc] += bv.gp_E[cc * bv.SG + gg] * q;
-    }
-    double Bt[6], t[3], V[6], g[3];
-    for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];  // L^-1 S (lm_damp_lane)
-    for (int i = 0; i < 3; ++i) t[i] = bv.lm_t[i * bv.SL + gl];
-    for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
-    for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
-    // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c):  t' = t + L^-1 S a
-    const double t0 = t[0] + Bt[0] * a[0];
-    const double t1 = t[1] + Bt[1] * a[0] + Bt[2] * a[1];
-    const double t2 = t[2] + Bt[3] * a[0] + Bt[4] * a[1] + Bt[5] * a[2];
-    // delta_l = -S L^-T t'
-    const double d0 = -(Bt[0] * t0 + Bt[1] * t1 + Bt[3] * t2);
-    const double d1 = -(Bt[2] * t1 + Bt[4] * t2);
-    const double d2 = -(Bt[5] * t2);
-    xc[0] = x[0] + d0;
-    xc[1] = x[1] + d1;
-    xc[2] = x[2] + d2;
-    const double Vd0 = V[0] * d0 + V[1] * d1 + V[2] * d2;
-    const double Vd1 = V[1] * d0 + V[3] * d1 + V[4] * d2;
-    const double Vd2 = V[2] * d0 + V[4] * d1 + V[5] * d2;
-    part[2] = -(g[0] * d0 + g[1] * d1 + g[2] * d2) - (a[0] * d0 + a[1] * d1 + a[2] * d2) -
-              0.5 * (d0 * Vd0 + d1 * Vd1 + d2 * Vd2);
-    const double e0 = x[0] - xc[0], e1 = x[1] - xc[1], e2 = x[2] - xc[2];
-    part[3] = e0 * e0 + e1 * e1 + e2 * e2;
-    part[4] = xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
+    part[6] = cost;
+    part[7] = fail ? 1.0 : 0.0;
+    double* o = bv.lm_c + 3 * (int64_t)gl;
+    o[0] = xc[0];
+    o[1] = xc[1];
+    o[2] = xc[2];
 }
 
 // ======================================================================================= camera-only rows
@@ -1273,6 +1294,27 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             bv.pdist_c[gk] = bv.pdist[gk];
         }
     }
+    KBA_SYNC();
+    // what the landmark-side kernels need of the proposed camera step: dR per keyframe (back-substitution) and the
+    // per-view constants of the candidate poses (candidate cost), kba_math.hpp:quat_dR / view_consts_item
+    for (int k = tid; k < wd.n_kf; k += nt) {
+        const int gk = wd.kf0 + k;
+        const double zero3[3] = {0.0, 0.0, 0.0};
+        quat_dR(bv.pose + 7 * (int64_t)gk, cm[k * kCamSlots] ? dl + k * kCamSlots : zero3, bv.kf_dR + 9 * (int64_t)gk);
+    }
+    for (int j = tid; j < wd.n_view; j += nt) {
+        const int view = wd.view0 + j;
+        const double* cam = bv.view_cam + 16 * (int64_t)view;
+        const double* pc = bv.pose_c + 7 * (int64_t)bv.view_kf[view];
+        double* vl = bv.view_lin_c + (int64_t)kViewLin * view;
+        double R[9];
+        quat_R(pc, R);
+        mat3_mul(cam + 4, R, vl);
+        for (int i = 0; i < 3; ++i) vl[9 + i] = cam[4 + 3 * i] * pc[4] + cam[4 + 3 * i + 1] * pc[5] + cam[4 + 3 * i + 2] * pc[6] + cam[13 + i];
+        vl[25] = cam[0];
+        vl[26] = cam[1];
+        vl[27] = cam[2];
+    }
     KBA_TICK(12);
     // three sums at once (red holds 3*nt doubles)
     double v3[3] = {part, step2, cand2};
@@ -1298,9 +1340,9 @@ KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red
         c2 += bv.lblk_part[(int64_t)b * 8 + 4];
         if (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0) lfail = 1.0;
     }
-    for (int b = wd.blk0 + tid; b < wd.blk0 + wd.n_blk; b += nt) {
-        cost += bv.blk_cost_c[b];
-        if (bv.blk_fail_c[b]) cfail = 1.0;
+    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt) {  // candidate cost of the observations (backsub_lane)
+        cost += bv.lblk_part[(int64_t)b * 8 + 6];
+        if (bv.lblk_part[(int64_t)b * 8 + 7] != 0.0) cfail = 1.0;
     }
     for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost_c[g];
     const int nrows = reg_row_count(wd);

@@ -5,14 +5,14 @@
 //                                                    LandmarkDepthError incl. loss corrector and local
 //                                                    parameterisation (cost_functors_ceres.hpp:53-222,
 //                                                    bundle_adjuster_keyframes.cpp:584-620) + F^T F / F^T r block sums
-// k_cost          1 per observation          HBM     Evaluator::Evaluate(cost only) at the candidate point
 // k_gp            1 per ground-plane row     -       GroundPlaneHeightRegularization (cost_functors_ceres.hpp:355-392)
 // k_lm_accum      1 per landmark             HBM     E^T E, E^T r (SchurEliminator chunk), Jacobi column scale
 // k_lm_damp       1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark
 // k_schur<T>      wave per 256 lm            MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
 // k_cam_assemble  workgroup per window       -       camera-camera blocks, regularisers, IterationZero / step tail
 // k_cam_solve     workgroup per window       -       reduced camera system: dense Cholesky in LDS, camera step
-// k_backsub       1 per landmark             HBM     BackSubstitute + candidate point + model-cost-change parts
+// k_backsub       1 per landmark             HBM     BackSubstitute + candidate point + model-cost-change parts +
+//                                                    Evaluator::Evaluate(cost only) of its observations at the candidate
 // k_step_decide   1 per window               -       TrustRegionMinimizer step acceptance (kba_lm.hpp)
 // k_trim_*        1 per obs / lm / window    HBM     robust_optimization::solveTrimmed residual evaluation + quantile
 //
@@ -415,26 +415,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     if (threadIdx.x == 0) bv.blk_fail[b] = any_fail;
 }
 
-__global__ __launch_bounds__(kBlock) void k_cost(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl_at(bv, wl, blockIdx.x);
-    if (b < 0) return;
-    const int w = bv.view_win[bv.blk_view[b]];
-    if (!bv.st[w].active) return;
-    __shared__ double lds[4];
-    double cost = 0.0;
-    int fail = 0;
-    for (int q = 0; q < kObsPerLane; ++q) {
-        double cq;
-        int fq;
-        cost_lane(bv, c, b, threadIdx.x + q * kBlock, cq, fq);
-        cost += cq;
-        fail |= fq;
-    }
-    const int any_fail = __syncthreads_or(fail);
-    block_sum<1>(&cost, lds, bv.blk_cost_c + b);
-    if (threadIdx.x == 0) bv.blk_fail_c[b] = any_fail;
-}
-
 // shard / n_shards: landmark sharding - a shard evaluates only the rows of its own landmarks.
 // (streaming solve: grid = (listed windows, chunks of 256 rows of a window))
 __global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
@@ -493,16 +473,30 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c,
     if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 5] = any ? 1.0 : 0.0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, const int32_t* wl) {
+// back-substitution of the landmarks + the cost of their observations at the candidate point (kba_items.hpp:backsub_lane)
+__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
-    __shared__ double lds[12];
+    __shared__ double lds[16];
     double part[8];
-    part[2] = part[3] = part[4] = 0.0;
-    if ((int)threadIdx.x < bv.lblk_n[b]) backsub_lane(bv, bv.lblk_lm0[b] + threadIdx.x, part);
-    block_sum<3>(part + 2, lds, bv.lblk_part + (int64_t)b * 8 + 2);
+    part[2] = part[3] = part[4] = part[6] = part[7] = 0.0;
+    if ((int)threadIdx.x < bv.lblk_n[b]) backsub_lane(bv, c, bv.lblk_lm0[b] + threadIdx.x, part);
+    const int any_fail = __syncthreads_or(part[7] != 0.0);
+    const double v4[4] = {part[2], part[3], part[4], part[6]};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double sum = wave_sum(v4[i]);
+        if (lane == 0) lds[wave * 4 + i] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int slot = threadIdx.x < 3 ? 2 + threadIdx.x : 6;
+        bv.lblk_part[(int64_t)b * 8 + slot] = (lds[threadIdx.x] + lds[4 + threadIdx.x]) + (lds[8 + threadIdx.x] + lds[12 + threadIdx.x]);
+    }
+    if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 7] = any_fail ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------ Schur complement (MFMA)

@@ -151,6 +151,9 @@ struct BatchView {
     const int32_t* view_kf;     // [TV] global keyframe index
     const int32_t* view_win;    // [TV]
     const double* view_cam;     // [TV*16] f,cx,cy,pad, Rc[9], tc[3]
+    double* view_lin_c;         // [TV*kViewLin] the same for the CANDIDATE poses (written by k_cam_solve; H, h0, intrinsics)
+    double* kf_dR;              // [TK*9] dR = derivative of R(q) along the proposed rotation step of the keyframe (k_cam_solve):
+                                // F_pose delta_pose of an observation = Ft (dR p + delta_t), no per-observation M(q, p)
     double* view_lin;           // [TV*kViewLin] per-view constants of the CURRENT poses (k_view_consts): H = Rc R(q) (9),
                                 // h0 = Rc t + tc (3), Rc (9), q (4), f, cx, cy - wave-uniform operands of k_linearize
     const int32_t* blk_view;    // [n_blk]

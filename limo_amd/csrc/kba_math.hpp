@@ -86,6 +86,26 @@ KBA_HD void rot_tangent_jac(const double* q, const double* p, double* M) {
     M[8] = -Aw2 * z - Ax2 * y + Ay2 * x + Az2 * w;
 }
 
+// dR (3x3, row-major) = derivative of the polynomial R(q) along the tangent step delta of the left-multiplying quaternion
+// update (dq = P(q) delta, P = QuaternionParameterization::ComputeJacobian): rot_tangent_jac(q, p, M) M delta == dR p
+// for every p.  One matrix per keyframe instead of one M per observation wherever only the PRODUCT with a step is needed.
+KBA_HD void quat_dR(const double* q, const double* delta, double* D) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double dw = -x * delta[0] - y * delta[1] - z * delta[2];
+    const double dx = w * delta[0] + z * delta[1] - y * delta[2];
+    const double dy = -z * delta[0] + w * delta[1] + x * delta[2];
+    const double dz = y * delta[0] - x * delta[1] + w * delta[2];
+    D[0] = -4.0 * (y * dy + z * dz);
+    D[1] = 2.0 * (y * dx + x * dy - z * dw - w * dz);
+    D[2] = 2.0 * (z * dx + x * dz + y * dw + w * dy);
+    D[3] = 2.0 * (y * dx + x * dy + z * dw + w * dz);
+    D[4] = -4.0 * (x * dx + z * dz);
+    D[5] = 2.0 * (z * dy + y * dz - x * dw - w * dx);
+    D[6] = 2.0 * (z * dx + x * dz - y * dw - w * dy);
+    D[7] = 2.0 * (z * dy + y * dz + x * dw + w * dx);
+    D[8] = -4.0 * (x * dx + y * dy);
+}
+
 // ---------------------------------------------------------------------------------------- losses
 // rho[0..2] of ScaledLoss(CauchyLoss(a), weight) at s
 KBA_HD void loss_cauchy(double a, double weight, double s, double* rho) {

@@ -634,12 +634,8 @@ struct limo_ba_batch : Executor {
         LAUNCH_CHECK("k_cam_solve");
         for (size_t i = 0; i < pv.size(); ++i) {
             if (count_lblk(i)) {
-                hipLaunchKernelGGL(k_backsub, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], list_lblk(i));
+                hipLaunchKernelGGL(k_backsub, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], c, list_lblk(i));
                 LAUNCH_CHECK("k_backsub");
-            }
-            if (count_blk(i)) {
-                hipLaunchKernelGGL(k_cost, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
-                LAUNCH_CHECK("k_cost");
             }
             if (P.TG) {
                 hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 1, shard_of(i), shard_P);
@@ -843,8 +839,7 @@ struct limo_ba_batch : Executor {
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
         hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
-        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, L(SL_LBLK));
-        if (cap[SL_BLK]) hipLaunchKernelGGL(k_cost, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
+        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
         if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 1, 0, 1);
         hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
         if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);

@@ -252,34 +252,21 @@ struct EmuBatch : Executor {
                 if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
                 const int w = v.lblk_win[b];
                 if (!v.st[w].active) continue;
-                double mcc = 0.0, s2 = 0.0, c2 = 0.0;
+                double mcc = 0.0, s2 = 0.0, c2 = 0.0, cost = 0.0, fail = 0.0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) {
                     double part[8];
-                    backsub_lane(v, v.lblk_lm0[b] + t, part);
+                    backsub_lane(v, c, v.lblk_lm0[b] + t, part);
                     mcc += part[2];
                     s2 += part[3];
                     c2 += part[4];
+                    cost += part[6];
+                    if (part[7] != 0.0) fail = 1.0;
                 }
                 v.lblk_part[(int64_t)b * 8 + 2] = mcc;
                 v.lblk_part[(int64_t)b * 8 + 3] = s2;
                 v.lblk_part[(int64_t)b * 8 + 4] = c2;
-            }
-            // candidate cost
-            for (int b = 0; b < v.n_blk; ++b) {
-                if (!owns(si, shard_P > 1 ? P.blk_owner[b] : 0)) continue;
-                const int w = v.view_win[v.blk_view[b]];
-                if (!v.st[w].active) continue;
-                double cost = 0.0;
-                int fail = 0;
-                for (int t = 0; t < kObsBlock; ++t) {
-                    double cst;
-                    int f;
-                    cost_lane(v, c, b, t, cst, f);
-                    cost += cst;
-                    fail |= f;
-                }
-                v.blk_cost_c[b] = cost;
-                v.blk_fail_c[b] = fail;
+                v.lblk_part[(int64_t)b * 8 + 6] = cost;  // candidate cost of the observations of these landmarks
+                v.lblk_part[(int64_t)b * 8 + 7] = fail;
             }
             for (int w = 0; w < v.n_win; ++w) {
                 if (!v.st[w].active) continue;
