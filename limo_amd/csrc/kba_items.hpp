@@ -235,13 +235,11 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
     for (int j = 0; j < wd.n_view; ++j) {
         const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
         if (s < 0) continue;
-        double E[9], Ft[9], R[9], r[3];
+        double E[9], r[3];
         double c4[4];
         for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
         for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
-        ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
-        quat_R(bv.pose + 7 * (int64_t)bv.view_kf[wd.view0 + j], R);
-        mat3_mul(Ft, R, E);
+        ft_build(c4, bv.view_lin + (int64_t)kViewLin * (wd.view0 + j), E);  // E = c^T H, H = Rc R(q) of the view (view_consts_item)
         for (int row = 0; row < 3; ++row) {
             const double e0 = E[row * 3], e1 = E[row * 3 + 1], e2 = E[row * 3 + 2];
             V[0] += e0 * e0;
@@ -1266,14 +1264,36 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         const double* d = dl + k * kCamSlots;
         const double* x = bv.pose + 7 * (int64_t)gk;
         double* xc = bv.pose_c + 7 * (int64_t)gk;
+        double pc[7];  // candidate pose (kept in registers for the per-view constants below)
         if (cm[k * kCamSlots + 0]) {
-            pose_plus(x, d, xc);
+            pose_plus(x, d, pc);
             for (int i = 0; i < 7; ++i) {
-                step2 += (x[i] - xc[i]) * (x[i] - xc[i]);
-                cand2 += xc[i] * xc[i];
+                step2 += (x[i] - pc[i]) * (x[i] - pc[i]);
+                cand2 += pc[i] * pc[i];
             }
         } else {
-            for (int i = 0; i < 7; ++i) xc[i] = x[i];
+            for (int i = 0; i < 7; ++i) pc[i] = x[i];
+        }
+        for (int i = 0; i < 7; ++i) xc[i] = pc[i];
+        {   // what the landmark-side kernels need of the proposed camera step: dR of this keyframe (back-substitution:
+            // F_pose delta = Ft (dR p + delta_t), kba_math.hpp:quat_dR) and the per-view constants of its candidate
+            // pose (candidate cost, cf. view_consts_item)
+            const double zero3[3] = {0.0, 0.0, 0.0};
+            quat_dR(x, cm[k * kCamSlots] ? d : zero3, bv.kf_dR + 9 * (int64_t)gk);
+            double Rk[9];
+            quat_R(pc, Rk);
+            for (int j = 0; j < wd.n_view; ++j) {
+                const int view = wd.view0 + j;
+                if (bv.view_kf[view] != gk) continue;
+                const double* cam = bv.view_cam + 16 * (int64_t)view;
+                double* vl = bv.view_lin_c + (int64_t)kViewLin * view;
+                mat3_mul(cam + 4, Rk, vl);
+                for (int i = 0; i < 3; ++i)
+                    vl[9 + i] = cam[4 + 3 * i] * pc[4] + cam[4 + 3 * i + 1] * pc[5] + cam[4 + 3 * i + 2] * pc[6] + cam[13 + i];
+                vl[25] = cam[0];
+                vl[26] = cam[1];
+                vl[27] = cam[2];
+            }
         }
         const double* n = bv.pdir + 3 * (int64_t)gk;
         double* ncand = bv.pdir_c + 3 * (int64_t)gk;
@@ -1293,27 +1313,6 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         } else {
             bv.pdist_c[gk] = bv.pdist[gk];
         }
-    }
-    KBA_SYNC();
-    // what the landmark-side kernels need of the proposed camera step: dR per keyframe (back-substitution) and the
-    // per-view constants of the candidate poses (candidate cost), kba_math.hpp:quat_dR / view_consts_item
-    for (int k = tid; k < wd.n_kf; k += nt) {
-        const int gk = wd.kf0 + k;
-        const double zero3[3] = {0.0, 0.0, 0.0};
-        quat_dR(bv.pose + 7 * (int64_t)gk, cm[k * kCamSlots] ? dl + k * kCamSlots : zero3, bv.kf_dR + 9 * (int64_t)gk);
-    }
-    for (int j = tid; j < wd.n_view; j += nt) {
-        const int view = wd.view0 + j;
-        const double* cam = bv.view_cam + 16 * (int64_t)view;
-        const double* pc = bv.pose_c + 7 * (int64_t)bv.view_kf[view];
-        double* vl = bv.view_lin_c + (int64_t)kViewLin * view;
-        double R[9];
-        quat_R(pc, R);
-        mat3_mul(cam + 4, R, vl);
-        for (int i = 0; i < 3; ++i) vl[9 + i] = cam[4 + 3 * i] * pc[4] + cam[4 + 3 * i + 1] * pc[5] + cam[4 + 3 * i + 2] * pc[6] + cam[13 + i];
-        vl[25] = cam[0];
-        vl[26] = cam[1];
-        vl[27] = cam[2];
     }
     KBA_TICK(12);
     // three sums at once (red holds 3*nt doubles)

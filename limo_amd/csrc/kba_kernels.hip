@@ -907,8 +907,13 @@ __global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveCons
     WinState& st = bv.st[w];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (st.active && st.need_lin) {
-        const int64_t so = bv.win[w].cam_scr_off;  // large windows (> ~12 keyframes) assemble in global memory
-        cam_assemble(bv, c, w, threadIdx.x, blockDim.x, so >= 0 ? bv.cam_scratch + so : smem);
+        // large windows (> ~12 keyframes) assemble in global memory.  Two calls, not one with a selected pointer: the
+        // scratch accesses of the common case must stay LDS instructions (a pointer that may be either makes them flat)
+        const int64_t so = bv.win[w].cam_scr_off;
+        if (so >= 0)
+            cam_assemble(bv, c, w, threadIdx.x, blockDim.x, bv.cam_scratch + so);
+        else
+            cam_assemble(bv, c, w, threadIdx.x, blockDim.x, smem);
         __syncthreads();
 #ifdef KBA_PROFILE_TICKS
         if (w == 0 && threadIdx.x == 0)
@@ -943,8 +948,11 @@ __global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts 
     if (!bv.st[w].active) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
-    const int64_t so = bv.win[w].cam_scr_off;
-    cam_solve(bv, c, w, threadIdx.x, blockDim.x, so >= 0 ? bv.cam_scratch + so : smem, &flag);
+    const int64_t so = bv.win[w].cam_scr_off;  // (two calls: see k_cam_assemble)
+    if (so >= 0)
+        cam_solve(bv, c, w, threadIdx.x, blockDim.x, bv.cam_scratch + so, &flag);
+    else
+        cam_solve(bv, c, w, threadIdx.x, blockDim.x, smem, &flag);
 #ifdef KBA_PROFILE_TICKS
     __syncthreads();
     if (w == 0 && threadIdx.x == 0)
