@@ -1,0 +1,140 @@
+// limo_stream — ROS-free streaming visual odometry on a synthetic KITTI-00-shaped drive (BASELINE.json configs[4]):
+//   per frame: 64-beam sweep + tracked features -> StreamDriver (limo_depth_estimate -> adjustPoseOnly -> keyframe
+//   selection -> push -> deactivateKeyframes -> solve) -> KITTI pose row.
+// The replacement of the reference's demo application (demo_keyframe_bundle_adjustment_meta/apps/main_program/
+// main_program.cpp:39-216 reads KITTI data from disk and plays it through the ROS nodes; there is no dataset here, so the
+// drive is synthesised by synth_world.hpp) and of the node's callback (limo_amd/kba/stream_driver.hpp).
+//
+//   limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses out.txt] [--no-depth] [--quiet]
+// Prints one summary line per run and `key value` lines for scripts: fps of the pipeline (input synthesis excluded and
+// reported separately), ATE against the ground truth, share of features that received a LiDAR depth.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+
+#include "../../limo_amd/kba/stream_driver.hpp"
+#include "synth_world.hpp"
+
+using namespace keyframe_bundle_adjustment;
+
+int main(int argc, char** argv) {
+    int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
+    uint64_t seed = 7;
+    std::string poses_path;
+    bool use_depth = true, quiet = false;
+    for (int i = 1; i < argc; ++i) {
+        auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
+        if (arg("--frames")) n_frames = std::atoi(argv[++i]);
+        else if (arg("--features")) n_feat = std::atoi(argv[++i]);
+        else if (arg("--az")) n_az = std::atoi(argv[++i]);
+        else if (arg("--seed")) seed = std::strtoull(argv[++i], nullptr, 10);
+        else if (arg("--window")) window = std::atoi(argv[++i]);
+        else if (arg("--poses")) poses_path = argv[++i];
+        else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
+        else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else {
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses file] [--no-depth] [--quiet]\n");
+            return 2;
+        }
+    }
+    using clk = std::chrono::steady_clock;
+    synth_world::World world(n_frames, seed);
+    world.n_az = n_az;
+    Camera::Ptr cam = std::make_shared<Camera>(world.f, Vector2d(world.cx, world.cy), world.cam_veh);
+    StreamParams sp;
+    sp.max_size_optimization_window = window;
+    sp.assign_depth = use_depth;
+    sp.solver_time_sec = -1.;  // no wall-clock cap: the drive is reproducible
+    sp.image_width = (int)world.W;
+    sp.image_height = (int)world.H;
+    sp.height_over_ground = synth_world::World::kHeightOverGround;
+    StreamDriver driver(sp, cam, world.cam_lidar);
+
+    std::mt19937_64 rng(seed * 31 + 1);
+    const int history = 10;
+    std::vector<int> live;  // landmarks tracked in the previous frame
+    std::map<int, int> first_seen;
+    std::vector<float> cloud;
+    std::vector<uint8_t> cloud_ground;
+    double sec_synth = 0., sec_pipeline = 0.;
+    size_t n_points = 0;
+    for (int t = 0; t < n_frames; ++t) {
+        const auto t0 = clk::now();
+        world.sweep(t, cloud, cloud_ground);
+        n_points += cloud.size() / 4;
+        // tracks that survive into this frame (still visible, not occluded), then new ones up to n_feat
+        const Vector3d here = world.origin_veh[t].translation();
+        const std::vector<int> near = world.boxes_near(here, 70.);
+        std::vector<int> now;
+        std::vector<double> uvz;
+        for (int id : live) {
+            double u, v, z;
+            if (world.visible(t, world.lms[id], near, u, v, z)) now.push_back(id);
+        }
+        if ((int)now.size() < n_feat) {
+            const size_t before = world.lms.size();
+            world.spawn(t, cloud, cloud_ground, n_feat - (int)now.size(), rng);
+            for (size_t id = before; id < world.lms.size(); ++id) {
+                now.push_back((int)id);
+                first_seen[(int)id] = t;
+            }
+        }
+        Tracklets ts;
+        for (int k = 0; k < history && t - k >= 0; ++k) ts.stamps.push_back((uint64_t)(t - k) * 50000000ull + 1000ull);
+        for (int id : now) {
+            Tracklet tr;
+            tr.id = id;
+            const int age = std::min(history, t - first_seen[id] + 1);
+            for (int k = 0; k < age; ++k) {
+                double u, v, z;
+                if (!world.project(t - k, world.lms[id].p, u, v, z)) break;
+                double n3[3];
+                synth_world::hash_normals((uint64_t)(t - k) * 1000003ull + (uint64_t)id, n3);
+                tr.feature_points.push_back(FeaturePoint((float)(u + 0.3 * n3[0]), (float)(v + 0.3 * n3[1])));  // d < 0: the driver fills it
+            }
+            if (tr.feature_points.empty()) continue;
+            tr.age = tr.feature_points.size();
+            tr.label = world.lms[id].ground ? 7 : 11;  // cityscapes road / building
+            ts.tracks.push_back(tr);
+        }
+        live = now;
+        const auto t1 = clk::now();
+        driver.process(ts, cloud.data(), cloud.size() / 4);
+        const auto t2 = clk::now();
+        sec_synth += std::chrono::duration<double>(t1 - t0).count();
+        sec_pipeline += std::chrono::duration<double>(t2 - t1).count();
+        if (!quiet && (t % 100 == 0 || t == n_frames - 1)) {
+            const Vector3d e = driver.poses().back().inverse().translation() - world.origin_veh[t].translation();
+            std::printf("frame %d: %zu tracks, %zu points, position error %.3f m, %d keyframes, %d solves\n", t, ts.tracks.size(), cloud.size() / 4, e.norm(),
+                        driver.stats().keyframes, driver.stats().solves);
+            std::fflush(stdout);
+        }
+    }
+    // absolute trajectory error of the dumped poses (vehicle positions in the origin frame)
+    double se = 0., worst = 0.;
+    for (int t = 0; t < n_frames; ++t) {
+        const Vector3d e = driver.poses()[t].inverse().translation() - world.origin_veh[t].translation();
+        se += e.norm() * e.norm();
+        worst = std::max(worst, e.norm());
+    }
+    const double ate = std::sqrt(se / n_frames);
+    if (!poses_path.empty()) {
+        std::ofstream f(poses_path);
+        driver.writeKittiTrajectory(f);
+    }
+    const auto& st = driver.stats();
+    std::printf("limo_stream: %d frames (%d keyframes, %d solves, window %d), %.0f points and %.0f features per frame, %.1f %% of the features with a LiDAR depth\n",
+                n_frames, st.keyframes, st.solves, window, (double)n_points / n_frames, (double)st.features / n_frames,
+                100. * st.features_with_depth / std::max(1, st.features));
+    std::printf("limo_stream: pipeline %.2f ms per frame -> %.1f frames/s (depth %.2f, pose-only %.2f, push %.2f, solve %.2f ms per frame; %.2f ms per solve()); input synthesis %.1f ms per frame\n",
+                1e3 * sec_pipeline / n_frames, n_frames / sec_pipeline, 1e3 * st.sec_depth / n_frames, 1e3 * st.sec_pose_only / n_frames,
+                1e3 * st.sec_push / n_frames, 1e3 * st.sec_solve / n_frames, st.solves ? 1e3 * st.sec_solve / st.solves : 0., 1e3 * sec_synth / n_frames);
+    std::printf("limo_stream: ATE rmse %.4f m (max %.4f m) over %.1f m\n", ate, worst, 0.55 * (n_frames - 1));
+    std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\n", n_frames, n_frames / sec_pipeline, ate, worst,
+                (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves);
+    return 0;
+}

@@ -1,0 +1,244 @@
+// stream_driver.hpp — ROS-free streaming driver: the per-frame call order of the reference's node
+//   keyframe_bundle_adjustment_ros_tool/src/mono_lidar/mono_lidar.cpp:88-373 (MonoLidar::callbackSubscriber)
+// with the depth assignment of the (separate) tracklets_depth node in front of it, on the MI355X library:
+//   LiDAR sweep + tracked features of the frame
+//     -> limo_depth_estimate            FeaturePoint::d of every track's newest point (include/limo_hip.h)
+//     -> motion prior                   external, or constant velocity from the last two poses (the node: tf or the
+//                                       five-point algorithm scaled by the last keyframes' speed, :119-186 - not restated)
+//     -> Keyframe(prior) + adjustPoseOnly            (:192-211)
+//     -> KeyframeSelector::select                    (:218-222)
+//     -> push                                        (:231-233)
+//     -> deactivateKeyframes + updateLabels + solve  (:245-263, every time_between_keyframes)
+//     -> pose of the frame in KITTI form             (:281-294: camera_0 <- camera_t, 12 numbers per row)
+// The very first frame is a Pose-fixed keyframe at the identity (:305-326).
+// Everything numerical happens behind the C-ABI; this file is host-side control flow only.
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/limo_hip.h"
+#include "bundle_adjuster_keyframes.hpp"
+#include "keyframe_selector.hpp"
+#include "landmark_selection_voxel.hpp"
+
+namespace keyframe_bundle_adjustment {
+
+struct StreamParams {
+    // optimisation window (MonoLidar.rosif / keyframe_ba_monolid.launch)
+    int max_size_optimization_window = 5;
+    int min_number_connecting_landmarks = 3;
+    double time_between_keyframes_sec = 0.09;   // solve at most this often (:245), also the time sparsification scheme
+    double critical_rotation_difference = 0.1;  // KeyframeSelectionSchemePose
+    double min_median_flow = 3.;                // KeyframeRejectionSchemeFlow
+    double shrubbery_weight = 0.9;
+    double height_over_ground = 0.31;           // Plane::distance of new keyframes (:191)
+    double solver_time_sec = 20.;               // wall-clock cap of a solve; <= 0: none (deterministic)
+    double prior_speed = 11.;                   // m/s along the vehicle's x axis while no motion has been estimated yet (the
+                                                // node scales its five-point direction by interface_.prior_speed, :160-165)
+    // landmark selection (keyframe_ba_monolid.launch:36-38, mono_lidar.cpp:396-430)
+    unsigned max_number_landmarks_near_bin = 200, max_number_landmarks_middle_bin = 200, max_number_landmarks_far_bin = 100;
+    double roi_middle = 15., roi_far = 40.;
+    // depth assignment
+    bool assign_depth = true;
+    int image_width = 1241, image_height = 376;
+    std::vector<int> ground_labels{6, 7, 8, 9, 10};  // cityscapes labels treated as ground (labels_["ground"])
+};
+
+class StreamDriver {
+public:
+    struct Stats {
+        int frames = 0, keyframes = 0, solves = 0, features = 0, features_with_depth = 0;
+        double sec_depth = 0., sec_pose_only = 0., sec_push = 0., sec_solve = 0., sec_total = 0.;
+    };
+
+    StreamDriver(const StreamParams& p, Camera::Ptr camera, const EigenPose& T_camera_lidar) : p_(p), camera_(camera), T_cam_lidar_(T_camera_lidar) {
+        ba_.set_solver_time(p.solver_time_sec);
+        selector_.addScheme(KeyframeRejectionSchemeFlow::createConst(p.min_median_flow));
+        selector_.addScheme(KeyframeSelectionSchemePose::createConst(p.critical_rotation_difference));
+        selector_.addScheme(KeyframeSparsificationSchemeTime::createConst(p.time_between_keyframes_sec * 1e9));
+        LandmarkSparsificationSchemeVoxel::Parameters vp;
+        vp.max_num_landmarks_near = p.max_number_landmarks_near_bin;
+        vp.max_num_landmarks_middle = p.max_number_landmarks_middle_bin;
+        vp.max_num_landmarks_far = p.max_number_landmarks_far_bin;
+        vp.roi_far_xyz = {{p.roi_far, p.roi_far, p.roi_far}};
+        vp.roi_middle_xyz = {{p.roi_middle, p.roi_middle, p.roi_middle}};
+        ba_.landmark_selector_->addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
+        LandmarkSelectionSchemeAddDepth::Parameters ap;  // always keep the 20 nearest depth / ground landmarks of the oldest keyframe
+        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
+                                                         [](const Measurement& m, const Vector3d&) { return m.d; }));
+        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
+                                                         [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
+        ba_.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
+        if (limo_ctx_create(0, &ctx_) != LIMO_OK) throw std::runtime_error("StreamDriver: no HIP device (limo_ctx_create)");
+        limo_depth_default_params(&depth_params_);
+    }
+    ~StreamDriver() {
+        if (ctx_) limo_ctx_destroy(ctx_);
+    }
+    StreamDriver(const StreamDriver&) = delete;
+    StreamDriver& operator=(const StreamDriver&) = delete;
+
+    // One frame.  `tracklets`: the tracker's message - stamps[0] = this frame, every track's feature_points[0] = its point
+    // in this frame (newest first).  Depths the caller already knows stay; the others (d < 0) are filled from the sweep:
+    // point 0 by limo_depth_estimate on `cloud_xyzi` (KITTI velodyne layout, n_pts x 4 floats; may be null), points 1..
+    // from what this driver assigned to the same track in earlier frames.  external_prior: keyframe <- origin pose of the
+    // frame if the caller has one (the node's tf prior), else constant velocity.
+    // Returns the frame's pose estimate (keyframe <- origin).
+    EigenPose process(Tracklets tracklets, const float* cloud_xyzi, size_t n_pts, const EigenPose* external_prior = nullptr) {
+        using clk = std::chrono::steady_clock;
+        const auto t_begin = clk::now();
+        if (tracklets.stamps.empty()) return last_pose_;  // (:98-104)
+        const TimestampNSec stamp = tracklets.stamps.front();
+        assignDepth(tracklets, cloud_xyzi, n_pts);
+        stats_.sec_depth += std::chrono::duration<double>(clk::now() - t_begin).count();
+        Plane ground_plane;
+        ground_plane.distance = p_.height_over_ground;
+        EigenPose pose = EigenPose::Identity();
+        bool is_keyframe = false;
+        if (ba_.keyframes_.empty()) {  // first frame: Pose-fixed keyframe at the origin (:305-326)
+            ba_.push(Keyframe(stamp, tracklets, camera_, EigenPose::Identity(), Keyframe::FixationStatus::Pose, ground_plane));
+            is_keyframe = true;
+        } else {
+            EigenPose prior = external_prior ? *external_prior : constantVelocityPrior(stamp);
+            {   // a product of estimated transforms: back onto SO(3) (convert() does not normalise, definitions.cpp:14-28)
+                Pose q = convert(prior);
+                const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                for (int i = 0; i < 4; ++i) q[i] /= n;
+                prior = convert(q);
+            }
+            auto cur = std::make_shared<Keyframe>(stamp, tracklets, camera_, prior, Keyframe::FixationStatus::None, ground_plane);
+            if (!external_prior && ba_.keyframes_.size() >= 3) {  // refine the prior against the fixed landmarks (:200-211)
+                const auto t0 = clk::now();
+                ba_.adjustPoseOnly(*cur);
+                stats_.sec_pose_only += std::chrono::duration<double>(clk::now() - t0).count();
+            }
+            pose = cur->getEigenPose();
+            const auto selected = selector_.select({cur}, ba_.getActiveKeyframePtrs());
+            const auto t1 = clk::now();
+            for (const auto& kf : selected) ba_.push(*kf);
+            stats_.sec_push += std::chrono::duration<double>(clk::now() - t1).count();
+            is_keyframe = !selected.empty();
+            const double now_sec = convert(stamp);
+            if (ba_.keyframes_.size() > 2 && is_keyframe && now_sec - last_solved_sec_ > 0.98 * p_.time_between_keyframes_sec) {
+                ba_.deactivateKeyframes(p_.min_number_connecting_landmarks, 3, p_.max_size_optimization_window);
+                ba_.updateLabels(tracklets, p_.shrubbery_weight);
+                const auto t2 = clk::now();
+                last_summary_ = ba_.solve();
+                stats_.sec_solve += std::chrono::duration<double>(clk::now() - t2).count();
+                ++stats_.solves;
+                last_solved_sec_ = now_sec;
+            }
+            // the optimised pose if the frame became a keyframe, its prior otherwise (:281-294)
+            if (ba_.getKeyframe().timestamp_ == stamp) pose = ba_.getKeyframe().getEigenPose();
+        }
+        if (have_last_) last_motion_ = pose * last_pose_.inverse();
+        have_motion_ = have_last_;
+        last_pose_ = pose;
+        last_stamp_ = stamp;
+        have_last_ = true;
+        ++stats_.frames;
+        stats_.keyframes += is_keyframe;
+        poses_.push_back(pose);
+        stats_.sec_total += std::chrono::duration<double>(clk::now() - t_begin).count();
+        return pose;
+    }
+
+    // KITTI odometry row of a frame (helpers::poseToString, mono_lidar.cpp:281-294): camera_0 <- camera_t =
+    // T_cam_veh * (keyframe <- origin)^-1 * T_cam_veh^-1, first three rows, row-major, 12 numbers.
+    void writeKittiPose(std::ostream& os, const EigenPose& pose_kf_origin) const {
+        const EigenPose cv = camera_->getEigenPose();
+        const EigenPose m = cv * pose_kf_origin.inverse() * cv.inverse();
+        char buf[512];
+        std::snprintf(buf, sizeof(buf), "%.12g %.12g %.12g %.12g %.12g %.12g %.12g %.12g %.12g %.12g %.12g %.12g", m.R[0], m.R[1], m.R[2], m.t[0],
+                      m.R[3], m.R[4], m.R[5], m.t[1], m.R[6], m.R[7], m.R[8], m.t[2]);
+        os << buf << "\n";
+    }
+    void writeKittiTrajectory(std::ostream& os) const {
+        for (const auto& p : poses_) writeKittiPose(os, p);
+    }
+
+    BundleAdjusterKeyframes& adjuster() { return ba_; }
+    const std::vector<EigenPose>& poses() const { return poses_; }
+    const Stats& stats() const { return stats_; }
+    const std::string& lastSummary() const { return last_summary_; }
+    limo_depth_params& depthParams() { return depth_params_; }
+
+private:
+    // constant velocity from the last two poses; before there are two: straight ahead at prior_speed
+    EigenPose constantVelocityPrior(TimestampNSec stamp) const {
+        if (have_motion_) return last_motion_ * last_pose_;
+        EigenPose m = EigenPose::Identity();
+        m.t[0] = -p_.prior_speed * (convert(stamp) - convert(last_stamp_));  // new vehicle <- old vehicle
+        return m * last_pose_;
+    }
+
+    // FeaturePoint::d of the tracks: newest point from the sweep (limo_depth_estimate), history from earlier frames.
+    void assignDepth(Tracklets& ts, const float* cloud, size_t n_pts) {
+        const size_t n = ts.tracks.size();
+        stats_.features += (int)n;
+        if (p_.assign_depth && cloud && n_pts && n) {
+            uv_.resize(2 * n);
+            ground_.resize(n);
+            depth_.assign(n, -1.f);
+            for (size_t i = 0; i < n; ++i) {
+                uv_[2 * i] = ts.tracks[i].feature_points[0].u;
+                uv_[2 * i + 1] = ts.tracks[i].feature_points[0].v;
+                ground_[i] = 0;
+                for (int l : p_.ground_labels) ground_[i] |= ts.tracks[i].label == l;
+            }
+            const Pose T = convert(T_cam_lidar_);
+            const int rc = limo_depth_estimate(ctx_, cloud, n_pts, T.data(), camera_->focal_length, camera_->principal_point[0],
+                                               camera_->principal_point[1], p_.image_width, p_.image_height, uv_.data(), n, ground_.data(),
+                                               &depth_params_, depth_.data());
+            if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate: ") + limo_last_error(ctx_));
+            for (size_t i = 0; i < n; ++i)
+                if (ts.tracks[i].feature_points[0].d < 0.f) ts.tracks[i].feature_points[0].d = depth_[i];
+        }
+        // remember this frame's depth per track, fill the history points from the memory (ring of the last frames)
+        const TimestampNSec stamp = ts.stamps.front();
+        for (auto& tr : ts.tracks) {
+            auto& h = history_[tr.id];
+            h.emplace_back(stamp, tr.feature_points[0].d);
+            if (h.size() > 16) h.erase(h.begin());
+            for (size_t k = 1; k < tr.feature_points.size() && k < ts.stamps.size(); ++k) {
+                if (tr.feature_points[k].d >= 0.f) continue;
+                for (const auto& e : h)
+                    if (e.first == ts.stamps[k]) tr.feature_points[k].d = e.second;
+            }
+            stats_.features_with_depth += tr.feature_points[0].d > 0.f;
+        }
+        if (++frames_since_gc_ >= 64) {  // forget tracks that ended
+            frames_since_gc_ = 0;
+            const TimestampNSec oldest = ts.stamps.back();
+            for (auto it = history_.begin(); it != history_.end();)
+                it = (it->second.empty() || it->second.back().first < oldest) ? history_.erase(it) : std::next(it);
+        }
+    }
+
+    StreamParams p_;
+    Camera::Ptr camera_;
+    EigenPose T_cam_lidar_;
+    BundleAdjusterKeyframes ba_;
+    KeyframeSelector selector_;
+    limo_ctx* ctx_ = nullptr;
+    limo_depth_params depth_params_;
+    std::unordered_map<unsigned long, std::vector<std::pair<TimestampNSec, float>>> history_;
+    int frames_since_gc_ = 0;
+    std::vector<float> uv_, depth_;
+    std::vector<uint8_t> ground_;
+    std::vector<EigenPose> poses_;
+    EigenPose last_pose_ = EigenPose::Identity(), last_motion_ = EigenPose::Identity();
+    bool have_last_ = false, have_motion_ = false;
+    TimestampNSec last_stamp_ = 0;
+    double last_solved_sec_ = -1e30;
+    std::string last_summary_;
+    Stats stats_;
+};
+
+}  // namespace keyframe_bundle_adjustment

@@ -20,10 +20,20 @@ def kitti_T_cam_lidar():
     return Rt_to_pose(R, t)
 
 
+def hdl64_elevations_deg():
+    """Beam elevations of the Velodyne HDL-64E S2 that recorded KITTI: an upper block of 32 lasers from +2 deg down to
+    -8.33 deg (1/3 deg apart) and a lower block of 32 from -8.83 deg to -24.33 deg (1/2 deg apart).  With KITTI's
+    f = 719 px that is 4.2 px between scan lines over most of the image (upper block) and 6.3 px near its bottom: the
+    9-pixel-high search window of the depth estimator (mono_lidar_fusion_parameters.yaml:17) then sees two scan lines
+    almost everywhere in the upper block - with 64 evenly spread beams (5.4 px) half of the windows see only one line
+    and no plane can be fitted."""
+    return np.concatenate([2.0 - np.arange(32) / 3.0, -8.83 - np.arange(32) * 0.5])
+
+
 def make_sweep(seed, n_az=2000, n_boxes=25, range_sigma=0.02, max_range=80.0):
     """Returns cloud [n,4] float32 (lidar frame).  Rays that hit nothing within max_range produce no return."""
     rng = np.random.default_rng(int(seed))
-    elev = np.deg2rad(np.linspace(2.0, -24.8, 64))
+    elev = np.deg2rad(hdl64_elevations_deg())
     az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + rng.uniform(0, 2 * np.pi / n_az)
     E, A = np.meshgrid(elev, az, indexing="ij")
     d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)

@@ -15,6 +15,8 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -273,6 +275,9 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
         }
     }
     const double hw = 0.5 * p->pixelarea_search_width, hh = 0.5 * p->pixelarea_search_height;
+    // per-gate rejection counts (ORACLE_DEPTH_STATS=1 prints them: which gate starves a workload of depths)
+    enum { G_NEIGHBOURS, G_HISTOGRAM, G_SEGMENT3, G_PLANAR, G_PARALLEL, G_GLOBAL, G_LOCAL, G_OK, G_N };
+    long gate[G_N] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t k = 0; k < n_feat; ++k) {
         depth_out[k] = -1.0f;
         const double fu = feat_uv[2 * k], fv = feat_uv[2 * k + 1];
@@ -282,7 +287,10 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
         for (const Vis& q : vis)
             if (std::fabs(q.u - (fu + p->pixelarea_search_offset_x)) <= hw && std::fabs(q.v - (fv + p->pixelarea_search_offset_y)) <= hh)
                 nb.push_back(&q);
-        if ((int)nb.size() < p->neighbors_count_min) continue;  // yaml:48
+        if ((int)nb.size() < p->neighbors_count_min) {  // yaml:48
+            gate[G_NEIGHBOURS]++;
+            continue;
+        }
         double depth = -1.0;
         double zlo, zhi;
         if (feat_is_ground && feat_is_ground[k] && ground.ok) {
@@ -310,7 +318,10 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
                 zlo = 0.0;
                 zhi = std::numeric_limits<double>::max();
             }
-            if (!ray_plane_depth(P, fu, fv, f, cx, cy, p->viewray_plane_orthoganality_treshold, &depth)) continue;
+            if (!ray_plane_depth(P, fu, fv, f, cx, cy, p->viewray_plane_orthoganality_treshold, &depth)) {
+                gate[G_PARALLEL]++;
+                continue;
+            }
         } else {
             // ---- D3: histogram segmentation by camera depth, bin width yaml:61, from the nearest neighbour's depth;
             //      the NEAREST bin that is a local maximum with >= min_pointcount points is kept (LIMO paper: "nearest
@@ -331,13 +342,19 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
                     const int prev = b > 0 ? cnt[b - 1] : 0, next = b + 1 < nbins ? cnt[b + 1] : 0;
                     if (cnt[b] >= p->histogram_segmentation_min_pointcount && cnt[b] > prev && cnt[b] >= next) pick = b;
                 }
-                if (pick < 0) continue;
+                if (pick < 0) {
+                    gate[G_HISTOGRAM]++;
+                    continue;
+                }
                 for (const Vis* q : nb)
                     if (std::min(nbins - 1, (int)std::floor((q->z - zmin) / bw)) == pick) seg.push_back(q);
             } else {
                 seg = nb;
             }
-            if (seg.size() < 3) continue;
+            if (seg.size() < 3) {
+                gate[G_SEGMENT3]++;
+                continue;
+            }
             zlo = std::numeric_limits<double>::max();
             zhi = -zlo;
             for (const Vis* q : seg) {
@@ -377,7 +394,10 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
             };
             if (p->do_check_triangleplanar_condition) {
                 const double s = std::min(sin_at(A, B, Cc), std::min(sin_at(B, A, Cc), sin_at(Cc, A, B)));
-                if (s < p->triangleplanar_crossnorm_treshold) continue;
+                if (s < p->triangleplanar_crossnorm_treshold) {
+                    gate[G_PLANAR]++;
+                    continue;
+                }
             }
             Plane4 P;
             const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {Cc[0] - A[0], Cc[1] - A[1], Cc[2] - A[2]};
@@ -389,19 +409,32 @@ int oracle_depth_estimate(const float* cloud, size_t n_pts, const double* T_cam_
             for (int q = 0; q < 3; ++q) P.n[q] /= nn;
             P.d = -(P.n[0] * A[0] + P.n[1] * A[1] + P.n[2] * A[2]);
             P.ok = true;
-            if (!ray_plane_depth(P, fu, fv, f, cx, cy, p->viewray_plane_orthoganality_treshold, &depth)) continue;
+            if (!ray_plane_depth(P, fu, fv, f, cx, cy, p->viewray_plane_orthoganality_treshold, &depth)) {
+                gate[G_PARALLEL]++;
+                continue;
+            }
         }
         // ---- D5: global gate (yaml:97-103, mode 0: reject) and local gate relative to the depth range of the points the
         //      patch was built from (yaml:108-114)
-        if (p->treshold_depth_enabled && !(depth > p->treshold_depth_min && depth < p->treshold_depth_max)) continue;
+        if (p->treshold_depth_enabled && !(depth > p->treshold_depth_min && depth < p->treshold_depth_max)) {
+            gate[G_GLOBAL]++;
+            continue;
+        }
         if (p->treshold_depth_local_enabled) {
             const double v = p->treshold_depth_local_value;
             const double lo = p->treshold_depth_local_valuetype ? zlo * (1.0 - v) : zlo - v;
             const double hi = p->treshold_depth_local_valuetype ? zhi * (1.0 + v) : zhi + v;
-            if (!(depth >= lo && depth <= hi)) continue;
+            if (!(depth >= lo && depth <= hi)) {
+                gate[G_LOCAL]++;
+                continue;
+            }
         }
+        gate[G_OK]++;
         depth_out[k] = (float)depth;
     }
+    if (std::getenv("ORACLE_DEPTH_STATS"))
+        std::fprintf(stderr, "[depth oracle] %zu features, %zu visible points: < 3 neighbours %ld, no histogram bin %ld, segment < 3 %ld, triangle not planar enough %ld, ray || plane %ld, global gate %ld, local gate %ld, accepted %ld\n",
+                     n_feat, vis.size(), gate[G_NEIGHBOURS], gate[G_HISTOGRAM], gate[G_SEGMENT3], gate[G_PLANAR], gate[G_PARALLEL], gate[G_GLOBAL], gate[G_LOCAL], gate[G_OK]);
     return LIMO_OK;
 }
 

@@ -599,5 +599,19 @@ int limo_ba_adjust_pose_only(limo_ctx*, limo_ba_window* w, const limo_speed_prio
                              limo_ba_report* r) {
     return emu_ba_solve_batch(1, w, o, r, 1, p);
 }
+#ifdef KBA_EMU_DEPTH
+// depth assignment of the emulated backend = the CPU oracle's (oracle/depth_oracle.cpp, liboracle.so): test
+// infrastructure standing in for test infrastructure, so that limo_stream can run its drive without a GPU
+void oracle_depth_default_params(limo_depth_params* out);
+int oracle_depth_estimate(const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar, double f, double cx, double cy, int32_t img_w,
+                          int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground, const limo_depth_params* params,
+                          float* depth_out);
+void limo_depth_default_params(limo_depth_params* out) { oracle_depth_default_params(out); }
+int limo_depth_estimate(limo_ctx*, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar, double f, double cx, double cy,
+                        int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
+                        const limo_depth_params* params, float* depth_out) {
+    return oracle_depth_estimate(cloud_xyzi, n_pts, T_cam_lidar, f, cx, cy, img_w, img_h, feat_uv, n_feat, feat_is_ground, params, depth_out);
+}
+#endif
 }
 #endif

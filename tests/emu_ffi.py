@@ -42,6 +42,26 @@ def build_stream_test(gpu=False):
     return out
 
 
+STREAM_APP_SRC = os.path.join(_HERE, "..", "apps", "limo_stream", "limo_stream.cpp")
+
+
+def build_stream_app(gpu=False):
+    """apps/limo_stream (synthetic drive through limo_amd/kba/stream_driver.hpp) against liblimo_hip.so, or against the
+    emulated C-ABI + the oracle's depth assignment (CPU tier)."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
+    out = os.path.join(_HERE, "cpp", "_build", "limo_stream_gpu" if gpu else "limo_stream_emu")
+    if not gpu:
+        oracle_dir = os.path.join(_HERE, "..", "oracle", "_build")
+        abi = os.path.join(_HERE, "cpp", "_build", "libkba_emu_abi_depth.so")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-DKBA_EMU_DEPTH", "-o", abi] + _SRC + [os.path.join(csrc, "host_misc.cpp"), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + [abi, "-Wl,-rpath," + os.path.dirname(abi), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
+        return out
+    libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    return out
+
+
 def build_shim_tests(gpu=False):
     """tests/cpp/test_kba_shim.cpp + the kba shim, linked against the emulated C-ABI (CPU tier) or liblimo_hip.so."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)

@@ -3,6 +3,7 @@ C++ shim (limo_amd/kba): CPU tier links the emulated C-ABI, GPU tier links libli
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import emu_ffi
@@ -63,3 +64,49 @@ def test_long_streaming_sequence_on_gpu_is_reproducible():
     ate = float(summary.split("ATE rmse ")[1].split(" m")[0])
     assert ate < 0.25, summary
     assert "non-finite" not in outs[0]  # no landmark position is ever NaN / inf
+
+
+# ---- apps/limo_stream: the product's streaming driver (limo_amd/kba/stream_driver.hpp) on the synthetic drive, LiDAR depth
+#      assignment in the loop (BASELINE.json configs[4] end to end)
+def run_limo_stream(exe, frames, az, poses_path=None, extra=()):
+    cmd = [exe, "--frames", str(frames), "--az", str(az), "--quiet"] + list(extra)
+    if poses_path:
+        cmd += ["--poses", poses_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+    print(r.stdout[-1500:])
+    print(r.stderr[-800:])
+    assert r.returncode == 0
+    return {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("frames", "fps", "ate_rmse", "ate_max", "depth_fraction", "keyframes", "solves")}
+
+
+def test_limo_stream_with_emulated_backend(tmp_path):
+    """Sweep -> depth assignment -> FeaturePoint::d -> adjustPoseOnly -> keyframe selection -> push -> deactivateKeyframes
+    -> solve -> KITTI pose rows, on the emulated C-ABI (BA) + the oracle's depth assignment."""
+    exe = emu_ffi.build_stream_app(gpu=False)
+    poses = str(tmp_path / "poses.txt")
+    out = run_limo_stream(exe, 40, 2000, poses)
+    assert out["frames"] == 40 and out["keyframes"] >= 15 and out["solves"] >= 12
+    assert out["depth_fraction"] > 0.2          # the features' depths come from the sweep, nowhere else
+    assert out["ate_rmse"] < 0.05 and out["ate_max"] < 0.12
+    rows = [l.split() for l in open(poses).read().splitlines() if l.strip()]
+    assert len(rows) == 40 and all(len(r) == 12 for r in rows)  # KITTI odometry format, mono_lidar.cpp:281-294
+    first = np.array(rows[0], float).reshape(3, 4)
+    assert np.allclose(first, np.eye(4)[:3], atol=1e-12)        # the first frame is the origin
+    no_depth = run_limo_stream(exe, 40, 2000, extra=["--no-depth"])
+    assert no_depth["depth_fraction"] == 0.0 and no_depth["ate_rmse"] > out["ate_rmse"]  # monocular: scale drifts without LiDAR
+
+
+@pytest.mark.gpu
+def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
+    """The same drive through liblimo_hip.so (depth.hip + the BA kernels) and through the emulated / oracle backend:
+    trajectory parity frame by frame, plus accuracy against the ground truth."""
+    gpu, emu = emu_ffi.build_stream_app(gpu=True), emu_ffi.build_stream_app(gpu=False)
+    pg, pe = str(tmp_path / "gpu.txt"), str(tmp_path / "emu.txt")
+    og = run_limo_stream(gpu, 80, 2000, pg)
+    oe = run_limo_stream(emu, 80, 2000, pe)
+    assert og["ate_rmse"] < 0.05 and og["depth_fraction"] > 0.2
+    assert abs(og["depth_fraction"] - oe["depth_fraction"]) < 0.01
+    a = np.array([l.split() for l in open(pg).read().splitlines() if l.strip()], float)
+    b = np.array([l.split() for l in open(pe).read().splitlines() if l.strip()], float)
+    assert a.shape == b.shape == (80, 12)
+    assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() < 5e-3  # camera positions of the two drives, metres
