@@ -324,6 +324,28 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
                         size_t n_feat, const uint8_t* feat_is_ground, const limo_depth_params* params,
                         float* depth_out);
 
+/*
+ * The same for a batch of sweeps of one sensor rig (an offline replay: the reference's demo application reads every
+ * frame of a KITTI sequence from disk, demo_keyframe_bundle_adjustment_meta/apps/main_program/main_program.cpp:97-170):
+ * the frame is a grid dimension of the five kernels, so a call costs five launches whatever n_frames is.  Results are
+ * those of n_frames separate limo_depth_estimate calls, bit for bit.
+ *   flags & LIMO_DEPTH_DEVICE_POINTERS: cloud_xyzi / feat_uv / feat_is_ground / depth_out of every frame are device
+ *   pointers on the context's GPU (sweeps already resident in HBM; nothing is copied).  A non-NULL feat_is_ground then
+ *   means "estimate the ground plane of this frame" (the labels cannot be inspected from the host).
+ */
+typedef struct limo_depth_frame {
+    const float* cloud_xyzi;       /* [n_pts*4]  */
+    size_t n_pts;
+    const float* feat_uv;          /* [n_feat*2] */
+    size_t n_feat;
+    const uint8_t* feat_is_ground; /* [n_feat] or NULL */
+    float* depth_out;              /* [n_feat]   */
+} limo_depth_frame;
+#define LIMO_DEPTH_DEVICE_POINTERS 1u
+int limo_depth_estimate_batch(limo_ctx* ctx, int32_t n_frames, const limo_depth_frame* frames, const double* T_cam_lidar,
+                              double f, double cx, double cy, int32_t img_w, int32_t img_h, const limo_depth_params* params,
+                              uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,20 @@ class Ray(C.Structure):  # struct limo_ray
     ]
 
 
+class DepthFrame(C.Structure):  # struct limo_depth_frame (pointers as integers: host arrays or device addresses)
+    _fields_ = [
+        ("cloud_xyzi", C.c_void_p),
+        ("n_pts", C.c_size_t),
+        ("feat_uv", C.c_void_p),
+        ("n_feat", C.c_size_t),
+        ("feat_is_ground", C.c_void_p),
+        ("depth_out", C.c_void_p),
+    ]
+
+
+DEPTH_DEVICE_POINTERS = 1
+
+
 class DepthParams(C.Structure):  # struct limo_depth_params
     _fields_ = [
         ("pixelarea_search_width", C.c_int32),
@@ -174,6 +188,7 @@ ABI_SYMBOLS = [
     "limo_trim_quantile",
     "limo_depth_default_params",
     "limo_depth_estimate",
+    "limo_depth_estimate_batch",
 ]
 
 _lib = None
@@ -252,5 +267,7 @@ def load():
         C.POINTER(DepthParams),
         c_float_p,
     ]
+    lib.limo_depth_estimate_batch.argtypes = [vp, C.c_int32, C.POINTER(DepthFrame), c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                              C.POINTER(DepthParams), C.c_uint32]
     _lib = lib
     return lib

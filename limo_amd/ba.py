@@ -203,3 +203,44 @@ def depth_estimate(ctx, frame, params=None, use_ground_labels=True):
     )
     _check(rc, ctx.ptr, "limo_depth_estimate")
     return out
+
+
+def depth_estimate_batch(ctx, frames, params=None, use_ground_labels=True, device=False):
+    """limo_depth_estimate_batch over a list of frame dicts of one rig (calibration of frames[0]).
+    device=False: numpy clouds / features in, list of float32 depth arrays out.
+    device=True: every frame dict carries torch CUDA tensors "cloud" (n,4 float32), "uv" (m,2 float32), optionally
+    "is_ground" (m uint8); returns a list of torch CUDA float32 tensors (nothing crosses PCIe)."""
+    lib = ctx.lib
+    p = params if params is not None else depth_default_params()
+    n = len(frames)
+    arr = (_ffi.DepthFrame * max(1, n))()
+    keep, outs = [], []
+    for k, fr in enumerate(frames):
+        if device:
+            import torch
+
+            cloud, uv = fr["cloud"].contiguous(), fr["uv"].contiguous()
+            assert cloud.is_cuda and cloud.dtype == torch.float32 and uv.is_cuda and uv.dtype == torch.float32
+            g = fr["is_ground"].contiguous() if use_ground_labels and fr.get("is_ground") is not None else None
+            out = torch.empty(uv.shape[0], dtype=torch.float32, device=uv.device)
+            arr[k] = _ffi.DepthFrame(cloud.data_ptr(), cloud.shape[0], uv.data_ptr(), uv.shape[0], g.data_ptr() if g is not None else None, out.data_ptr())
+        else:
+            cloud = np.ascontiguousarray(fr["cloud"], np.float32)
+            uv = np.ascontiguousarray(fr["uv"], np.float32)
+            g = np.ascontiguousarray(fr["is_ground"], np.uint8) if use_ground_labels else None
+            out = np.zeros(uv.shape[0], np.float32)
+            arr[k] = _ffi.DepthFrame(cloud.ctypes.data, cloud.shape[0], uv.ctypes.data, uv.shape[0], g.ctypes.data if g is not None else None, out.ctypes.data)
+        keep.append((cloud, uv, g))
+        outs.append(out)
+    if n == 0:
+        return []
+    f0 = frames[0]
+    T = np.ascontiguousarray(f0["T_cam_lidar"], np.float64)
+    if device:
+        import torch
+
+        torch.cuda.current_stream().synchronize()  # the tensors above may still be in flight on torch's stream
+    rc = lib.limo_depth_estimate_batch(ctx.ptr, n, arr, T.ctypes.data_as(_ffi.c_double_p), f0["f"], f0["cx"], f0["cy"], f0["w"], f0["h"], C.byref(p),
+                                       _ffi.DEPTH_DEVICE_POINTERS if device else 0)
+    _check(rc, ctx.ptr, "limo_depth_estimate_batch")
+    return outs

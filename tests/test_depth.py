@@ -115,3 +115,46 @@ def test_gpu_depth_on_analytic_walls(ctx, oracle):
     empty = dict(fr)
     empty["cloud"] = fr["cloud"][:0]
     assert (ba.depth_estimate(ctx, empty, use_ground_labels=False) == -1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_depth_batch_equals_single_calls(ctx, oracle):
+    """limo_depth_estimate_batch: frames of different sizes (one of them empty, one without ground labels' plane) in one
+    call give the bits of separate calls, from host buffers and from device-resident buffers; a second, smaller call
+    afterwards still starts from clean counters (the zone a call clears for its successor)."""
+    import torch
+
+    from limo_amd import ba
+
+    frames = [synth_lidar.make_frame(s) for s in (11, 12, 13)]
+    frames[1]["cloud"] = synth_lidar.make_sweep(12, n_az=900)                      # fewer returns than the others
+    frames[1]["uv"], frames[1]["is_ground"], frames[1]["z_true"] = synth_lidar.make_features(frames[1]["cloud"], 12)
+    frames[2]["uv"] = frames[2]["uv"][:700]
+    frames[2]["is_ground"] = frames[2]["is_ground"][:700]
+    empty = dict(frames[0])
+    empty["cloud"] = frames[0]["cloud"][:0]
+    frames.append(empty)
+    singles = [ba.depth_estimate(ctx, fr) for fr in frames]
+    for k, fr in enumerate(frames[:3]):
+        compare(singles[k], oracle.depth_estimate(fr))
+    assert (singles[3] == -1).all()
+    batch = ba.depth_estimate_batch(ctx, frames)
+    for a, b in zip(singles, batch):
+        assert np.array_equal(a, b)
+    dev_frames = []
+    for fr in frames:
+        d = dict(fr)
+        d["cloud"] = torch.from_numpy(np.ascontiguousarray(fr["cloud"], np.float32)).cuda()
+        d["uv"] = torch.from_numpy(np.ascontiguousarray(fr["uv"], np.float32)).cuda()
+        d["is_ground"] = torch.from_numpy(np.ascontiguousarray(fr["is_ground"], np.uint8)).cuda()
+        dev_frames.append(d)
+    dev = ba.depth_estimate_batch(ctx, dev_frames, device=True)
+    for a, b in zip(singles, dev):
+        assert np.array_equal(a, b.cpu().numpy())
+    # more frames than one launch group holds (32), then a single frame again
+    many = [frames[k % 3] for k in range(35)]
+    out = ba.depth_estimate_batch(ctx, many)
+    for k, o in enumerate(out):
+        assert np.array_equal(o, singles[k % 3])
+    assert np.array_equal(ba.depth_estimate(ctx, frames[1]), singles[1])
+    assert np.array_equal(ba.depth_estimate(ctx, frames[0], use_ground_labels=False), ba.depth_estimate_batch(ctx, frames[:1], use_ground_labels=False)[0])
