@@ -165,6 +165,11 @@ void limo_ctx_destroy(limo_ctx* ctx);
 /* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own. */
 int limo_ctx_set_stream(limo_ctx* ctx, void* hip_stream);
 const char* limo_last_error(const limo_ctx* ctx);
+/* Page-locked host memory for buffers that cross PCIe every call (a frame's sweep, a window's observations): every
+ * entry point takes pageable or page-locked host pointers alike, page-locked ones are read by the GPU's copy engine
+ * directly instead of through the runtime's staging copy.  NULL when the allocation fails. */
+void* limo_host_alloc(size_t bytes);
+void limo_host_free(void* p);
 
 void limo_ba_default_options(limo_ba_options* out);
 

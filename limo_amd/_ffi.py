@@ -168,6 +168,8 @@ ABI_SYMBOLS = [
     "limo_ctx_destroy",
     "limo_ctx_set_stream",
     "limo_last_error",
+    "limo_host_alloc",
+    "limo_host_free",
     "limo_ba_default_options",
     "limo_ba_solve",
     "limo_ba_batch_create",
@@ -267,6 +269,10 @@ def load():
         C.POINTER(DepthParams),
         c_float_p,
     ]
+    lib.limo_host_alloc.argtypes = [C.c_size_t]
+    lib.limo_host_alloc.restype = C.c_void_p
+    lib.limo_host_free.argtypes = [C.c_void_p]
+    lib.limo_host_free.restype = None
     lib.limo_depth_estimate_batch.argtypes = [vp, C.c_int32, C.POINTER(DepthFrame), c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                               C.POINTER(DepthParams), C.c_uint32]
     _lib = lib

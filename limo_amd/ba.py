@@ -244,3 +244,21 @@ def depth_estimate_batch(ctx, frames, params=None, use_ground_labels=True, devic
                                        _ffi.DEPTH_DEVICE_POINTERS if device else 0)
     _check(rc, ctx.ptr, "limo_depth_estimate_batch")
     return outs
+
+
+def host_array(shape, dtype):
+    """numpy array on page-locked host memory (limo_host_alloc); freed when the array is collected."""
+    lib = _ffi.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = lib.limo_host_alloc(max(1, n))
+    if not ptr:
+        raise MemoryError("limo_host_alloc(%d)" % n)
+
+    class _Owner:
+        def __del__(self, free=lib.limo_host_free, p=ptr):
+            free(p)
+
+    buf = (C.c_char * max(1, n)).from_address(ptr)
+    buf._owner = _Owner()
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)

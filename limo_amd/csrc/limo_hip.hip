@@ -932,6 +932,14 @@ int limo_ctx_create(int device, limo_ctx** out) {
     return LIMO_OK;
 }
 
+void* limo_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : nullptr;
+}
+void limo_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void limo_ctx_destroy(limo_ctx* ctx) {
     if (!ctx) return;
     if (ctx->depth_ws && ctx->depth_ws_free) ctx->depth_ws_free(ctx->depth_ws);

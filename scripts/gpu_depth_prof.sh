@@ -24,6 +24,10 @@ d = ba.depth_estimate(ctx, fr)
 res = {"points": int(fr["cloud"].shape[0]), "features": int(fr["uv"].shape[0]), "with_depth": int((d > 0).sum()), "batch_frames": F}
 mode = os.environ.get("DEPTH_MODE", "all")
 if mode in ("all", "single"): res["ms_per_frame_single_host"] = rate(lambda: ba.depth_estimate(ctx, fr), 1, 5 * reps)
+if mode in ("all", "single"):
+    pinned = dict(fr); pinned["cloud"] = ba.host_array(fr["cloud"].shape, np.float32); pinned["cloud"][:] = fr["cloud"]
+    res["ms_per_frame_single_host_pinned_cloud"] = rate(lambda: ba.depth_estimate(ctx, pinned), 1, 5 * reps)
+    assert np.array_equal(ba.depth_estimate(ctx, pinned), d)
 if mode in ("all", "batch"): res["ms_per_frame_batch_host"] = rate(lambda: ba.depth_estimate_batch(ctx, frames), F, reps)
 dev = []
 for f in frames:
@@ -55,7 +59,7 @@ out = {"command": "scripts/gpu_depth_prof.sh (PMC=1): rocprofv3 --pmc FETCH_SIZE
 for db_path in sorted(glob.glob("gpurun_out/pmc_depth/*_results.db")):
     db = sqlite3.connect(db_path)
     for name, ctr, val, dur in db.execute("select name, counter_name, max(counter_value), max(duration) from pmc_events group by name, counter_name"):
-        n = re.sub(r"\(.*", "", name).replace("void ", "").replace("(anonymous namespace)::", "")
+        n = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
         k = out["kernels"].setdefault(n, {})
         k[ctr] = val
         k["launch_us_under_counters"] = max(k.get("launch_us_under_counters", 0.0), dur / 1e3)

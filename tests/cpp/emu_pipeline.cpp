@@ -566,6 +566,8 @@ int limo_ctx_create(int, limo_ctx** out) {
     return LIMO_OK;
 }
 void limo_ctx_destroy(limo_ctx* c) { delete c; }
+void* limo_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void limo_host_free(void* p) { std::free(p); }
 int limo_ctx_set_stream(limo_ctx*, void*) { return LIMO_OK; }
 const char* limo_last_error(const limo_ctx* c) { return c ? c->err.c_str() : ""; }
 void limo_ba_default_options(limo_ba_options* o) {
