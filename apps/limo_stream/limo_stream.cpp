@@ -5,7 +5,11 @@
 // main_program.cpp:39-216 reads KITTI data from disk and plays it through the ROS nodes; there is no dataset here, so the
 // drive is synthesised by synth_world.hpp) and of the node's callback (limo_amd/kba/stream_driver.hpp).
 //
-//   limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses out.txt] [--no-depth] [--quiet]
+//   limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses out.txt] [--gt-poses gt.txt]
+//               [--dump-velodyne DIR] [--velodyne DIR] [--no-depth] [--quiet]
+// --dump-velodyne writes every synthetic sweep as a KITTI velodyne scan (DIR/NNNNNN.bin); --velodyne replays scans from
+// such a directory instead of ray-casting them (the scans of a real KITTI sequence have the same format; the tracked
+// features of a real sequence come from the feature tracker, which is outside this path).
 // Prints one summary line per run and `key value` lines for scripts: fps of the pipeline (input synthesis excluded and
 // reported separately), ATE against the ground truth, share of features that received a LiDAR depth.
 #include <chrono>
@@ -16,6 +20,7 @@
 #include <map>
 #include <string>
 
+#include "../../limo_amd/kba/kitti_io.hpp"
 #include "../../limo_amd/kba/stream_driver.hpp"
 #include "synth_world.hpp"
 
@@ -24,7 +29,7 @@ using namespace keyframe_bundle_adjustment;
 int main(int argc, char** argv) {
     int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
     uint64_t seed = 7;
-    std::string poses_path;
+    std::string poses_path, gt_path, dump_dir, replay_dir;
     bool use_depth = true, quiet = false;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
@@ -34,10 +39,13 @@ int main(int argc, char** argv) {
         else if (arg("--seed")) seed = std::strtoull(argv[++i], nullptr, 10);
         else if (arg("--window")) window = std::atoi(argv[++i]);
         else if (arg("--poses")) poses_path = argv[++i];
+        else if (arg("--gt-poses")) gt_path = argv[++i];
+        else if (arg("--dump-velodyne")) dump_dir = argv[++i];
+        else if (arg("--velodyne")) replay_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else {
-            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses file] [--no-depth] [--quiet]\n");
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--quiet]\n");
             return 2;
         }
     }
@@ -64,7 +72,19 @@ int main(int argc, char** argv) {
     size_t n_points = 0;
     for (int t = 0; t < n_frames; ++t) {
         const auto t0 = clk::now();
-        world.sweep(t, cloud, cloud_ground);
+        world.sweep(t, cloud, cloud_ground);  // (also labels the returns that hit the ground: the features' class labels come from it)
+        if (!replay_dir.empty()) {
+            std::vector<float> scan;
+            if (!kitti_io::readVelodyneBin(kitti_io::velodynePath(replay_dir, t), scan) || scan.size() != cloud.size()) {
+                std::fprintf(stderr, "limo_stream: cannot replay %s\n", kitti_io::velodynePath(replay_dir, t).c_str());
+                return 1;
+            }
+            cloud.swap(scan);
+        }
+        if (!dump_dir.empty() && !kitti_io::writeVelodyneBin(kitti_io::velodynePath(dump_dir, t), cloud.data(), cloud.size() / 4)) {
+            std::fprintf(stderr, "limo_stream: cannot write %s\n", kitti_io::velodynePath(dump_dir, t).c_str());
+            return 1;
+        }
         n_points += cloud.size() / 4;
         // tracks that survive into this frame (still visible, not occluded), then new ones up to n_feat
         const Vector3d here = world.origin_veh[t].translation();
@@ -126,6 +146,20 @@ int main(int argc, char** argv) {
         std::ofstream f(poses_path);
         driver.writeKittiTrajectory(f);
     }
+    // devkit-style relative errors on the KITTI pose rows (camera frame)
+    std::vector<EigenPose> gt_rows, est_rows;
+    {
+        const EigenPose cv = cam->getEigenPose();
+        for (int t = 0; t < n_frames; ++t) {
+            gt_rows.push_back(cv * world.origin_veh[t] * cv.inverse());
+            est_rows.push_back(cv * driver.poses()[t].inverse() * cv.inverse());
+        }
+        if (!gt_path.empty()) {
+            std::ofstream f(gt_path);
+            for (const auto& p : gt_rows) kitti_io::writePoseRow(f, p);
+        }
+    }
+    const kitti_io::TrajectoryError te = kitti_io::evaluateTrajectory(gt_rows, est_rows);
     const auto& st = driver.stats();
     std::printf("limo_stream: %d frames (%d keyframes, %d solves, window %d), %.0f points and %.0f features per frame, %.1f %% of the features with a LiDAR depth\n",
                 n_frames, st.keyframes, st.solves, window, (double)n_points / n_frames, (double)st.features / n_frames,
@@ -134,6 +168,9 @@ int main(int argc, char** argv) {
                 1e3 * sec_pipeline / n_frames, n_frames / sec_pipeline, 1e3 * st.sec_depth / n_frames, 1e3 * st.sec_pose_only / n_frames,
                 1e3 * st.sec_push / n_frames, 1e3 * st.sec_solve / n_frames, st.solves ? 1e3 * st.sec_solve / st.solves : 0., 1e3 * sec_synth / n_frames);
     std::printf("limo_stream: ATE rmse %.4f m (max %.4f m) over %.1f m\n", ate, worst, 0.55 * (n_frames - 1));
+    if (te.rel_samples)
+        std::printf("limo_stream: relative errors over 100..800 m sub-paths (KITTI devkit measure, %d samples): translation %.3f %%, rotation %.5f deg/m\n",
+                    te.rel_samples, 100. * te.rel_trans, te.rel_rot * 180. / M_PI);
     std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\n", n_frames, n_frames / sec_pipeline, ate, worst,
                 (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves);
     return 0;

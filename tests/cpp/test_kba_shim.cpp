@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <random>
 #include <string>
@@ -14,6 +15,7 @@
 
 #include "../../limo_amd/kba/bundle_adjuster_keyframes.hpp"
 #include "../../limo_amd/kba/keyframe_selector.hpp"
+#include "../../limo_amd/kba/kitti_io.hpp"
 #include "../../limo_amd/kba/landmark_selection_voxel.hpp"
 
 using namespace keyframe_bundle_adjustment;
@@ -370,6 +372,57 @@ static void test_exceptions() {
     CHECK(thrown);
 }
 
+// The data formats either side of the path (limo_amd/kba/kitti_io.hpp): velodyne .bin round trip, pose rows round trip,
+// trajectory errors of a known perturbation.
+static void test_kitti_io() {
+    namespace io = kitti_io;
+    const std::string dir = "/tmp";
+    std::vector<float> cloud;
+    for (int i = 0; i < 1000; ++i)
+        for (int k = 0; k < 4; ++k) cloud.push_back(0.25f * (float)i - 3.f * (float)k);
+    const std::string scan = io::velodynePath(dir, 42);
+    CHECK(scan == "/tmp/000042.bin");
+    CHECK(io::writeVelodyneBin(scan, cloud.data(), cloud.size() / 4));
+    std::vector<float> back;
+    CHECK(io::readVelodyneBin(scan, back));
+    CHECK(back == cloud);
+    CHECK(!io::readVelodyneBin(dir + "/no_such_scan.bin", back));
+    {  // a file that is not made of 16-byte records is refused
+        std::FILE* f = std::fopen(scan.c_str(), "ab");
+        std::fputc(0, f);
+        std::fclose(f);
+        CHECK(!io::readVelodyneBin(scan, back));
+    }
+    std::remove(scan.c_str());
+    // a 1 km drive with a slow turn; the estimate drifts by 1 % in scale and 1 mrad per 10 m in yaw
+    std::vector<EigenPose> gt, est;
+    EigenPose g, e;
+    for (int k = 0; k < 1000; ++k) {
+        gt.push_back(g);
+        est.push_back(e);
+        g.translate(Vector3d(0., 0., 1.)).rotate(0.001, Vector3d(0., 1., 0.));
+        e.translate(Vector3d(0., 0., 1.01)).rotate(0.0011, Vector3d(0., 1., 0.));
+    }
+    const std::string pf = dir + "/kitti_io_poses.txt";
+    {
+        std::ofstream f(pf);
+        for (const auto& p : est) io::writePoseRow(f, p);
+    }
+    std::vector<EigenPose> est_back;
+    CHECK(io::readPoses(pf, est_back));
+    CHECK(est_back.size() == est.size());
+    for (size_t k = 0; k < est.size(); k += 111) CHECK(est_back[k].isApprox(est[k], 1e-9));
+    std::remove(pf.c_str());
+    const io::TrajectoryError same = io::evaluateTrajectory(gt, gt);
+    CHECK(same.ate_rmse == 0. && same.rel_trans == 0. && same.rel_samples > 0);
+    const io::TrajectoryError err = io::evaluateTrajectory(gt, est);
+    CHECK(std::abs(err.path_length - 999.) < 1.);
+    CHECK(err.rel_samples > 100);
+    CHECK(err.rel_trans > 0.009 && err.rel_trans < 0.06);              // 1 % scale + the yaw drift's lever arm
+    CHECK(std::abs(err.rel_rot - 0.0001) < 2e-5);                       // 0.1 mrad per metre
+    CHECK(err.ate_max > 9. && err.ate_rmse > 3. && err.ate_rmse < err.ate_max);
+}
+
 int main(int argc, char** argv) {
     struct T {
         const char* name;
@@ -377,6 +430,7 @@ int main(int argc, char** argv) {
     } tests[] = {{"LandmarkCreator.CreateWithDepth", test_create_with_depth},
                  {"BundleAdjusterKeyframes.deactivateKeyframes", test_deactivate_keyframes},
                  {"BundleAdjusterKeyframes.exceptions", test_exceptions},
+                 {"KittiIo.formats", test_kitti_io},
                  {"KeyframeSelector.process", test_keyframe_selector_process},
                  {"LandmarkSelector.base", test_landmark_selector_base},
                  {"LandmarkSelector.voxel", test_landmark_selector_voxel},

@@ -68,10 +68,22 @@ def test_oracle_ground_plane_and_ground_features(oracle):
     assert pl[1] < -0.99 and 1.5 < pl[3] < 1.8
     d = oracle.depth_estimate(fr)
     ok = d > 0
-    assert ok.any()
+    assert ok.mean() > 0.3  # this scene: 37 % (see test_acceptance_share_of_the_synthetic_scenes)
     assert np.median(np.abs(d[ok] - fr["z_true"][ok])) < 0.1  # metres, against the ray-cast ground truth
     d2 = oracle.depth_estimate(fr)
     assert np.array_equal(d, d2)  # seeded RANSAC: deterministic
+
+
+def test_acceptance_share_of_the_synthetic_scenes(oracle):
+    """How many features get a depth, and why the others do not (ORACLE_DEPTH_STATS=1 prints the per-gate counts).
+    The sweeps use the HDL-64E S2 beam layout (1/3 deg rings above -8.33 deg, 1/2 deg below; 2000 azimuth steps = 0.18 deg
+    = 2.3 px): the 6x9 px window of the parameter file sees 2-3 returns of 1-2 rings, so the gates that reject are
+    geometric - fewer than 3 returns in the window (21-39 % of the features), fewer than 3 returns left in the selected
+    0.3 m histogram bin on grazing surfaces (9-31 %), view ray within 5.7 deg of the fitted plane (6-16 %, ground beyond
+    ~16 m), triangle not planar enough (<3 %); the two depth-range gates reject nothing.  12-60 % per scene, 44 % over
+    these six; the streaming drive (features spawned on surfaces the sweep hits) reaches 61 % (profiles/r02_limo_stream_c5_gpu.log)."""
+    share = [float((oracle.depth_estimate(synth_lidar.make_frame(s)) > 0).mean()) for s in (1, 2, 4, 5, 11, 12)]
+    assert min(share) > 0.3 and np.mean(share) > 0.4, share
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
