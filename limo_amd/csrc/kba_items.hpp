@@ -225,11 +225,12 @@ KBA_HD void gp_lane(const BatchView& bv, int g, bool candidate, double* cost_out
 // ======================================================================================= landmarks
 // V = sum E^T E, g = sum E^T r over the landmark's observations (+ its ground-plane row).
 // part: [0] max|g| (gradient inf-norm part), [1] |x|^2
-KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, double* part) {
+// w = window of the landmark, handed in by the caller: uniform over the workgroup, so the window descriptor and the
+// per-view constants come through scalar loads instead of one vector load per lane
+KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int w, int gl, double* part) {
     part[0] = 0.0;
     part[1] = 0.0;
     if (bv.lm_state[gl] != 1) return;
-    const int w = bv.lm_win[gl];
     const WinDesc& wd = bv.win[w];
     double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int j = 0; j < wd.n_view; ++j) {
@@ -282,9 +283,8 @@ KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int gl, dou
 // the landmark block:  Bt = L^-1 S  (lower triangular, 6: [l00 s0 | l10 s0, l11 s1 | l20 s0, l21 s1, l22 s2]) - every
 // later use of L^-1 comes with the scale attached (Y' = .. S L^-T = .. Bt^T, delta = -S L^-T t = -Bt^T t) - and
 // t = L^-1 S g = Bt g.  Returns 1 on Cholesky failure.
-KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int gl) {
+KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int w, int gl) {
     if (bv.lm_state[gl] != 1) return 0;
-    const int w = bv.lm_win[gl];
     const double radius = bv.st[w].radius;
     double s[3], V[6], g[3];
     for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
@@ -454,7 +454,8 @@ KBA_HD int schur_col(int i, int nfq) {
 // poses' per-view constants are in view_lin_c (k_cam_solve), so the measurements (12 B per observation through the slot
 // table) are all that is read - the separate observation-major cost pass read 52 B per observation.
 // part: [2] model-cost-change part, [3] |x - x_cand|^2, [4] |x_cand|^2, [6] candidate cost, [7] 1 = a functor failed
-KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int gl, double* part) {
+// w = window of the landmark (uniform over the workgroup: scalar loads of the window's and the views' constants)
+KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int gl, double* part) {
     part[2] = part[3] = part[4] = part[6] = part[7] = 0.0;
     const int state = bv.lm_state[gl];
     const double* xp = bv.lm + 3 * (int64_t)gl;
@@ -467,7 +468,6 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int gl, doub
         o[2] = xc[2];
         return;
     }
-    const int w = bv.lm_win[gl];
     const WinDesc& wd = bv.win[w];
     if (state == 1) {
         double a[3] = {0, 0, 0};

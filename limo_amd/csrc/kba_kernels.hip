@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c
     if (!st.active || !st.need_lin) return;
     __shared__ double lds[8];
     double part[2] = {0.0, 0.0};
-    if ((int)threadIdx.x < bv.lblk_n[b]) lm_accum_lane(bv, c, bv.lblk_lm0[b] + threadIdx.x, part);
+    if ((int)threadIdx.x < bv.lblk_n[b]) lm_accum_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x, part);
     const double m = wave_max(part[0]);
     const double s = wave_sum(part[1]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c,
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     int fail = 0;
-    if ((int)threadIdx.x < bv.lblk_n[b]) fail = lm_damp_lane(bv, c, bv.lblk_lm0[b] + threadIdx.x);
+    if ((int)threadIdx.x < bv.lblk_n[b]) fail = lm_damp_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x);
     const int any = __syncthreads_or(fail);
     if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 5] = any ? 1.0 : 0.0;
 }
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c,
     __shared__ double lds[16];
     double part[8];
     part[2] = part[3] = part[4] = part[6] = part[7] = 0.0;
-    if ((int)threadIdx.x < bv.lblk_n[b]) backsub_lane(bv, c, bv.lblk_lm0[b] + threadIdx.x, part);
+    if ((int)threadIdx.x < bv.lblk_n[b]) backsub_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x, part);
     const int any_fail = __syncthreads_or(part[7] != 0.0);
     const double v4[4] = {part[2], part[3], part[4], part[6]};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -149,7 +149,7 @@ struct EmuBatch : Executor {
                 double gmax = 0.0, xn2 = 0.0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) {
                     double part[8];
-                    lm_accum_lane(v, c, v.lblk_lm0[b] + t, part);
+                    lm_accum_lane(v, c, w, v.lblk_lm0[b] + t, part);
                     gmax = std::fmax(gmax, part[0]);
                     xn2 += part[1];
                 }
@@ -188,7 +188,7 @@ struct EmuBatch : Executor {
                 const int w = v.lblk_win[b];
                 if (!v.st[w].active) continue;
                 int fail = 0;
-                for (int t = 0; t < v.lblk_n[b]; ++t) fail |= lm_damp_lane(v, c, v.lblk_lm0[b] + t);
+                for (int t = 0; t < v.lblk_n[b]; ++t) fail |= lm_damp_lane(v, c, w, v.lblk_lm0[b] + t);
                 v.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
             }
             // Schur slabs: upper triangle of Z^T Z per Schur workgroup (rhs = column nfq, see kba_items.hpp)
@@ -255,7 +255,7 @@ struct EmuBatch : Executor {
                 double mcc = 0.0, s2 = 0.0, c2 = 0.0, cost = 0.0, fail = 0.0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) {
                     double part[8];
-                    backsub_lane(v, c, v.lblk_lm0[b] + t, part);
+                    backsub_lane(v, c, w, v.lblk_lm0[b] + t, part);
                     mcc += part[2];
                     s2 += part[3];
                     c2 += part[4];
