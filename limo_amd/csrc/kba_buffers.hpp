@@ -89,6 +89,8 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
     KBA_BUF(blk_part, NB * kLinPartial * D, nullptr);
     KBA_BUF(blk_fail, NB * I, nullptr);
+    KBA_BUF(lv_part, (size_t)(P.lvpart_total > 0 ? P.lvpart_total : 1) * D, nullptr);
+    KBA_BUF(lblk_linfail, NL * I, nullptr);
     KBA_BUF(blk_cost_c, NB * D, nullptr);
     KBA_BUF(blk_fail_c, NB * I, nullptr);
     KBA_BUF(lm_V, (size_t)P.SL * 6 * D, nullptr);
@@ -122,11 +124,11 @@ struct PartialArray {
     int point;
 };
 inline std::vector<PartialArray> partial_arrays(const PackedBatch& P) {
-    const size_t NB = (size_t)std::max(1, P.n_blk), NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG),
+    const size_t NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG),
                  TL = (size_t)std::max(1, P.TL);
     return {
-        {offsetof(BatchView, blk_part), NB * kLinPartial, false, 1},
-        {offsetof(BatchView, blk_fail), NB, true, 1},
+        {offsetof(BatchView, lv_part), (size_t)std::max<int64_t>(1, P.lvpart_total), false, 1},
+        {offsetof(BatchView, lblk_linfail), NL, true, 1},
         {offsetof(BatchView, gp_r), (size_t)P.SG, false, 1},
         {offsetof(BatchView, gp_F), (size_t)P.SG * 10, false, 1},
         {offsetof(BatchView, gp_cost), TG, false, 1},

@@ -170,6 +170,92 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
     linearize_lane_acc(bv, c, b, t, out, want_cost);
 }
 
+// ---- landmark-major linearisation (k_lin_lm): a lane holds ONE landmark and walks over the window's views.
+// Per (landmark, view) pair: lin_obs as above (residual, factored Jacobian planes, camera-side sums), planes stored at
+// the observation's index, and the landmark block V += E^T E, g += E^T r with E = c^T H - the statements of the
+// former k_lm_accum, in the same view order, so V and g keep their bits; the 56 B / observation that kernel read back
+// (and its launch) are gone.  The camera-side sums of a view leave the wave through one reduce-scatter per view
+// (a slice per wave, no barrier inside the view loop; the four slices are added after the last view: BatchView::lv_part).
+struct LmAcc {
+    double V[6], g[3];
+};
+KBA_HD void lin_lm_accum(const double* vl, const double* r3, const double* c4, LmAcc& a) {
+    double E[9];
+    ft_build(c4, vl, E);  // E = c^T H, H = Rc R(q) of the view (view_consts_item)
+    for (int row = 0; row < 3; ++row) {
+        const double e0 = E[row * 3], e1 = E[row * 3 + 1], e2 = E[row * 3 + 2];
+        a.V[0] += e0 * e0;
+        a.V[1] += e0 * e1;
+        a.V[2] += e0 * e2;
+        a.V[3] += e1 * e1;
+        a.V[4] += e1 * e2;
+        a.V[5] += e2 * e2;
+        a.g[0] += e0 * r3[row];
+        a.g[1] += e1 * r3[row];
+        a.g[2] += e2 * r3[row];
+    }
+}
+// after the views: the landmark's ground-plane row, V / g / Jacobi scale to memory.  part: [0] max|g|, [1] |x|^2
+KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int w, int gl, LmAcc& a, double* part) {
+    double* V = a.V;
+    double* g = a.g;
+    const int gg = bv.lm_gp[gl];
+    if (gg >= 0) {
+        const double e0 = bv.gp_E[0 * bv.SG + gg], e1 = bv.gp_E[1 * bv.SG + gg], e2 = bv.gp_E[2 * bv.SG + gg];
+        const double r = bv.gp_r[gg];
+        V[0] += e0 * e0;
+        V[1] += e0 * e1;
+        V[2] += e0 * e2;
+        V[3] += e1 * e1;
+        V[4] += e1 * e2;
+        V[5] += e2 * e2;
+        g[0] += e0 * r;
+        g[1] += e1 * r;
+        g[2] += e2 * r;
+    }
+    for (int i = 0; i < 6; ++i) bv.lm_V[i * bv.SL + gl] = V[i];
+    for (int i = 0; i < 3; ++i) bv.lm_g[i * bv.SL + gl] = g[i];
+    if (bv.st[w].compute_scale) {
+        const double d[3] = {V[0], V[3], V[5]};
+        for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
+    }
+    part[0] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    const double* x = bv.lm + 3 * (int64_t)gl;
+    part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+}
+// Plain form of one landmark for the CPU emulation (k_lin_lm runs the same statements software-pipelined and
+// branch-free): cam[j] receives the camera-side sums of view j.  Returns 1 if a functor failed.
+KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl, bool want_cost, LinLane* cam, double* part) {
+    const WinDesc& wd = bv.win[w];
+    part[0] = part[1] = 0.0;
+    for (int j = 0; j < wd.n_view; ++j) {
+        cam[j].cost = 0.0;
+        cam[j].fail = 0;
+        for (int i = 0; i < 21; ++i) cam[j].U[i] = 0.0;
+        for (int i = 0; i < 6; ++i) cam[j].g[i] = 0.0;
+    }
+    const int state = bv.lm_state[gl];
+    if (state == 0) return 0;
+    LmAcc acc;
+    for (int i = 0; i < 6; ++i) acc.V[i] = 0.0;
+    for (int i = 0; i < 3; ++i) acc.g[i] = 0.0;
+    int fail = 0;
+    for (int j = 0; j < wd.n_view; ++j) {
+        const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
+        if (s < 0) continue;
+        LinIn in;
+        lin_fetch(bv, s, gl, in);
+        const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);
+        double r3[3], c4[4];
+        if (!lin_obs(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
+        for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + s] = r3[i];
+        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + s] = c4[i];
+        lin_lm_accum(vl, r3, c4, acc);
+    }
+    if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
+    return fail;
+}
+
 // Un-robustified residual norms for trimming (robust_solving.cpp:24-44 with apply_loss = false).
 KBA_HD void trim_residual_lane(const BatchView& bv, int b, int t, double* plane_rep, double* plane_dep) {
     if (t >= bv.blk_n[b]) return;
@@ -223,62 +309,6 @@ KBA_HD void gp_lane(const BatchView& bv, int g, bool candidate, double* cost_out
 }
 
 // ======================================================================================= landmarks
-// V = sum E^T E, g = sum E^T r over the landmark's observations (+ its ground-plane row).
-// part: [0] max|g| (gradient inf-norm part), [1] |x|^2
-// w = window of the landmark, handed in by the caller: uniform over the workgroup, so the window descriptor and the
-// per-view constants come through scalar loads instead of one vector load per lane
-KBA_HD void lm_accum_lane(const BatchView& bv, const SolveConsts& c, int w, int gl, double* part) {
-    part[0] = 0.0;
-    part[1] = 0.0;
-    if (bv.lm_state[gl] != 1) return;
-    const WinDesc& wd = bv.win[w];
-    double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    for (int j = 0; j < wd.n_view; ++j) {
-        const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
-        if (s < 0) continue;
-        double E[9], r[3];
-        double c4[4];
-        for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
-        for (int i = 0; i < 3; ++i) r[i] = bv.obs_r[i * bv.SO + s];
-        ft_build(c4, bv.view_lin + (int64_t)kViewLin * (wd.view0 + j), E);  // E = c^T H, H = Rc R(q) of the view (view_consts_item)
-        for (int row = 0; row < 3; ++row) {
-            const double e0 = E[row * 3], e1 = E[row * 3 + 1], e2 = E[row * 3 + 2];
-            V[0] += e0 * e0;
-            V[1] += e0 * e1;
-            V[2] += e0 * e2;
-            V[3] += e1 * e1;
-            V[4] += e1 * e2;
-            V[5] += e2 * e2;
-            g[0] += e0 * r[row];
-            g[1] += e1 * r[row];
-            g[2] += e2 * r[row];
-        }
-    }
-    const int gg = bv.lm_gp[gl];
-    if (gg >= 0) {
-        const double e0 = bv.gp_E[0 * bv.SG + gg], e1 = bv.gp_E[1 * bv.SG + gg], e2 = bv.gp_E[2 * bv.SG + gg];
-        const double r = bv.gp_r[gg];
-        V[0] += e0 * e0;
-        V[1] += e0 * e1;
-        V[2] += e0 * e2;
-        V[3] += e1 * e1;
-        V[4] += e1 * e2;
-        V[5] += e2 * e2;
-        g[0] += e0 * r;
-        g[1] += e1 * r;
-        g[2] += e2 * r;
-    }
-    for (int i = 0; i < 6; ++i) bv.lm_V[i * bv.SL + gl] = V[i];
-    for (int i = 0; i < 3; ++i) bv.lm_g[i * bv.SL + gl] = g[i];
-    if (bv.st[w].compute_scale) {
-        const double d[3] = {V[0], V[3], V[5]};
-        for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
-    }
-    part[0] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-    const double* x = bv.lm + 3 * (int64_t)gl;
-    part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-}
-
 // (V' + D^2) = L L^T with V' = S V S (Jacobi-scaled), D^2 = clamp(diag V')/radius.  Stores what the step needs of
 // the landmark block:  Bt = L^-1 S  (lower triangular, 6: [l00 s0 | l10 s0, l11 s1 | l20 s0, l21 s1, l22 s2]) - every
 // later use of L^-1 comes with the scale attached (Y' = .. S L^-T = .. Bt^T, delta = -S L^-T t = -Bt^T t) - and
@@ -887,13 +917,15 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
     KBA_SYNC();
-    // (1) observation blocks: U_k (6x6) and g_k per keyframe = sum over the linearize workgroups of its views
-    //     (contiguous range kf_blk0/kf_nblk); one lane per (keyframe, entry): single writer, fixed order.
+    // (1) observations: U_k (6x6) and g_k per keyframe = sum of the camera-side partial sums of its views over the
+    //     window's landmark workgroups and their waves (k_lin_lm); one lane per (keyframe, entry): single writer, fixed order.
     for (int e = tid; e < wd.n_kf * 27; e += nt) {
         const int kl = e / 27, q = e % 27;
-        const int b0 = bv.kf_blk0[wd.kf0 + kl], nb = bv.kf_nblk[wd.kf0 + kl];
         double acc = 0.0;
-        for (int b = b0; b < b0 + nb; ++b) acc += bv.blk_part[(int64_t)b * kLinPartial + 1 + q];
+        for (int j = 0; j < wd.n_view; ++j) {
+            if (bv.view_kf[wd.view0 + j] - wd.kf0 != kl) continue;
+            for (int b = 0; b < wd.n_lblk; ++b) acc += bv.lv_part[wd.lvpart_off + (int64_t)(b * wd.n_view + j) * kLinPartial + 1 + q];
+        }
         if (q < 21) {
             int a = 0, rem = q;
             while (rem >= 6 - a) {
@@ -1033,10 +1065,9 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     if (c.pad == 44) return;
     // (5) reductions
     double cost = 0.0, failf = 0.0, gmax = 0.0, xn2 = 0.0, reg_free = 0.0, reg_fixed = 0.0;
-    for (int b = wd.blk0 + tid; b < wd.blk0 + wd.n_blk; b += nt) {
-        cost += bv.blk_part[(int64_t)b * kLinPartial];
-        if (bv.blk_fail[b]) failf = 1.0;
-    }
+    for (int i = tid; i < wd.n_lblk * wd.n_view; i += nt) cost += bv.lv_part[wd.lvpart_off + (int64_t)i * kLinPartial];
+    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt)
+        if (bv.lblk_linfail[b]) failf = 1.0;
     for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost[g];
     for (int i = tid; i < nrows; i += nt) {
         if (rows[i].n < 0)

@@ -335,85 +335,127 @@ __global__ void k_view_consts(BatchView bv) {
     view_consts_item(bv, v);
 }
 
-// Jacobian evaluation.  A workgroup holds <= 1024 observations of ONE view: the view's constants (H = Rc R, Rc, q,
-// intrinsics: 28 doubles) are wave-uniform and live in scalar registers; a lane takes 4 observations (consecutive lanes
-// -> consecutive observations in every pass) and accumulates the 27 camera-side sums in registers before the one
-// workgroup reduction.  The passes are software-pipelined: the observation index / measurement of pass q + 2 and the
-// gathered landmark of pass q + 1 are in flight while pass q computes (the kernel is bound by the dependent chain
-// index -> landmark gather -> ~450 fp64 operations, not by bytes).
+// ------------------------------------------------------------------------------------------ linearisation, landmark-major
+// k_lin_lm: Jacobian evaluation (B1, B2, B5, B6) AND the landmark blocks V = sum E^T E, g = sum E^T r in one pass
+// (kba_items.hpp:lin_lm_lane has the plain statements).  Lane = landmark, loop over the window's views:
+//   * the view's 28 constants come through SCALAR loads: view_lin is read through the constant address space (written by
+//     k_view_consts, the launch before), so the loads stay s_load although plane stores precede them in the loop;
+//   * the observation of the pair (slot table -> index s -> u, v, d: 12 B) is fetched one view ahead, the slot two ahead;
+//   * branch-free: a landmark that does not see the view (or is out of the problem) runs the same arithmetic on a valid
+//     dummy observation, contributes zeros and stores into the dump area behind the planes;
+//   * the 28 camera-side sums of the view leave each WAVE through one reduce-scatter into the wave's LDS slice (no
+//     barrier in the loop); after the last view one barrier, then lane (view, entry) adds the four slices.
+// Bytes per pair: 4 (slot) + 12 (u, v, d) read, 56 (planes) written; per landmark 32 read + 72 written - the separate
+// view-major linearise + landmark-major accumulate pair moved 101 + 93 B per observation.
+typedef const double __attribute__((address_space(4))) cdouble;
 template <int WAVES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize(BatchView bv, SolveConsts c, const int32_t* wl) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
-    const int view = bv.blk_view[b];
-    const int w = bv.view_win[view];
+    const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
     const bool want_cost = st.first != 0;  // workgroup-uniform
-    __shared__ double lds[4 * kLinPartial];
-    // the view's constants: uniform loads BEFORE the first store of the kernel, so they are scalar loads into SGPRs
-    double vl[28];
+    const WinDesc& wd = bv.win[w];
+    const int n_view = wd.n_view;
+    const int n = bv.lblk_n[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_block = (int)threadIdx.x < n;
+    const int gl = bv.lblk_lm0[b] + (in_block ? (int)threadIdx.x : n - 1);  // lanes past the end shadow the last landmark
+    const int state = in_block ? bv.lm_state[gl] : 0;
+    LinIn in;
+    in.p[0] = bv.lm[3 * (int64_t)gl];
+    in.p[1] = bv.lm[3 * (int64_t)gl + 1];
+    in.p[2] = bv.lm[3 * (int64_t)gl + 2];
+    in.w = bv.lm_weight[gl];
+    const int32_t* slot = bv.lm_slot + gl;
+    cdouble* vc = (cdouble*)(bv.view_lin + (int64_t)kViewLin * wd.view0);
+    double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
+    extern __shared__ __attribute__((aligned(16))) double lv_lds[];  // [view][wave][kLinPartial]
+    const int64_t dump = bv.SO - kObsBlock + threadIdx.x;
+    LmAcc acc;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc.V[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc.g[i] = 0.0;
+    int fail = 0;
+    // pipeline: slot of view j + 2, measurement of view j + 1 in flight while view j computes
+    int s_cur = slot[0];
+    int s_nxt = n_view > 1 ? slot[bv.SL] : -1;
+    float u_n, v_n, d_n;
     {
-        const double* vg = bv.view_lin + (int64_t)kViewLin * view;
-#pragma unroll
-        for (int i = 0; i < 28; ++i) vl[i] = vg[i];
+        const int64_t o = s_cur >= 0 ? s_cur : 0;
+        u_n = bv.obs_u[o];
+        v_n = bv.obs_v[o];
+        d_n = bv.obs_d[o];
     }
-    const int n = bv.blk_n[b];
-    const int64_t o0 = bv.blk_obs0[b];
-    LinLane l;
-    l.cost = 0.0;
-    l.fail = 0;
+    const int rs_idx = rs28_index(lane);
+    for (int j = 0; j < n_view; ++j) {
+        double vl[28];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) l.U[i] = 0.0;
+        for (int i = 0; i < 28; ++i) vl[i] = vc[(int64_t)j * kViewLin + i];
+        const int s = s_cur;
+        in.u = u_n;
+        in.v = v_n;
+        in.d = d_n;
+        s_cur = s_nxt;
+        s_nxt = j + 2 < n_view ? slot[(int64_t)(j + 2) * bv.SL] : -1;
+        {
+            const int64_t o = s_cur >= 0 ? s_cur : 0;
+            u_n = bv.obs_u[o];
+            v_n = bv.obs_v[o];
+            d_n = bv.obs_d[o];
+        }
+        const bool have = state != 0 && s >= 0;
+        in.live = have;
+        LinLane l;
+        l.cost = 0.0;
+        l.fail = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
-    const int t0 = threadIdx.x;
-    // No divergent branch touches memory: a lane past the end of a partial block (t >= n) loads the block's last
-    // observation, is treated as dead, and stores its zeros into the dump area behind the planes (index TOpad + lane).
-    const int64_t dump = bv.SO - kObsBlock + t0;
-    auto idx = [&](int t) { return o0 + (t < n ? t : n - 1); };
-    // stage A: landmark index of the observation; stage B: the gathered inputs
-    int gl_a = bv.obs_lm[idx(t0)];
-    int gl_b = bv.obs_lm[idx(t0 + kBlock)];
-    LinIn cur;
-    lin_fetch(bv, idx(t0), gl_a, cur);
-    const int n_pass = (n + kBlock - 1) / kBlock;  // uniform
+        for (int i = 0; i < 21; ++i) l.U[i] = 0.0;
 #pragma unroll
-    for (int q = 0; q < kObsPerLane; ++q) {
-        if (q >= n_pass) break;
-        const int t = t0 + q * kBlock;
-        const int gl_n = gl_b;  // landmark of pass q + 1
-        if (q + 2 < kObsPerLane) gl_b = bv.obs_lm[idx(t + 2 * kBlock)];
-        LinIn nxt = cur;
-        if (q + 1 < kObsPerLane) lin_fetch(bv, idx(t + kBlock), gl_n, nxt);
-        if (t >= n) cur.live = 0;
+        for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
         double r3[3], c4[4];
-        if (!lin_obs(vl, c, cur, want_cost, r3, c4, l)) l.fail = 1;
-        if (c.pad != 22) {  // (22: profiling aid, skip the plane stores)
-            const int64_t o = t < n ? o0 + t : dump;
+        if (!lin_obs(vl, c, in, want_cost, r3, c4, l)) fail = 1;
+        {
+            const int64_t o = have ? s : dump;
 #pragma unroll
             for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
         }
-        cur = nxt;
+        lin_lm_accum(vl, r3, c4, acc);  // zeros where the pair does not exist
+        double vals[kLinPartial];
+        vals[0] = l.cost;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) vals[1 + i] = l.U[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
+        static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter28");
+        const double tot = wave_reduce_scatter28(vals, lane);
+        if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
     }
-    double vals[kLinPartial];
-    vals[0] = l.cost;
-#pragma unroll
-    for (int i = 0; i < 21; ++i) vals[1 + i] = l.U[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
-    const int fail = l.fail;
+    double part[2] = {0.0, 0.0};
+    if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
+    __shared__ double lds[8];
+    const double m = wave_max(part[0]);
+    const double sm = wave_sum(part[1]);
+    if (lane == 0) {
+        lds[wave] = m;
+        lds[4 + wave] = sm;
+    }
     const int any_fail = __syncthreads_or(fail);
-    if (c.pad == 21) {  // profiling aid: skip the workgroup reduction
-        if (threadIdx.x < kLinPartial) bv.blk_part[(int64_t)b * kLinPartial + threadIdx.x] = vals[0];
-    } else {
-        static_assert(kLinPartial == 28, "block_sum28");
-        block_sum28(vals, lds, bv.blk_part + (int64_t)b * kLinPartial);
+    for (int e = threadIdx.x; e < n_view * kLinPartial; e += kBlock) {
+        const double* q = lv_lds + (e / kLinPartial) * kLinWaves * kLinPartial + e % kLinPartial;
+        out[e] = (q[0] + q[kLinPartial]) + (q[2 * kLinPartial] + q[3 * kLinPartial]);
     }
-    if (threadIdx.x == 0) bv.blk_fail[b] = any_fail;
+    if (threadIdx.x == 0) {
+        bv.lblk_part[(int64_t)b * 8 + 0] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+        bv.lblk_part[(int64_t)b * 8 + 1] = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+        bv.lblk_linfail[b] = any_fail;
+    }
 }
+__host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }
 
 // shard / n_shards: landmark sharding - a shard evaluates only the rows of its own landmarks.
 // (streaming solve: grid = (listed windows, chunks of 256 rows of a window))
@@ -439,29 +481,6 @@ __global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
 }
 
 // ------------------------------------------------------------------------------------------ landmarks
-__global__ __launch_bounds__(kBlock) void k_lm_accum(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl_at(bv, wl, blockIdx.x);
-    if (b < 0) return;
-    const int w = bv.lblk_win[b];
-    const WinState& st = bv.st[w];
-    if (!st.active || !st.need_lin) return;
-    __shared__ double lds[8];
-    double part[2] = {0.0, 0.0};
-    if ((int)threadIdx.x < bv.lblk_n[b]) lm_accum_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x, part);
-    const double m = wave_max(part[0]);
-    const double s = wave_sum(part[1]);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        lds[wave] = m;
-        lds[4 + wave] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bv.lblk_part[(int64_t)b * 8 + 0] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
-        bv.lblk_part[(int64_t)b * 8 + 1] = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;

@@ -34,6 +34,7 @@ constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per p
 
 // number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
 constexpr int kLinPartial = 28;
+constexpr int kLinWaves = 4;      // waves of a landmark workgroup: each keeps its own camera-side partial sums (no barrier per view)
 
 struct WinDesc {
     int32_t kf0, n_kf;
@@ -67,6 +68,8 @@ struct WinDesc {
     int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer
     int64_t spart_off;        // offset of this window's Schur partial slabs
     int64_t sred_off;         // offset of this window's per-shard slabs (n_shards x nf_pad^2) in S_red
+    int64_t lvpart_off;       // offset of this window's camera-side partial sums in BatchView::lv_part:
+                              // [landmark workgroup of the window][view][kLinPartial]
     int64_t cam_scr_off;      // >= 0: the window's camera system does not fit into LDS (more than ~12 keyframes): offset of its
                               // scratch in BatchView::cam_scratch (k_cam_assemble / k_cam_solve work there, in L2, instead)
 };
@@ -183,8 +186,10 @@ struct BatchView {
     // materialise Jp / Jl in full.
     double *obs_r, *obs_c;            // [3|4][SO]
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
-    double* blk_part;           // [n_blk*kLinPartial]
+    double* blk_part;           // [n_blk*kLinPartial]  (view-major passes: limo_ba_evaluate)
     int32_t* blk_fail;          // [n_blk]
+    double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
+    int32_t* lblk_linfail;      // [n_lblk] a functor failed in this landmark workgroup
     double* blk_cost_c;         // [n_blk] candidate cost partials
     int32_t* blk_fail_c;        // [n_blk]
     // --- landmark side

@@ -519,6 +519,8 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
         d.sred_off = P.sred_total;
         if (P.n_shards > 1) P.sred_total += (int64_t)P.n_shards * d.nf_pad * d.nf_pad;
+        d.lvpart_off = P.lvpart_total;
+        P.lvpart_total += (int64_t)d.n_lblk * d.n_view * kLinPartial;
         {   // camera system too large for LDS: scratch in global memory (kba_items.hpp:kCamLdsCapBytes)
             const int need = std::max(cam_assemble_scratch(d.nc, kBlock), cam_solve_scratch(d.nc, kBlock));
             d.cam_scr_off = -1;

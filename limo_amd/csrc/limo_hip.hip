@@ -532,29 +532,19 @@ struct limo_ba_batch : Executor {
                 hipLaunchKernelGGL(k_view_consts, dim3(cdiv(P.TV, 256)), dim3(256), 0, s, bv);
                 LAUNCH_CHECK("k_view_consts");
             }
-            EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
-            static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;  // A/B timing aid
+            // ground-plane rows first: the landmark pass adds them to the landmark blocks
             for (size_t i = 0; i < pv.size(); ++i)
-                if (count_blk(i)) {
-                    if (lin_waves == 2)
-                        hipLaunchKernelGGL(k_linearize<2>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
-                    else if (lin_waves == 4)
-                        hipLaunchKernelGGL(k_linearize<4>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
-                    else
-                        hipLaunchKernelGGL(k_linearize<3>, dim3(count_blk(i)), dim3(kBlock), 0, s, pv[i], c, list_blk(i));
-                    LAUNCH_CHECK("k_linearize");
+                if (P.TG) {
+                    hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 0, shard_of(i), shard_P);
+                    LAUNCH_CHECK("k_gp");
+                }
+            EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
+            for (size_t i = 0; i < pv.size(); ++i)
+                if (count_lblk(i)) {
+                    hipLaunchKernelGGL(k_lin_lm<3>, dim3(count_lblk(i)), dim3(kBlock), lin_lm_lds_bytes(P.Vmax), s, pv[i], c, list_lblk(i));
+                    LAUNCH_CHECK("k_lin_lm");
                 }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
-        }
-        for (size_t i = 0; i < pv.size(); ++i) {
-            if (P.TG) {
-                hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 0, shard_of(i), shard_P);
-                LAUNCH_CHECK("k_gp");
-            }
-            if (count_lblk(i)) {
-                hipLaunchKernelGGL(k_lm_accum, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], c, list_lblk(i));
-                LAUNCH_CHECK("k_lm_accum");
-            }
         }
         allreduce(1);
         // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
@@ -782,7 +772,6 @@ struct limo_ba_batch : Executor {
         const BatchView& sv = g.sv;
         const int* cap = g.cap;
         auto L = [&](int k) { return (const int32_t*)(g.d_lists + sv.sched_off[k] + 1); };
-        static const int lin_waves = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
         if (round > 0) note(hipStreamWaitEvent(s, g.trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
         hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(g.n_slots, 256)), dim3(256), 0, s, sv, c);
         hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(kSchedThreads), 0, s, sv, round);
@@ -801,19 +790,11 @@ struct limo_ba_batch : Executor {
         // ---- linearisation of the windows that need it
         hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
         {
+            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_LINEARIZE, s) : nullptr;
-            if (cap[SL_BLK]) {
-                if (lin_waves == 2)
-                    hipLaunchKernelGGL(k_linearize<2>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-                else if (lin_waves == 4)
-                    hipLaunchKernelGGL(k_linearize<4>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-                else
-                    hipLaunchKernelGGL(k_linearize<3>, dim3(cap[SL_BLK]), dim3(kBlock), 0, s, sv, c, L(SL_BLK));
-            }
+            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lin_lm<3>, dim3(cap[SL_LBLK]), dim3(kBlock), lin_lm_lds_bytes(P.Vmax), s, sv, c, L(SL_LBLK));
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
-        if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
-        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_accum, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
         hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
         LAUNCH_CHECK("linearisation kernels");
         // ---- trust-region step of the windows that iterate

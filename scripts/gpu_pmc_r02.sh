@@ -36,11 +36,11 @@ for name, k in out["kernels"].items():
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         k["hbm_MB"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / 1e6
         k["hbm_TBps_under_counters"] = k["hbm_MB"] / k["launch_us_under_counters"] if k["launch_us_under_counters"] else None
-        if meta and "k_linearize" in name:
+        if meta and ("k_linearize" in name or "k_lin_lm" in name):
             k["hbm_bytes_per_observation"] = k["hbm_MB"] * 1e6 / meta["observations"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k and k.get("SQ_BUSY_CYCLES"):
         k["mfma_busy_over_sq_busy"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / k["SQ_BUSY_CYCLES"]
-lin = [n for n in out["kernels"] if n.startswith("k_linearize")]
+lin = [n for n in out["kernels"] if n.startswith("k_lin_lm") or n.startswith("k_linearize")]
 if lin:
     out["kernels"]["k_linearize"] = out["kernels"][lin[0]]
 json.dump(out, open("gpurun_out/r02_pmc_kernels.json", "w"), indent=1)

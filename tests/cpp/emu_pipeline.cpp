@@ -115,25 +115,6 @@ struct EmuBatch : Executor {
         }
         for (size_t si = 0; si < pv.size(); ++si) {
             BatchView& v = pv[si];
-            // K1: observations
-            for (int b = 0; b < v.n_blk; ++b) {
-                if (!owns(si, shard_P > 1 ? P.blk_owner[b] : 0)) continue;
-                const int w = v.view_win[v.blk_view[b]];
-                if (!v.st[w].active || !v.st[w].need_lin) continue;
-                double part[kLinPartial];
-                for (int i = 0; i < kLinPartial; ++i) part[i] = 0.0;
-                int fail = 0;
-                for (int t = 0; t < kObsBlock; ++t) {
-                    LinLane l;
-                    linearize_lane(v, c, b, t, l, v.st[w].first != 0);
-                    part[0] += l.cost;
-                    for (int i = 0; i < 21; ++i) part[1 + i] += l.U[i];
-                    for (int i = 0; i < 6; ++i) part[22 + i] += l.g[i];
-                    fail |= l.fail;
-                }
-                for (int i = 0; i < kLinPartial; ++i) v.blk_part[(int64_t)b * kLinPartial + i] = part[i];
-                v.blk_fail[b] = fail;
-            }
             // ground-plane rows
             for (int w = 0; w < v.n_win; ++w) {
                 if (!v.st[w].active || !v.st[w].need_lin) continue;
@@ -141,20 +122,37 @@ struct EmuBatch : Executor {
                 for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g)
                     if (owns_lm(si, v.gp_lm[g])) gp_lane(v, g, false, v.gp_cost);
             }
-            // landmarks
+            // landmark-major linearisation (k_lin_lm): observations of every landmark, planes, landmark blocks; the
+            // camera-side sums per (landmark workgroup, view, wave)
+            std::vector<LinLane> cam(kMaxViews);
             for (int b = 0; b < v.n_lblk; ++b) {
                 if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
                 const int w = v.lblk_win[b];
                 if (!v.st[w].active || !v.st[w].need_lin) continue;
+                const WinDesc& wd = v.win[w];
+                double* out = v.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * wd.n_view * kLinPartial;
+                std::vector<double> slices((size_t)wd.n_view * kLinWaves * kLinPartial, 0.0);  // [view][wave][28]
                 double gmax = 0.0, xn2 = 0.0;
+                int fail = 0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) {
                     double part[8];
-                    lm_accum_lane(v, c, w, v.lblk_lm0[b] + t, part);
+                    fail |= lin_lm_lane(v, c, w, v.lblk_lm0[b] + t, v.st[w].first != 0, cam.data(), part);
                     gmax = std::fmax(gmax, part[0]);
                     xn2 += part[1];
+                    for (int j = 0; j < wd.n_view; ++j) {
+                        double* o = slices.data() + ((size_t)j * kLinWaves + t / 64) * kLinPartial;
+                        o[0] += cam[j].cost;
+                        for (int i = 0; i < 21; ++i) o[1 + i] += cam[j].U[i];
+                        for (int i = 0; i < 6; ++i) o[22 + i] += cam[j].g[i];
+                    }
+                }
+                for (int e = 0; e < wd.n_view * kLinPartial; ++e) {
+                    const double* q = slices.data() + (size_t)(e / kLinPartial) * kLinWaves * kLinPartial + e % kLinPartial;
+                    out[e] = (q[0] + q[kLinPartial]) + (q[2 * kLinPartial] + q[3 * kLinPartial]);
                 }
                 v.lblk_part[(int64_t)b * 8 + 0] = gmax;
                 v.lblk_part[(int64_t)b * 8 + 1] = xn2;
+                v.lblk_linfail[b] = fail;
             }
         }
         exchange(1);
