@@ -499,18 +499,36 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
         return;
     }
     const WinDesc& wd = bv.win[w];
+    // The view loops are branch-free and software-pipelined (slot two views ahead, data one view ahead): a pair the
+    // landmark does not have reads observation 0 and contributes exact zeros - with `continue` around the loads the
+    // memory queue drained at every view.
+    const int32_t* slot = bv.lm_slot + gl;
+    const int n_view = wd.n_view;
     if (state == 1) {
         double a[3] = {0, 0, 0};
-        for (int j = 0; j < wd.n_view; ++j) {
-            const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
-            if (s < 0) continue;
+        int s_cur = slot[0];
+        int s_nxt = n_view > 1 ? slot[bv.SL] : -1;
+        double c4n[4];
+        {
+            const int64_t o = s_cur >= 0 ? s_cur : 0;
+            for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
+        }
+        for (int j = 0; j < n_view; ++j) {
+            const bool have = s_cur >= 0;
+            double c4[4];
+            for (int i = 0; i < 4; ++i) c4[i] = have ? c4n[i] : 0.0;
+            s_cur = s_nxt;
+            s_nxt = j + 2 < n_view ? slot[(int64_t)(j + 2) * bv.SL] : -1;
+            {
+                const int64_t o = s_cur >= 0 ? s_cur : 0;
+                for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
+            }
             const int gk = bv.view_kf[wd.view0 + j];
             const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
             const double* dR = bv.kf_dR + 9 * (int64_t)gk;
             const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);  // H = Rc R at [0..8], Rc at [12..20]
             // F dc = Ft (dR x + d_trans);  E^T (F dc) with E = c^T H
-            double Ft[9], E[9], c4[4], m[3], q[3];
-            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
+            double Ft[9], E[9], m[3], q[3];
             ft_build(c4, vl + 12, Ft);
             ft_build(c4, vl, E);
             mat3_vec(dR, x, m);
@@ -558,27 +576,43 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
     const double lw = bv.lm_weight[gl];
     double cost = 0.0;
     int fail = 0;
-    for (int j = 0; j < wd.n_view; ++j) {
-        const int s = bv.lm_slot[(int64_t)j * bv.SL + gl];
-        if (s < 0) continue;
-        const double* vc = bv.view_lin_c + (int64_t)kViewLin * (wd.view0 + j);
-        const double z0 = vc[0] * xc[0] + vc[1] * xc[1] + vc[2] * xc[2] + vc[9];
-        const double z1 = vc[3] * xc[0] + vc[4] * xc[1] + vc[5] * xc[2] + vc[10];
-        const double z2 = vc[6] * xc[0] + vc[7] * xc[1] + vc[8] * xc[2] + vc[11];
-        if (!(fabs(z2) >= 0.01)) {
-            fail = 1;
-            continue;
+    {
+        int s_cur = slot[0];
+        int s_nxt = n_view > 1 ? slot[bv.SL] : -1;
+        float un, vn, dn;
+        {
+            const int64_t o = s_cur >= 0 ? s_cur : 0;
+            un = bv.obs_u[o];
+            vn = bv.obs_v[o];
+            dn = bv.obs_d[o];
         }
-        const float d = bv.obs_d[s];
-        const double ru = vc[25] * (z0 / z2) + vc[26] - static_cast<double>(bv.obs_u[s]);
-        const double rv = vc[25] * (z1 / z2) + vc[27] - static_cast<double>(bv.obs_v[s]);
-        double rho[3];
-        loss_cauchy(c.a_rep, lw, ru * ru + rv * rv, rho);
-        cost += 0.5 * rho[0];
-        if (d > 0.0f) {
+        for (int j = 0; j < n_view; ++j) {
+            const bool have = s_cur >= 0;
+            const float u = un, v = vn, d = dn;
+            s_cur = s_nxt;
+            s_nxt = j + 2 < n_view ? slot[(int64_t)(j + 2) * bv.SL] : -1;
+            {
+                const int64_t o = s_cur >= 0 ? s_cur : 0;
+                un = bv.obs_u[o];
+                vn = bv.obs_v[o];
+                dn = bv.obs_d[o];
+            }
+            const double* vc = bv.view_lin_c + (int64_t)kViewLin * (wd.view0 + j);
+            const double z0 = vc[0] * xc[0] + vc[1] * xc[1] + vc[2] * xc[2] + vc[9];
+            const double z1 = vc[3] * xc[0] + vc[4] * xc[1] + vc[5] * xc[2] + vc[10];
+            const double z2r = vc[6] * xc[0] + vc[7] * xc[1] + vc[8] * xc[2] + vc[11];
+            const bool z_ok = fabs(z2r) >= 0.01;
+            if (have && !z_ok) fail = 1;
+            const double z2 = z_ok ? z2r : 1.0;  // keeps the arithmetic finite; masked below
+            const double ru = vc[25] * (z0 / z2) + vc[26] - static_cast<double>(u);
+            const double rv = vc[25] * (z1 / z2) + vc[27] - static_cast<double>(v);
+            double rho[3];
+            loss_cauchy(c.a_rep, lw, ru * ru + rv * rv, rho);
+            double pair = 0.5 * rho[0];
             const double rd = z2 - static_cast<double>(d);
             loss_cauchy(c.a_dep, lw, rd * rd, rho);
-            cost += 0.5 * rho[0];
+            pair += d > 0.0f ? 0.5 * rho[0] : 0.0;
+            cost += have && z_ok ? pair : 0.0;
         }
     }
     part[6] = cost;
