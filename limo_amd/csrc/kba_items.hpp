@@ -179,6 +179,7 @@ KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int
 struct LmAcc {
     double V[6], g[3];
 };
+KBA_HD int lm_damp_store(const BatchView& bv, const SolveConsts& c, double radius, int gl, const double* s, const double* V, const double* g);
 KBA_HD void lin_lm_accum(const double* vl, const double* r3, const double* c4, LmAcc& a) {
     double E[9];
     ft_build(c4, vl, E);  // E = c^T H, H = Rc R(q) of the view (view_consts_item)
@@ -195,7 +196,8 @@ KBA_HD void lin_lm_accum(const double* vl, const double* r3, const double* c4, L
         a.g[2] += e2 * r3[row];
     }
 }
-// after the views: the landmark's ground-plane row, V / g / Jacobi scale to memory.  part: [0] max|g|, [1] |x|^2
+// after the views: the landmark's ground-plane row, V / g / Jacobi scale to memory, damping.
+// part: [0] max|g|, [1] |x|^2, [5] 1 = the damped block is not positive definite
 KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int w, int gl, LmAcc& a, double* part) {
     double* V = a.V;
     double* g = a.g;
@@ -215,19 +217,25 @@ KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int w, int 
     }
     for (int i = 0; i < 6; ++i) bv.lm_V[i * bv.SL + gl] = V[i];
     for (int i = 0; i < 3; ++i) bv.lm_g[i * bv.SL + gl] = g[i];
+    double sc[3];
     if (bv.st[w].compute_scale) {
         const double d[3] = {V[0], V[3], V[5]};
-        for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
+        for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = sc[i] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
+    } else {
+        for (int i = 0; i < 3; ++i) sc[i] = bv.lm_scale[i * bv.SL + gl];
     }
     part[0] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
     const double* x = bv.lm + 3 * (int64_t)gl;
     part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    // (V' + D^2) = L L^T for the step that follows this linearisation (the radius is final: kba_lm.hpp:lm_decide_step);
+    // the stand-alone k_lm_damp only runs after rejected steps
+    part[5] = lm_damp_store(bv, c, bv.st[w].radius, gl, sc, V, g) ? 1.0 : 0.0;
 }
 // Plain form of one landmark for the CPU emulation (k_lin_lm runs the same statements software-pipelined and
 // branch-free): cam[j] receives the camera-side sums of view j.  Returns 1 if a functor failed.
 KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl, bool want_cost, LinLane* cam, double* part) {
     const WinDesc& wd = bv.win[w];
-    part[0] = part[1] = 0.0;
+    part[0] = part[1] = part[5] = 0.0;
     for (int j = 0; j < wd.n_view; ++j) {
         cam[j].cost = 0.0;
         cam[j].fail = 0;
@@ -313,13 +321,7 @@ KBA_HD void gp_lane(const BatchView& bv, int g, bool candidate, double* cost_out
 // the landmark block:  Bt = L^-1 S  (lower triangular, 6: [l00 s0 | l10 s0, l11 s1 | l20 s0, l21 s1, l22 s2]) - every
 // later use of L^-1 comes with the scale attached (Y' = .. S L^-T = .. Bt^T, delta = -S L^-T t = -Bt^T t) - and
 // t = L^-1 S g = Bt g.  Returns 1 on Cholesky failure.
-KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int w, int gl) {
-    if (bv.lm_state[gl] != 1) return 0;
-    const double radius = bv.st[w].radius;
-    double s[3], V[6], g[3];
-    for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
-    for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
-    for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
+KBA_HD int lm_damp_store(const BatchView& bv, const SolveConsts& c, double radius, int gl, const double* s, const double* V, const double* g) {
     double A[6] = {s[0] * s[0] * V[0], s[0] * s[1] * V[1], s[0] * s[2] * V[2],
                    s[1] * s[1] * V[3], s[1] * s[2] * V[4], s[2] * s[2] * V[5]};
     A[0] += fmin(fmax(A[0], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
@@ -337,6 +339,16 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int w, int gl
     bv.lm_t[1 * bv.SL + gl] = Bt[1] * g[0] + Bt[2] * g[1];
     bv.lm_t[2 * bv.SL + gl] = Bt[3] * g[0] + Bt[4] * g[1] + Bt[5] * g[2];
     return fail;
+}
+// Stand-alone pass: only after a REJECTED step (new radius, same linearisation) - after a linearisation the landmark pass
+// (lin_lm_finish) has damped with the radius of the coming step already.
+KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int w, int gl) {
+    if (bv.lm_state[gl] != 1) return 0;
+    double s[3], V[6], g[3];
+    for (int i = 0; i < 3; ++i) s[i] = bv.lm_scale[i * bv.SL + gl];
+    for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
+    for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
+    return lm_damp_store(bv, c, bv.st[w].radius, gl, s, V, g);
 }
 
 // ======================================================================================= Schur tiles

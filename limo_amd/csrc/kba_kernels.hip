@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         const double tot = wave_reduce_scatter28(vals, lane);
         if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
     }
-    double part[2] = {0.0, 0.0};
+    double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
     __shared__ double lds[8];
     const double m = wave_max(part[0]);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         lds[wave] = m;
         lds[4 + wave] = sm;
     }
-    const int any_fail = __syncthreads_or(fail);
+    const int any_fail = __syncthreads_or(fail | (part[5] != 0.0 ? 2 : 0));  // bit 0: functor, bit 1: damping
     for (int e = threadIdx.x; e < n_view * kLinPartial; e += kBlock) {
         const double* q = lv_lds + (e / kLinPartial) * kLinWaves * kLinPartial + e % kLinPartial;
         out[e] = (q[0] + q[kLinPartial]) + (q[2 * kLinPartial] + q[3 * kLinPartial]);
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     if (threadIdx.x == 0) {
         bv.lblk_part[(int64_t)b * 8 + 0] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
         bv.lblk_part[(int64_t)b * 8 + 1] = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-        bv.lblk_linfail[b] = any_fail;
+        bv.lblk_part[(int64_t)b * 8 + 5] = (any_fail & 2) ? 1.0 : 0.0;
+        bv.lblk_linfail[b] = any_fail & 1;
     }
 }
 __host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c,
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
     const int w = bv.lblk_win[b];
-    if (!bv.st[w].active) return;
+    if (!bv.st[w].active || !bv.st[w].redamp) return;  // after a linearisation k_lin_lm has damped already
     int fail = 0;
     if ((int)threadIdx.x < bv.lblk_n[b]) fail = lm_damp_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x);
     const int any = __syncthreads_or(fail);

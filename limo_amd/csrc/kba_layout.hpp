@@ -84,6 +84,8 @@ struct WinState {
     int32_t acc_solves, acc_iters, acc_success, last_iters;
     int32_t n_trimmed, acc_lin;
     int32_t phase, trim_round;  // streaming solve (kba_lm.hpp:sched_advance): where the window is in the solveTrimmed schedule
+    int32_t redamp, pad_i;      // the last step was rejected: the landmark blocks must be damped again with the new radius
+                                // (after a linearisation the landmark pass has already done it)
     double radius, decrease_factor;
     double x_cost, x_norm, fixed_cost;
     double solve_initial_cost, solve_final_cost;

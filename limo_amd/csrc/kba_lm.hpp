@@ -27,6 +27,7 @@ KBA_HD void lm_solve_init(WinState& s, bool selected, int max_iter, const SolveC
     s.term = selected ? -1 : s.term;
     s.invalid_run = 0;
     s.compute_scale = 1;
+    s.redamp = 0;
     s.n_success = 0;
     s.n_unsuccess = 0;
     s.radius = c.initial_radius;
@@ -131,11 +132,7 @@ KBA_HD void lm_decide_lin(WinState& s, const WinRed& r, double fixed_cost, const
         if (s.acc_solves == 1) s.first_initial_cost = s.solve_initial_cost;
         s.n_success = 1;
     } else {
-        s.x_norm = s.xnorm_pending;
-        const double q = 2.0 * s.rho_pending - 1.0;
-        s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
-        s.radius = fmin(c.max_radius, s.radius);
-        s.decrease_factor = 2.0;
+        s.x_norm = s.xnorm_pending;  // (radius and decrease factor of the successful step: set in lm_decide_step already)
         s.n_success += 1;
     }
     if (s.iter >= s.max_iter) {
@@ -161,6 +158,7 @@ KBA_HD void lm_decide_step(WinState& s, const WinRed& r, const SolveConsts& c) {
         }
         s.radius = s.radius / s.decrease_factor;  // StepIsInvalid
         s.decrease_factor *= 2.0;
+        s.redamp = 1;
         lm_finalize_unsuccessful(s, c);
         return;
     }
@@ -180,12 +178,22 @@ KBA_HD void lm_decide_step(WinState& s, const WinRed& r, const SolveConsts& c) {
     if (rho > c.min_relative_decrease) {  // HandleSuccessfulStep (completed in lm_decide_lin)
         s.accept = 1;
         s.need_lin = 1;
+        s.redamp = 0;
+        // the trust region of the next step (HandleSuccessfulStep -> LevenbergMarquardtStrategy::StepAccepted): fixed here
+        // rather than after the relinearisation, so that the landmark pass of the relinearisation can damp with it
+        {
+            const double q = 2.0 * rho - 1.0;
+            s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+            s.radius = fmin(c.max_radius, s.radius);
+            s.decrease_factor = 2.0;
+        }
         s.rho_pending = rho;
         s.xnorm_pending = sqrt(r.cand2);
         s.cost_pending = cand_cost;
     } else {  // HandleUnsuccessfulStep
         s.radius = s.radius / s.decrease_factor;
         s.decrease_factor *= 2.0;
+        s.redamp = 1;
         lm_finalize_unsuccessful(s, c);
     }
 }

@@ -133,12 +133,13 @@ struct EmuBatch : Executor {
                 double* out = v.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * wd.n_view * kLinPartial;
                 std::vector<double> slices((size_t)wd.n_view * kLinWaves * kLinPartial, 0.0);  // [view][wave][28]
                 double gmax = 0.0, xn2 = 0.0;
-                int fail = 0;
+                int fail = 0, damp_fail = 0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) {
                     double part[8];
                     fail |= lin_lm_lane(v, c, w, v.lblk_lm0[b] + t, v.st[w].first != 0, cam.data(), part);
                     gmax = std::fmax(gmax, part[0]);
                     xn2 += part[1];
+                    damp_fail |= part[5] != 0.0;
                     for (int j = 0; j < wd.n_view; ++j) {
                         double* o = slices.data() + ((size_t)j * kLinWaves + t / 64) * kLinPartial;
                         o[0] += cam[j].cost;
@@ -152,6 +153,7 @@ struct EmuBatch : Executor {
                 }
                 v.lblk_part[(int64_t)b * 8 + 0] = gmax;
                 v.lblk_part[(int64_t)b * 8 + 1] = xn2;
+                v.lblk_part[(int64_t)b * 8 + 5] = damp_fail ? 1.0 : 0.0;
                 v.lblk_linfail[b] = fail;
             }
         }
@@ -184,7 +186,7 @@ struct EmuBatch : Executor {
             for (int b = 0; b < v.n_lblk; ++b) {
                 if (!owns(si, shard_P > 1 ? P.lblk_owner[b] : 0)) continue;
                 const int w = v.lblk_win[b];
-                if (!v.st[w].active) continue;
+                if (!v.st[w].active || !v.st[w].redamp) continue;
                 int fail = 0;
                 for (int t = 0; t < v.lblk_n[b]; ++t) fail |= lm_damp_lane(v, c, w, v.lblk_lm0[b] + t);
                 v.lblk_part[(int64_t)b * 8 + 5] = fail ? 1.0 : 0.0;
