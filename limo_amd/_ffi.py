@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblimo_hip.so")
+LIB_PATH = os.environ.get("LIMO_HIP_LIB") or os.path.join(_HERE, "lib", "liblimo_hip.so")  # LIMO_HIP_LIB: A/B another build of the SAME library
 
 LIMO_FIX_POSE, LIMO_FIX_SCALE, LIMO_FIX_NONE = 0, 1, 2
 LIMO_OK, LIMO_ERR_INVALID, LIMO_ERR_NOT_ENOUGH_KF, LIMO_ERR_RUNTIME, LIMO_ERR_NO_DEVICE = 0, -1, -2, -3, -4
