@@ -444,7 +444,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         lds[wave] = m;
         lds[4 + wave] = sm;
     }
-    const int any_fail = __syncthreads_or(fail | (part[5] != 0.0 ? 2 : 0));  // bit 0: functor, bit 1: damping
+    const int any_fail = __syncthreads_or(fail);                // a functor failed (the OR is logical, not bitwise)
+    const int any_damp_fail = __syncthreads_or(part[5] != 0.0);  // a damped landmark block is not positive definite
     for (int e = threadIdx.x; e < n_view * kLinPartial; e += kBlock) {
         const double* q = lv_lds + (e / kLinPartial) * kLinWaves * kLinPartial + e % kLinPartial;
         out[e] = (q[0] + q[kLinPartial]) + (q[2 * kLinPartial] + q[3 * kLinPartial]);
@@ -452,8 +453,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     if (threadIdx.x == 0) {
         bv.lblk_part[(int64_t)b * 8 + 0] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
         bv.lblk_part[(int64_t)b * 8 + 1] = (lds[4] + lds[5]) + (lds[6] + lds[7]);
-        bv.lblk_part[(int64_t)b * 8 + 5] = (any_fail & 2) ? 1.0 : 0.0;
-        bv.lblk_linfail[b] = any_fail & 1;
+        bv.lblk_part[(int64_t)b * 8 + 5] = any_damp_fail ? 1.0 : 0.0;
+        bv.lblk_linfail[b] = any_fail ? 1 : 0;
     }
 }
 __host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }

@@ -5,6 +5,9 @@
 // getKeyframe :989-1021) and src/definitions.cpp (conversions :14-28,63-69, calcQuaternionDiff :104-111).
 #include "bundle_adjuster_keyframes.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstdlib>
 #include <sstream>
 #include <stdexcept>
@@ -13,6 +16,48 @@
 #include "../csrc/kba_math.hpp"
 
 namespace keyframe_bundle_adjustment {
+
+// Debugging aid: LIMO_KBA_DUMP=<dir>[:<first>[:<last>]] writes the flattened window of the solve() calls number first..last
+// (default: all) as <dir>/solve_NNNNNN.bin = int32 n_kf, n_cam, n_lm, n_obs, then the arrays of limo_ba_window in declaration
+// order (tests/window_io.py reads them back into a Window): how a window of a long drive becomes a test fixture.
+static void dump_window_if_asked(const limo_ba_window& w) {
+    static const char* spec = std::getenv("LIMO_KBA_DUMP");
+    static int call = -1;
+    ++call;
+    if (!spec) return;
+    std::string dir(spec);
+    long first = 0, last = 1L << 40;
+    const size_t c1 = dir.find(':');
+    if (c1 != std::string::npos) {
+        const std::string rest = dir.substr(c1 + 1);
+        dir = dir.substr(0, c1);
+        first = std::atol(rest.c_str());
+        const size_t c2 = rest.find(':');
+        last = c2 != std::string::npos ? std::atol(rest.c_str() + c2 + 1) : first;
+    }
+    if (call < first || call > last) return;
+    char name[64];
+    std::snprintf(name, sizeof(name), "/solve_%06d.bin", call);
+    std::FILE* f = std::fopen((dir + name).c_str(), "wb");
+    if (!f) return;
+    const int32_t head[4] = {w.n_kf, w.n_cam, w.n_lm, w.n_obs};
+    std::fwrite(head, sizeof(int32_t), 4, f);
+    std::fwrite(w.kf_pose, sizeof(double), 7 * (size_t)w.n_kf, f);
+    std::fwrite(w.kf_plane_dir, sizeof(double), 3 * (size_t)w.n_kf, f);
+    std::fwrite(w.kf_plane_dist, sizeof(double), (size_t)w.n_kf, f);
+    std::fwrite(w.kf_fixation, sizeof(int32_t), (size_t)w.n_kf, f);
+    std::fwrite(w.cam, sizeof(double), 10 * (size_t)w.n_cam, f);
+    std::fwrite(w.lm_pos, sizeof(double), 3 * (size_t)w.n_lm, f);
+    std::fwrite(w.lm_weight, sizeof(double), (size_t)w.n_lm, f);
+    std::fwrite(w.lm_is_ground, 1, (size_t)w.n_lm, f);
+    std::fwrite(w.obs_kf, sizeof(int32_t), (size_t)w.n_obs, f);
+    std::fwrite(w.obs_lm, sizeof(int32_t), (size_t)w.n_obs, f);
+    std::fwrite(w.obs_cam, sizeof(int32_t), (size_t)w.n_obs, f);
+    std::fwrite(w.obs_u, sizeof(float), (size_t)w.n_obs, f);
+    std::fwrite(w.obs_v, sizeof(float), (size_t)w.n_obs, f);
+    std::fwrite(w.obs_d, sizeof(float), (size_t)w.n_obs, f);
+    std::fclose(f);
+}
 
 // ------------------------------------------------------------------------------------------ conversions
 Pose convert(const EigenPose& p) {
@@ -446,6 +491,7 @@ std::string BundleAdjusterKeyframes::solve() {
     o.max_solver_time_sec = solver_time_sec;
     limo_ba_report rep;
     limo_ctx* ctx = context();
+    dump_window_if_asked(F.w);
     const int rc = limo_ba_solve(ctx, &F.w, &o, &rep);
     if (rc == LIMO_ERR_NOT_ENOUGH_KF) throw NotEnoughKeyframesException(F.kfs.size(), 3);
     if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_ba_solve: ") + limo_last_error(ctx));

@@ -339,6 +339,9 @@ int main(int argc, char** argv) {
         if (ba.keyframes_.size() >= 3 && !std::getenv("STREAM_NO_POSEONLY")) {
             ba.adjustPoseOnly(*cur);
             CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
+            if (ba.last_report_.termination != 0 && ba.last_report_.termination != 1)
+                std::printf("frame %d adjustPoseOnly: termination %d, cost %.6e -> %.6e, %d iterations, %d solves\n", t, ba.last_report_.termination,
+                            ba.last_report_.initial_cost, ba.last_report_.final_cost, ba.last_report_.iterations_total, ba.last_report_.num_solves);
         }
         const auto selected = selector.select({cur}, ba.getActiveKeyframePtrs());
         CHECK(selected.size() < 2);
@@ -369,6 +372,10 @@ int main(int argc, char** argv) {
             ++n_solves;
             CHECK(!summary.empty());
             CHECK(ba.last_report_.termination == 0 || ba.last_report_.termination == 1);
+            if (ba.last_report_.termination != 0 && ba.last_report_.termination != 1)
+                std::printf("frame %d solve: termination %d, cost %.6e -> %.6e, %d iterations, %d solves, %d trimmed\n", t, ba.last_report_.termination,
+                            ba.last_report_.initial_cost, ba.last_report_.final_cost, ba.last_report_.iterations_total, ba.last_report_.num_solves,
+                            ba.last_report_.n_trimmed_landmarks);
             CHECK(ba.last_report_.final_cost <= ba.last_report_.initial_cost || ba.last_report_.initial_cost < 0);
             CHECK(ba.selected_landmark_ids_.size() <= 200 + 200 + 100 + 40);  // the budgets of the voxel scheme + add-depth
         }

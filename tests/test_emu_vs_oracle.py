@@ -273,3 +273,21 @@ def test_streaming_schedule_gives_the_lock_step_results(emu):
     ra, rb = emu.solve_batch(a, two), emu.solve_batch_streaming(b, two, 2)
     for x, y, p, q in zip(a, b, ra, rb):
         assert np.array_equal(x.kf_pose, y.kf_pose) and p["n_trimmed_landmarks"] == q["n_trimmed_landmarks"] and p["num_solves"] == q["num_solves"]
+
+
+def test_window_of_the_drive_with_rejected_steps_at_a_large_radius(oracle, emu):
+    """The fixture of tests/test_gpu_ba.py::test_window_of_the_drive_with_a_failed_landmark_cholesky through the emulated
+    pipeline: ~60 iterations, 13 rejected steps, same minimum as the oracle."""
+    import os
+
+    import window_io
+
+    w = window_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_drive_frame1674.npz"))
+    we, wo = w.copy(), w.copy()
+    re = emu.solve_batch([we], default_options())[0]
+    ro, _ = oracle.solve(wo, default_options())
+    assert re["termination"] == 0 and ro["termination"] == 0
+    assert re["n_trimmed_landmarks"] == ro["n_trimmed_landmarks"]
+    assert abs(re["final_cost"] - ro["final_cost"]) <= TOL * abs(ro["final_cost"])
+    assert rel_pose_err(we.kf_pose, wo.kf_pose) <= TOL
+    assert re["iterations_total"] - re["successful_steps"] >= 5

@@ -190,3 +190,19 @@ def test_invalid_input_is_rejected(ctx):
     big = synth.make_window(6, n_kf=33, n_lm=40)  # more than kMaxKf keyframes
     with pytest.raises(ba.LimoError):
         ctx.solve(big, default_options())
+
+
+def test_window_of_the_drive_with_a_failed_landmark_cholesky(ctx, oracle):
+    """tests/golden/window_drive_frame1674.npz: the window `solve()` received at frame 1674 of the 4541-frame drive (dumped
+    with LIMO_KBA_DUMP, tests/window_io.py).  Its final solve runs ~60 iterations with 13 rejected steps; at a large trust
+    radius the damped 3x3 block of a weakly observed landmark loses positive definiteness - an INVALID STEP (shrink the
+    radius, go on), which the landmark pass once reported as a failed Jacobian evaluation (a logical OR read bitwise): the
+    solve ended with FAILURE where the oracle converges."""
+    import os
+
+    import window_io
+
+    w = window_io.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_drive_frame1674.npz"))
+    rg, ro, _, _ = check_solve_parity(ctx, oracle, w, default_options())
+    assert ro["termination"] == 0 and rg["termination"] == 0
+    assert rg["iterations_total"] > 40  # the long plateau is what makes the radius grow
