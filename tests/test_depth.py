@@ -169,4 +169,9 @@ def test_gpu_depth_batch_equals_single_calls(ctx, oracle):
     for k, o in enumerate(out):
         assert np.array_equal(o, singles[k % 3])
     assert np.array_equal(ba.depth_estimate(ctx, frames[1]), singles[1])
+    # page-locked host memory (limo_host_alloc) for the sweep: same result
+    pinned = dict(frames[0])
+    pinned["cloud"] = ba.host_array(frames[0]["cloud"].shape, np.float32)
+    pinned["cloud"][:] = frames[0]["cloud"]
+    assert np.array_equal(ba.depth_estimate(ctx, pinned), singles[0])
     assert np.array_equal(ba.depth_estimate(ctx, frames[0], use_ground_labels=False), ba.depth_estimate_batch(ctx, frames[:1], use_ground_labels=False)[0])
