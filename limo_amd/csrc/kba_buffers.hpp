@@ -87,12 +87,8 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(obs_c, (size_t)(P.evaluate_only ? 1 : P.SO * 4) * D, nullptr);
     KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
-    KBA_BUF(blk_part, NB * kLinPartial * D, nullptr);
-    KBA_BUF(blk_fail, NB * I, nullptr);
     KBA_BUF(lv_part, (size_t)(P.lvpart_total > 0 ? P.lvpart_total : 1) * D, nullptr);
     KBA_BUF(lblk_linfail, NL * I, nullptr);
-    KBA_BUF(blk_cost_c, NB * D, nullptr);
-    KBA_BUF(blk_fail_c, NB * I, nullptr);
     KBA_BUF(lm_V, (size_t)P.SL * 6 * D, nullptr);
     KBA_BUF(lm_g, (size_t)P.SL * 3 * D, nullptr);
     KBA_BUF(lm_scale, (size_t)P.SL * 3 * D, nullptr);

@@ -4,7 +4,7 @@
 // take (tid, nthreads) and a scratch pointer and use KBA_SYNC between phases, so the same statements run
 //   * on gfx950 inside the __global__ wrappers of kba_kernels.hip (tid = threadIdx.x, scratch = LDS), and
 //   * serially in tests/cpp/emu_pipeline.cpp (tid = 0, nthreads = 1) for CPU-side unit tests of the host logic.
-// Reference rows: B1/B2 linearize_lane, B3 gp_lane, B4 cam_regs, B5 losses (kba_math.hpp),
+// Reference rows: B1/B2 lin_obs / lin_lm_lane, B3 gp_lane, B4 cam_regs, B5 losses (kba_math.hpp),
 // B6 manifolds, B7 trim_*, B8 lm_accum/lm_damp/schur_*/cam_assemble/cam_solve/backsub_lane.
 #pragma once
 #include "kba_layout.hpp"
@@ -40,7 +40,7 @@ struct LinLane {
 
 // Per-view constants of the current poses (one item per view, before the observations are linearised):
 //   vl[0..8] H = Rc R(q), vl[9..11] h0 = Rc t + tc (camera point = H p + h0), vl[12..20] Rc, vl[21..24] q, vl[25..27] f, cx, cy.
-// In k_linearize a workgroup holds observations of ONE view, so these are wave-uniform (scalar registers).
+// In k_lin_lm every lane of a wave is at the same view of the same window, so these are wave-uniform (scalar registers).
 KBA_HD void view_consts_item(const BatchView& bv, int view) {
     const double* cam = bv.view_cam + 16 * (int64_t)view;
     const double* pose = bv.pose + 7 * (int64_t)bv.view_kf[view];
@@ -145,29 +145,6 @@ KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, boo
         out.g[a] += J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
     }
     return z_ok || in.live == 0;
-}
-
-// Lane t of linearize workgroup b (ACCUMULATES cost / fail / U / g into `out`: a GPU lane folds kObsPerLane
-// observations before the reduction).  Plain form used by the CPU emulation; k_linearize runs the same lin_fetch /
-// lin_obs / stores software-pipelined.
-KBA_HD void linearize_lane_acc(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
-    if (t >= bv.blk_n[b]) return;
-    const int view = bv.blk_view[b];
-    const int64_t o = bv.blk_obs0[b] + t;
-    LinIn in;
-    lin_fetch(bv, o, bv.obs_lm[o], in);
-    double r3[3], c4[4];
-    if (!lin_obs(bv.view_lin + (int64_t)kViewLin * view, c, in, want_cost, r3, c4, out)) out.fail = 1;
-    for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
-    for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
-}
-
-KBA_HD void linearize_lane(const BatchView& bv, const SolveConsts& c, int b, int t, LinLane& out, bool want_cost = true) {
-    out.cost = 0.0;
-    out.fail = 0;
-    for (int i = 0; i < 21; ++i) out.U[i] = 0.0;
-    for (int i = 0; i < 6; ++i) out.g[i] = 0.0;
-    linearize_lane_acc(bv, c, b, t, out, want_cost);
 }
 
 // ---- landmark-major linearisation (k_lin_lm): a lane holds ONE landmark and walks over the window's views.

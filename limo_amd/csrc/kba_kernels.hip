@@ -223,7 +223,6 @@ __global__ void k_sched_advance(BatchView bv, SolveConsts c) {
     }
     const int gp_groups = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
     const int pl_groups = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
-    cnt[SL_BLK] = wd.n_blk;
     cnt[SL_LBLK] = wd.n_lblk;
     if (wd.schur_fast) {
         cnt[SL_SPLAIN] = pl_groups;
@@ -304,7 +303,6 @@ __global__ __launch_bounds__(256) void k_sched_fill(BatchView bv, SolveConsts c)
         if (lane == 0) L(SL_TWIN)[0] = w;
         return;
     }
-    for (int i = lane; i < wd.n_blk; i += 64) L(SL_BLK)[i] = wd.blk0 + i;
     for (int i = lane; i < wd.n_lblk; i += 64) L(SL_LBLK)[i] = wd.lblk0 + i;
     const int n_pg = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
     const int n_gg = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;

@@ -113,7 +113,7 @@ enum SchedPhase { PH_IDLE = 0, PH_TRIM_SOLVE = 1, PH_RETRY = 2, PH_TRIM = 3, PH_
 
 // Worklists the device-side scheduler rebuilds every round (streaming solve).  List k lives at
 // sched_lists + sched_off[k]: element [0] = number of entries, entries from [1].
-enum SchedList { SL_BLK = 0, SL_LBLK, SL_SPLAIN, SL_SFGP, SL_SGEN, SL_WIN, SL_TBLK, SL_TLBLK, SL_TWIN, SL_COUNT };
+enum SchedList { SL_LBLK = 0, SL_SPLAIN, SL_SFGP, SL_SGEN, SL_WIN, SL_TBLK, SL_TLBLK, SL_TWIN, SL_COUNT };
 
 struct SolveConsts {  // subset of limo_ba_options the kernels need
     double a_rep, a_dep;
@@ -160,7 +160,7 @@ struct BatchView {
     double* kf_dR;              // [TK*9] dR = derivative of R(q) along the proposed rotation step of the keyframe (k_cam_solve):
                                 // F_pose delta_pose of an observation = Ft (dR p + delta_t), no per-observation M(q, p)
     double* view_lin;           // [TV*kViewLin] per-view constants of the CURRENT poses (k_view_consts): H = Rc R(q) (9),
-                                // h0 = Rc t + tc (3), Rc (9), q (4), f, cx, cy - wave-uniform operands of k_linearize
+                                // h0 = Rc t + tc (3), Rc (9), q (4), f, cx, cy - wave-uniform operands of k_lin_lm
     const int32_t* blk_view;    // [n_blk]
     const int32_t* blk_obs0;    // [n_blk]
     const int32_t* blk_n;       // [n_blk]
@@ -188,12 +188,8 @@ struct BatchView {
     // materialise Jp / Jl in full.
     double *obs_r, *obs_c;            // [3|4][SO]
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
-    double* blk_part;           // [n_blk*kLinPartial]  (view-major passes: limo_ba_evaluate)
-    int32_t* blk_fail;          // [n_blk]
     double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
     int32_t* lblk_linfail;      // [n_lblk] a functor failed in this landmark workgroup
-    double* blk_cost_c;         // [n_blk] candidate cost partials
-    int32_t* blk_fail_c;        // [n_blk]
     // --- landmark side
     double *lm_V, *lm_g;        // planes [6|3][SL]  (unscaled E^T E, E^T r incl. ground-plane rows)
     double *lm_scale;           // [3][SL] Jacobi scaling

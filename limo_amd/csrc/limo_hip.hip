@@ -709,15 +709,14 @@ struct limo_ba_batch : Executor {
         int max_gp = 0;
         for (const WinDesc& d : P.win) {
             const int plg = (d.n_sblk_plain + c.schur_span - 1) / c.schur_span, gpg = (d.n_sblk - d.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
-            mx[SL_BLK] = std::max(mx[SL_BLK], (int)d.n_blk);
             mx[SL_LBLK] = std::max(mx[SL_LBLK], (int)d.n_lblk);
+            mx[SL_TBLK] = std::max(mx[SL_TBLK], (int)d.n_blk);
             mx[SL_SPLAIN] = std::max(mx[SL_SPLAIN], d.schur_fast ? plg : 0);
             mx[SL_SFGP] = std::max(mx[SL_SFGP], d.schur_fast ? gpg : 0);
             mx[SL_SGEN] = std::max(mx[SL_SGEN], d.schur_fast ? 0 : plg + gpg);
             max_gp = std::max(max_gp, (int)d.n_gp);
         }
         mx[SL_WIN] = 1;
-        mx[SL_TBLK] = mx[SL_BLK];
         mx[SL_TLBLK] = mx[SL_LBLK];
         mx[SL_TWIN] = 1;
         max_gp_chunks = std::max(1, cdiv(max_gp, 256));
