@@ -332,7 +332,7 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
 /*
  * The same for a batch of sweeps of one sensor rig (an offline replay: the reference's demo application reads every
  * frame of a KITTI sequence from disk, demo_keyframe_bundle_adjustment_meta/apps/main_program/main_program.cpp:97-170):
- * the frame is a grid dimension of the five kernels, so a call costs five launches whatever n_frames is.  Results are
+ * the frame is a grid dimension of every kernel, so a call costs seven launches whatever n_frames is.  Results are
  * those of n_frames separate limo_depth_estimate calls, bit for bit.
  *   flags & LIMO_DEPTH_DEVICE_POINTERS: cloud_xyzi / feat_uv / feat_is_ground / depth_out of every frame are device
  *   pointers on the context's GPU (sweeps already resident in HBM; nothing is copied).  A non-NULL feat_is_ground then
@@ -350,6 +350,15 @@ typedef struct limo_depth_frame {
 int limo_depth_estimate_batch(limo_ctx* ctx, int32_t n_frames, const limo_depth_frame* frames, const double* T_cam_lidar,
                               double f, double cx, double cy, int32_t img_w, int32_t img_h, const limo_depth_params* params,
                               uint32_t flags);
+
+/*
+ * Ground plane of frame `frame` of the LAST limo_depth_estimate / limo_depth_estimate_batch launch group on this context
+ * (a batch call runs groups of 32 frames; `frame` counts inside the last group): plane4 = (n, d) with n.p + d = 0 in the
+ * camera frame, d >= 0; all zero and *inliers = 0 if the frame had no ground-labelled feature or no plane was found.
+ * The estimator computes this plane anyway (yaml:125-143); the accessor exists so that a caller - and the parity tests -
+ * can look at it.
+ */
+int limo_depth_last_ground_plane(limo_ctx* ctx, int32_t frame, double* plane4, int32_t* inliers /* may be NULL */);
 
 #ifdef __cplusplus
 }

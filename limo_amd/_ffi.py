@@ -191,6 +191,7 @@ ABI_SYMBOLS = [
     "limo_depth_default_params",
     "limo_depth_estimate",
     "limo_depth_estimate_batch",
+    "limo_depth_last_ground_plane",
 ]
 
 _lib = None
@@ -206,6 +207,13 @@ def load():
             "limo_amd: %s not found - run `python -c 'import __graft_entry__ as g; g.build()'` first. "
             "There is no CPU fallback for the product path." % LIB_PATH
         )
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so); ours links /opt/rocm's.  A process that loads ours
+    # first and torch afterwards aborts at interpreter exit ("double free or corruption"); the other order is clean - so
+    # this Python plumbing (which uses torch for device tensors and torch.distributed anyway) fixes the order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     lib.limo_abi_version.restype = C.c_int
@@ -275,5 +283,6 @@ def load():
     lib.limo_host_free.restype = None
     lib.limo_depth_estimate_batch.argtypes = [vp, C.c_int32, C.POINTER(DepthFrame), c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                               C.POINTER(DepthParams), C.c_uint32]
+    lib.limo_depth_last_ground_plane.argtypes = [vp, C.c_int32, c_double_p, c_int32_p]
     _lib = lib
     return lib

@@ -205,6 +205,15 @@ def depth_estimate(ctx, frame, params=None, use_ground_labels=True):
     return out
 
 
+def depth_last_ground_plane(ctx, frame=0):
+    """limo_depth_last_ground_plane: (RANSAC inliers, plane4) of a frame of the last depth call on this context."""
+    pl = np.zeros(4)
+    n = C.c_int32(0)
+    rc = ctx.lib.limo_depth_last_ground_plane(ctx.ptr, frame, pl.ctypes.data_as(_ffi.c_double_p), C.byref(n))
+    _check(rc, ctx.ptr, "limo_depth_last_ground_plane")
+    return n.value, pl
+
+
 def depth_estimate_batch(ctx, frames, params=None, use_ground_labels=True, device=False):
     """limo_depth_estimate_batch over a list of frame dicts of one rig (calibration of frames[0]).
     device=False: numpy clouds / features in, list of float32 depth arrays out.

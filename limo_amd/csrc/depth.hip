@@ -6,26 +6,40 @@
 // FeaturePoint::d (matches_msg_types/include/matches_msg_types/feature_point.hpp:24-26).  Algorithmic choices the
 // parameter file leaves open are the ones documented in oracle/depth_oracle.cpp (the test oracle of this path).
 //
-// Five launches per call, every one with the frame as a grid dimension (a call carries 1..kMaxBatch sweeps):
-//   k_project    1 lane / lidar return   HBM   D1: lidar->camera, cut z<=0, pinhole projection, in-image test; visible
-//                                              returns are binned into 8x8-pixel image cells (index lists).  D6a, same
-//                                              pass: order-preserving compaction of the returns inside the z band
-//                                              (single-pass decoupled look-back scan over the workgroups of a frame).
-//                                              Also clears the OTHER scratch zone (cell counters, inlier counters, scan
-//                                              state) for the next call: no memset launches.
-//   k_ransac<first>, k_ransac<rest>   workgroup = (64 hypotheses, 1024 band returns): planes from seeded draws,
-//                inlier counts as integer atomics; the last workgroup of a frame to finish runs the sequential
-//                best-so-far / adaptive iteration bound over the counts.  <first> covers hypotheses 0..63, which is where
-//                the sequential loop almost always stops; the workgroups of <rest> leave at once unless it did not.
-//   k_refine     moments of the band returns near the RANSAC plane in one pass, fixed two-level summation order
-//                (deterministic); the last workgroup adds the chunk sums and finishes the plane (smallest eigenvector of
-//                the scatter matrix, sign).
-//   k_features   1 wave / feature   D2: gather the returns of the cells under the 6x9 px rectangle (ballot compaction
-//                into LDS, ordered by return index), D3: depth histogram in LDS + nearest local maximum, D4: largest
-//                triangle as a wave reduction over point pairs, plane, ray intersection, D5: gates; D6b: ground features
-//                use the inverse-distance weighted patch.
-// algorithmic bytes: 16 B read per return + 48 B written per visible return (u,v,x,y,z as fp64 + index);
-// per feature 8 B + ~10 neighbours x 48 B + 4 B out.
+// BIT-EXACT CONTRACT.  Every accept / reject decision and every depth of this file equals the oracle's bit for bit:
+//   * this translation unit is compiled with floating-point contraction OFF (pragma below + -ffp-contract=off in the
+//     build): every + - * / sqrt is one IEEE-754 operation, in the order the oracle writes it;
+//   * nothing derived from a return is stored in fp64: every kernel recomputes the camera-frame position / pixel of a
+//     return from its 16-byte record with the same statements (cam_point, pixel_of), so all kernels see the same bits;
+//   * the only long sum of the path - the moments of the ground-plane refinement - is accumulated in FIXED POINT
+//     (int64, units 2^-30 m and 2^-20 m^2): integer addition is associative, so the sum does not depend on the
+//     workgroup / lane / atomic order, and the oracle forms the same integers;
+//   * workgroups never hand data to each other inside a launch, with one exception: the look-back scan of k_project,
+//     whose messages are single 64-bit words (flag and value in one atomic).  Everything else is ordered by kernel
+//     boundaries (no "last workgroup" hand-offs through relaxed counters).
+//
+// Seven launches per call, every one with the frame as a grid dimension (a call carries 1..kMaxBatch sweeps):
+//   k_project    1 lane / lidar return   HBM   D1: lidar->camera, cut z<=0, pinhole projection, in-image test; the index
+//                                              of a visible return goes into the list of its 8x8-pixel image cell.  D6a,
+//                                              same pass: order-preserving compaction of the indices of the returns
+//                                              inside the z band (single-pass decoupled look-back scan over the
+//                                              workgroups of a frame).  Also clears the OTHER scratch zone (cell
+//                                              counters, inlier counters, moments, scan state) for the next call.
+//   k_ransac<first>, k_pick, k_ransac<rest>   workgroup = (64 hypotheses, 1024 returns): planes from seeded draws out
+//                of the band list, inlier counts over the sweep (band predicate evaluated on the fly) as integer
+//                atomics.  k_pick (one wave per frame) applies the sequential best-so-far / adaptive-iteration-bound
+//                semantics to hypotheses 0..63, which is where that loop almost always stops; the workgroups of <rest>
+//                leave at once unless it did not.
+//   k_refine     fixed-point moments of the band returns near the RANSAC plane (int64 atomics, order-free)
+//   k_plane      one wave per frame: centroid + scatter from the moments, smallest eigenvector, orientation
+//   k_features   1 wave / feature   D2: the returns of the cells under the 6x9 px rectangle, all cells in one pass
+//                (prefix sum over the cell counts, lane = candidate), ordered by return index; D3: depth histogram in
+//                LDS + nearest local maximum, D4: largest triangle as a wave reduction over point pairs, plane, ray
+//                intersection, D5: gates; D6b: ground features use the inverse-distance weighted patch.
+// HBM bytes moved (16 B / return + 20 B / visible return; 212 B / feature): k_project reads 16 B / return
+// and writes 4 B / visible return + 4 B / band return; k_ransac / k_refine read 16 B / return; k_features reads
+// ~20 B / candidate return (index + record) + 8 B / cell.
+#pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,21 +48,25 @@
 #include <vector>
 
 #include "../../include/limo_hip.h"
-#include "kba_math.hpp"
 #include "limo_ctx.hpp"
 
 namespace {
 
 constexpr int kCell = 8;        // pixels per image cell
-constexpr int kCellCap = 48;    // returns kept per cell (KITTI density: ~5 per cell)
-constexpr int kMaxNb = 64;      // neighbours kept per feature
+constexpr int kCellCap = 48;    // returns kept per cell (a spinning 64-beam scanner: 5-13 per cell); more => LIMO_ERR_INVALID
+constexpr int kMaxNb = 64;      // neighbours per feature; more => LIMO_ERR_INVALID
 constexpr int kMaxBins = 512;   // histogram bins per feature (0.3 m bins => 150 m of depth range)
 constexpr int kMaxHyp = 4096;   // RANSAC hypotheses
 constexpr int kMaxBatch = 32;   // frames per launch group (per-frame sizes and pointers travel as kernel arguments)
 constexpr int kHypPerBlock = 64;   // = lanes of a wave: lane k keeps the count of plane k
-constexpr int kRansacChunk = 1024;  // band returns per workgroup, 4 per lane
-constexpr int kRefineChunk = 1024;
-enum { CTR_TICKET = 0, CTR_RANSAC = 1, CTR_RANSAC2 = 2, CTR_REFINE = 3, CTR_COUNT = 8 };
+constexpr int kChunk = 1024;       // returns per workgroup of k_ransac / k_refine, 4 per lane
+constexpr int kMomVals = 10;       // count, sum e (3), sum e e^T (6)
+enum { CTR_TICKET = 0, CTR_COUNT = 4 };
+enum { OVF_CELL = 1, OVF_NEIGHBOURS = 2 };
+// fixed-point units of the refinement moments (oracle/depth_oracle.cpp uses the same constants)
+constexpr double kMomScale1 = 1073741824.0;  // 2^30 per metre
+constexpr double kMomScale2 = 1048576.0;     // 2^20 per square metre
+constexpr double kMomRange = 1024.0;         // returns further than this from the anchor point do not take part
 
 struct DepthView {
     double R[9], t[3];  // camera <- lidar
@@ -65,31 +83,40 @@ struct DepthView {
     int n_pts[kMaxBatch], n_feat[kMaxBatch];
     // workspace; frame f lives at base + f * stride
     size_t pt_stride;                 // returns
-    double *pu, *pv, *px, *py, *pz;   // per return, valid for the visible ones (listed in the cells)
-    int* cell_pts;                    // [frame][cell][kCellCap]
-    int* band_idx;                    // compacted indices of the returns inside the z band, in index order
-    double *bx, *by, *bz;             // camera-frame coordinates of the band returns (same order)
-    double* ref_part;                 // [frame][chunk of kRefineChunk band returns][10] partial moments of the refinement
-    size_t ref_stride;
+    int* cell_pts;                    // [frame][cell][kCellCap] indices of the visible returns of a cell
+    int* band_idx;                    // [frame][pt_stride] indices of the returns inside the z band, in index order
     int* band_n;                      // [frame]
-    double* plane;                    // [frame][8]: n(3), d, ok, inliers, more hypotheses wanted, iteration bound
-    double* red;                      // [frame][16]: refinement moments (10); [14] = index of the best hypothesis
+    double* plane;                    // [frame][8]: n(3), d, ok, RANSAC inliers, more hypotheses wanted, iteration bound
+    int* pick;                        // [frame][2]: best hypothesis, its count (after k_pick)
+    int* overflow;                    // pinned host word: OVF_* bits (a capacity of this file was exceeded)
     // zero-initialised scratch of this call / the zone this call clears for the next one
     int *zone, *zone_next;
     size_t zone_stride, zone_next_clear;  // ints per frame; ints of zone_next this call has to clear
-    int off_hyp, off_ctr, off_scan;       // layout of a frame's zone: cell_count at 0, inlier counts, counters, scan words
+    int off_hyp, off_ctr, off_mom, off_scan;  // layout of a frame's zone: cell_count at 0, inlier counts, counters, moments, scan words
 };
 
-struct FrameView {
-    const double *pu, *pv, *px, *py, *pz;
-    const int *cell_count, *cell_pts;
-    const double* plane;
+struct Cam {
+    double x, y, z;
 };
-__device__ __forceinline__ FrameView frame_view(const DepthView& d, int f) {
-    const size_t o = (size_t)f * d.pt_stride;
-    return {d.pu + o, d.pv + o, d.px + o, d.py + o, d.pz + o, d.zone + (size_t)f * d.zone_stride,
-            d.cell_pts + (size_t)f * d.n_cells * kCellCap, d.plane + 8 * (size_t)f};
+// D1, the statements of oracle_depth_estimate: camera-frame position of a return ...
+__device__ __forceinline__ Cam cam_point(const DepthView& d, const float4 q) {
+    const double x = q.x, y = q.y, z = q.z;
+    return {d.R[0] * x + d.R[1] * y + d.R[2] * z + d.t[0], d.R[3] * x + d.R[4] * y + d.R[5] * z + d.t[1],
+            d.R[6] * x + d.R[7] * y + d.R[8] * z + d.t[2]};
 }
+// ... and its pixel; false if it is cut (behind the camera, yaml:168) or outside the image
+__device__ __forceinline__ bool pixel_of(const DepthView& d, const Cam& c, double* u, double* v) {
+    if (d.p.do_use_cut_behind_camera && !(c.z > 0.0)) return false;
+    if (c.z == 0.0) return false;
+    *u = d.f * c.x / c.z + d.cx;
+    *v = d.f * c.y / c.z + d.cy;
+    return *u >= 0.0 && *u < (double)d.img_w && *v >= 0.0 && *v < (double)d.img_h;
+}
+__device__ __forceinline__ bool in_band(const DepthView& d, const float4 q) {
+    const double z = q.z;
+    return z >= d.p.ransac_plane_min_z && z <= d.p.ransac_plane_max_z;
+}
+__device__ __forceinline__ float4 load_return(const float* cloud, int i) { return reinterpret_cast<const float4*>(cloud)[i]; }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -98,27 +125,14 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-// agent-scope accesses to the words workgroups of one launch exchange (scan state, done counters, inlier counts)
+// agent-scope accesses to the scan words of k_project (flag and value travel in ONE 64-bit word, so a relaxed atomic
+// load that sees the flag has the value)
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// "last workgroup of the frame".  Everything workgroups of one launch hand to each other travels through agent-scope
-// atomics (inlier counts, partial sums stored / loaded with st_agent_f64 / ld_agent_f64), so the counter needs no
-// release / acquire fence: an agent-scope fence per workgroup writes back and invalidates the XCD's L2 and costs more
-// than the kernels' work.  After the barrier every atomic of the workgroup has been performed; the last workgroup's
-// loads are issued after its increment has returned.
-__device__ __forceinline__ bool last_block_done(int* counter, int total) {
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
-    __syncthreads();
-    return s_last != 0;
-}
-__device__ __forceinline__ void st_agent_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------------------------------ D1 + band compaction
 constexpr unsigned long long kScanAggregate = 1ull << 32, kScanPrefix = 2ull << 32;
@@ -145,28 +159,16 @@ __global__ __launch_bounds__(256) void k_project(DepthView d) {
     const bool live = i < n_pts;
     const size_t fo = (size_t)f * d.pt_stride;
     float4 q = {0.f, 0.f, 0.f, 0.f};
-    if (live) q = reinterpret_cast<const float4*>(d.cloud[f])[i];  // 16-byte coalesced read
-    const double x = q.x, y = q.y, z = q.z;
-    const double cxp = d.R[0] * x + d.R[1] * y + d.R[2] * z + d.t[0];
-    const double cyp = d.R[3] * x + d.R[4] * y + d.R[5] * z + d.t[1];
-    const double czp = d.R[6] * x + d.R[7] * y + d.R[8] * z + d.t[2];
-    if (live && !(d.p.do_use_cut_behind_camera && !(czp > 0.0)) && czp != 0.0) {
-        const double u = d.f * cxp / czp + d.cx;
-        const double v = d.f * cyp / czp + d.cy;
-        if (u >= 0.0 && u < (double)d.img_w && v >= 0.0 && v < (double)d.img_h) {
-            d.pu[fo + i] = u;
-            d.pv[fo + i] = v;
-            d.px[fo + i] = cxp;
-            d.py[fo + i] = cyp;
-            d.pz[fo + i] = czp;
-            const int cell = ((int)v / kCell) * d.cells_x + (int)u / kCell;
-            const int pos = atomicAdd(&zone[cell], 1);
-            if (pos < kCellCap) d.cell_pts[((size_t)f * d.n_cells + cell) * kCellCap + pos] = i;
-        }
+    if (live) q = load_return(d.cloud[f], i);  // 16-byte coalesced read
+    double u, v;
+    if (live && pixel_of(d, cam_point(d, q), &u, &v)) {
+        const int cell = ((int)v / kCell) * d.cells_x + (int)u / kCell;
+        const int pos = atomicAdd(&zone[cell], 1);
+        if (pos < kCellCap) d.cell_pts[((size_t)f * d.n_cells + cell) * kCellCap + pos] = i;
     }
     if (!((d.ground_mask >> f) & 1u)) return;  // no ground plane wanted for this frame (uniform over the workgroup)
     // ---- D6a: returns with lidar z inside [min_z, max_z], kept in index order
-    const bool flag = live && z >= d.p.ransac_plane_min_z && z <= d.p.ransac_plane_max_z;
+    const bool flag = live && in_band(d, q);
     const unsigned long long m = __ballot(flag);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[wave] = __popcll(m);
@@ -187,9 +189,9 @@ __global__ __launch_bounds__(256) void k_project(DepthView d) {
                 } while (__any((w >> 32) == 0));
                 const unsigned long long pm = __ballot((w >> 32) == 2);
                 const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;
-                int v = lane <= first_p ? (int)(unsigned)(w & 0xffffffffull) : 0;
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                excl += v;
+                int val = lane <= first_p ? (int)(unsigned)(w & 0xffffffffull) : 0;
+                for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+                excl += val;
                 if (pm) break;
             }
             if (lane == 0) st_agent(&st[blk], kScanPrefix | (unsigned)(excl + agg));
@@ -203,16 +205,12 @@ __global__ __launch_bounds__(256) void k_project(DepthView d) {
     if (flag) {
         int off = s_base;
         for (int k = 0; k < wave; ++k) off += wave_cnt[k];
-        const size_t pos = fo + off + __popcll(m & ((1ull << lane) - 1ull));
-        d.band_idx[pos] = i;
-        d.bx[pos] = cxp;
-        d.by[pos] = cyp;
-        d.bz[pos] = czp;
+        d.band_idx[fo + off + __popcll(m & ((1ull << lane) - 1ull))] = i;
     }
 }
 
 // ------------------------------------------------------------------------------------------ D6a ground plane
-// hypothesis `it` of a frame: plane through three seeded band returns; false for a degenerate draw
+// vertex v of hypothesis `it`: position in the band list (oracle_ground_plane draws the same numbers)
 __device__ __forceinline__ size_t hyp_vertex(const DepthView& d, int nb, int it, int v) {
     const uint64_t h = splitmix64(d.p.ransac_seed * 0x100000001B3ull + (uint64_t)it);
     return splitmix64(h + (uint64_t)v) % (uint64_t)nb;
@@ -228,120 +226,212 @@ __device__ __forceinline__ bool plane_through(const double* a, const double* b, 
     pl[3] = -(pl[0] * a[0] + pl[1] * a[1] + pl[2] * a[2]);
     return true;
 }
-__device__ bool hyp_plane(const DepthView& d, size_t fo, int nb, int it, double* pl) {
+__device__ bool hyp_plane(const DepthView& d, int f, int nb, int it, double* pl) {
     if (nb < 3) return false;
     const size_t i0 = hyp_vertex(d, nb, it, 0), i1 = hyp_vertex(d, nb, it, 1), i2 = hyp_vertex(d, nb, it, 2);
     if (i0 == i1 || i0 == i2 || i1 == i2) return false;
-    const double a[3] = {d.bx[fo + i0], d.by[fo + i0], d.bz[fo + i0]}, b[3] = {d.bx[fo + i1], d.by[fo + i1], d.bz[fo + i1]},
-                 c[3] = {d.bx[fo + i2], d.by[fo + i2], d.bz[fo + i2]};
+    const int* bidx = d.band_idx + (size_t)f * d.pt_stride;
+    const Cam A = cam_point(d, load_return(d.cloud[f], bidx[i0])), B = cam_point(d, load_return(d.cloud[f], bidx[i1])),
+              C = cam_point(d, load_return(d.cloud[f], bidx[i2]));
+    const double a[3] = {A.x, A.y, A.z}, b[3] = {B.x, B.y, B.z}, c[3] = {C.x, C.y, C.z};
     return plane_through(a, b, c, pl);
 }
 
-// Inlier counts: workgroup = (kHypPerBlock hypotheses, kRansacChunk band returns).  The returns are loaded once (4 per
-// lane, issued before anything else); 192 lanes draw and gather the 3 vertices of the 64 planes, 64 lanes build the planes
-// (LDS); every wave then tests its returns against the planes (ballot + popcount: wave-uniform counts, lane k keeps the
-// count of plane k).  Integer atomics make the totals order-independent.  The last workgroup of the frame applies the
-// sequential RANSAC semantics to the pre-computed hypotheses: keep the best so far, stop once the adaptive iteration
-// bound k = log(1-p)/log(1-w^3) is reached.
+// Inlier counts: workgroup = (kHypPerBlock hypotheses, kChunk returns of the sweep).  The returns are loaded once (4 per
+// lane, issued before anything else) and tested for the z band on the fly; 192 lanes draw and gather the 3 vertices of the
+// 64 planes, 64 lanes build the planes (LDS); every wave then tests its returns against the planes (ballot + popcount:
+// wave-uniform counts, lane k keeps the count of plane k).  Integer atomics make the totals order-independent.
 //
-// The sequential semantics almost always stop inside the first 64 hypotheses (inlier ratio 0.5 => bound 35), so the
-// counts come in two launches: <true> = hypotheses 0..63 + the pick over them; <false> = the other hypotheses, whose
-// workgroups leave at once unless the first pick asked for more (plane[6]), + the continued pick.
+// The sequential RANSAC semantics (keep the best so far, stop once the adaptive iteration bound
+// k = log(1-p)/log(1-w^3) is reached) almost always stop inside the first 64 hypotheses (inlier ratio 0.5 => bound 35),
+// so the counts come in two launches: <true> = hypotheses 0..63, then k_pick; <false> = the other hypotheses, whose
+// workgroups leave at once unless k_pick asked for more (plane[6]).
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_ransac(DepthView d) {
     const int f = blockIdx.z;
     if (!((d.ground_mask >> f) & 1u)) return;
-    double* plane = d.plane + 8 * (size_t)f;
-    if (!FIRST && plane[6] == 0.0) return;
+    if (!FIRST && d.plane[8 * (size_t)f + 6] == 0.0) return;
+    const int n_pts = d.n_pts[f];
+    const int q0 = blockIdx.y * kChunk;
+    if (q0 >= n_pts) return;  // the grid is sized for the largest sweep of the call
+    const int nb = d.band_n[f];
+    if (nb < 3) return;
     __shared__ double vtx[kHypPerBlock][3][3];
     __shared__ int vidx[kHypPerBlock][3];
     __shared__ double pl[kHypPerBlock][4];
     __shared__ int valid[kHypPerBlock], bc[kHypPerBlock];
-    __shared__ int cnts[FIRST ? kHypPerBlock : kMaxHyp];
-    int* zone = d.zone + (size_t)f * d.zone_stride;
-    int* hyp_count = zone + d.off_hyp;
+    int* hyp_count = d.zone + (size_t)f * d.zone_stride + d.off_hyp;
     const size_t fo = (size_t)f * d.pt_stride;
     const int n_hyp = d.n_hyp;
     const int h0 = (FIRST ? 0 : (int)blockIdx.x + 1) * kHypPerBlock;
-    const int nb = d.band_n[f];
-    const int q0 = blockIdx.y * kRansacChunk;
-    const int n_chunk = max(1, (nb + kRansacChunk - 1) / kRansacChunk);  // the grid is sized for the whole sweep
-    if ((int)blockIdx.y >= n_chunk) return;
     const int lane = threadIdx.x & 63;
-    if (nb >= 3) {
-        double x[4], y[4], z[4];
-        bool live[4];
+    double x[4], y[4], z[4];
+    bool live[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = q0 + k * 256 + (int)threadIdx.x;
-            live[k] = q < nb;
-            x[k] = live[k] ? d.bx[fo + q] : 0.0;
-            y[k] = live[k] ? d.by[fo + q] : 0.0;
-            z[k] = live[k] ? d.bz[fo + q] : 0.0;
-        }
-        if (threadIdx.x < 3 * kHypPerBlock) {
-            const int hl = threadIdx.x / 3, v = threadIdx.x % 3;
-            const size_t i = hyp_vertex(d, nb, min(h0 + hl, n_hyp - 1), v);
-            vidx[hl][v] = (int)i;
-            vtx[hl][v][0] = d.bx[fo + i];
-            vtx[hl][v][1] = d.by[fo + i];
-            vtx[hl][v][2] = d.bz[fo + i];
-        }
-        __syncthreads();
-        if (threadIdx.x < kHypPerBlock) {
-            const int hl = threadIdx.x;
-            double p4[4] = {0.0, 0.0, 0.0, 0.0};
-            const bool distinct = vidx[hl][0] != vidx[hl][1] && vidx[hl][0] != vidx[hl][2] && vidx[hl][1] != vidx[hl][2];
-            valid[hl] = h0 + hl < n_hyp && distinct && plane_through(vtx[hl][0], vtx[hl][1], vtx[hl][2], p4);
-            for (int k = 0; k < 4; ++k) pl[hl][k] = p4[k];
-            bc[hl] = 0;
-        }
-        __syncthreads();
-        const double thr = d.p.ransac_plane_distance_treshold;
-        int mine = 0;  // lane k: inliers of plane k among this wave's returns
-#pragma unroll 4
-        for (int k = 0; k < kHypPerBlock; ++k) {
-            const double a = pl[k][0], b = pl[k][1], c = pl[k][2], dd = pl[k][3];
-            int n = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) n += __popcll(__ballot(live[j] && fabs(a * x[j] + b * y[j] + c * z[j] + dd) < thr));
-            if (lane == k) mine = n;
-        }
-        if (mine) atomicAdd(&bc[lane], mine);
-        __syncthreads();
-        if (threadIdx.x < kHypPerBlock && bc[threadIdx.x] && valid[threadIdx.x]) atomicAdd(&hyp_count[h0 + threadIdx.x], bc[threadIdx.x]);
+    for (int k = 0; k < 4; ++k) {
+        const int q = q0 + k * 256 + (int)threadIdx.x;
+        float4 r = {0.f, 0.f, 0.f, 0.f};
+        if (q < n_pts) r = load_return(d.cloud[f], q);
+        live[k] = q < n_pts && in_band(d, r);
+        const Cam c = cam_point(d, r);
+        x[k] = c.x;
+        y[k] = c.y;
+        z[k] = c.z;
     }
-    if (!last_block_done(&zone[d.off_ctr + (FIRST ? CTR_RANSAC : CTR_RANSAC2)], gridDim.x * n_chunk)) return;
-    const int it0 = FIRST ? 0 : kHypPerBlock, it1 = FIRST ? min(n_hyp, kHypPerBlock) : n_hyp;
-    for (int h = it0 + threadIdx.x; h < it1; h += 256) cnts[h - it0] = __hip_atomic_load(&hyp_count[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 3 * kHypPerBlock) {
+        const int hl = threadIdx.x / 3, v = threadIdx.x % 3;
+        const size_t i = hyp_vertex(d, nb, min(h0 + hl, n_hyp - 1), v);
+        vidx[hl][v] = (int)i;
+        const Cam c = cam_point(d, load_return(d.cloud[f], d.band_idx[fo + i]));
+        vtx[hl][v][0] = c.x;
+        vtx[hl][v][1] = c.y;
+        vtx[hl][v][2] = c.z;
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double* red = d.red + 16 * (size_t)f;
-    int best = FIRST ? 0 : (int)plane[5], bi = FIRST ? -1 : (int)red[14];
-    double k_needed = FIRST ? (double)n_hyp : plane[7];
-    for (int it = it0; it < it1; ++it) {
-        if (it >= k_needed) break;
-        const int c = cnts[it - it0];
-        if (c > best) {
-            best = c;
-            bi = it;
-            const double w = (double)c / (double)nb;
-            const double denom = log(fmax(1e-300, 1.0 - w * w * w));
-            k_needed = denom < 0 ? log(1.0 - d.p.ransac_plane_probability) / denom : 0.0;
-        }
+    if (threadIdx.x < kHypPerBlock) {
+        const int hl = threadIdx.x;
+        double p4[4] = {0.0, 0.0, 0.0, 0.0};
+        const bool distinct = vidx[hl][0] != vidx[hl][1] && vidx[hl][0] != vidx[hl][2] && vidx[hl][1] != vidx[hl][2];
+        valid[hl] = h0 + hl < n_hyp && distinct && plane_through(vtx[hl][0], vtx[hl][1], vtx[hl][2], p4);
+        for (int k = 0; k < 4; ++k) pl[hl][k] = p4[k];
+        bc[hl] = 0;
     }
-    double p4[4] = {0.0, 0.0, 0.0, 0.0};
-    if (bi >= 0) hyp_plane(d, fo, nb, bi, p4);
-    for (int k = 0; k < 4; ++k) plane[k] = p4[k];
-    plane[4] = (best >= 3) ? 1.0 : 0.0;
-    plane[5] = best;
-    plane[6] = (FIRST && it1 < n_hyp && k_needed > (double)it1) ? 1.0 : 0.0;  // the sequential loop would go on
-    plane[7] = k_needed;
-    red[14] = bi;
+    __syncthreads();
+    const double thr = d.p.ransac_plane_distance_treshold;
+    int mine = 0;  // lane k: inliers of plane k among this wave's returns
+#pragma unroll 4
+    for (int k = 0; k < kHypPerBlock; ++k) {
+        const double a = pl[k][0], b = pl[k][1], c = pl[k][2], dd = pl[k][3];
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n += __popcll(__ballot(live[j] && fabs(a * x[j] + b * y[j] + c * z[j] + dd) < thr));
+        if (lane == k) mine = n;
+    }
+    if (mine) atomicAdd(&bc[lane], mine);
+    __syncthreads();
+    if (threadIdx.x < kHypPerBlock && bc[threadIdx.x] && valid[threadIdx.x]) atomicAdd(&hyp_count[h0 + threadIdx.x], bc[threadIdx.x]);
 }
 
-// One Jacobi rotation of the symmetric 3x3 matrix (a00 a01 a02 a11 a12 a22) in the (I,J) plane, eigenvectors in V;
-// indices are compile-time constants so that everything stays in registers.
+// The sequential RANSAC loop over pre-computed counts [it0, it1): statements of oracle_ground_plane.
+struct PickState {
+    int best, bi;
+    double k_needed;
+};
+__device__ __forceinline__ void pick_range(const DepthView& d, const int* hyp_count, int nb, int it0, int it1, PickState& s) {
+    for (int it = it0; it < it1; ++it) {
+        if (it >= s.k_needed) break;
+        const int c = hyp_count[it];
+        if (c > s.best) {
+            s.best = c;
+            s.bi = it;
+            const double w = (double)c / (double)nb;
+            const double denom = log(fmax(1e-300, 1.0 - w * w * w));
+            s.k_needed = denom < 0 ? log(1.0 - d.p.ransac_plane_probability) / denom : 0.0;
+        }
+    }
+}
+
+// One wave per frame, after k_ransac<true>: the pick over hypotheses 0..63 and whether the loop would go on.
+__global__ __launch_bounds__(64) void k_pick(DepthView d) {
+    const int f = blockIdx.x;
+    if (!((d.ground_mask >> f) & 1u)) return;
+    __shared__ int cnts[kHypPerBlock];
+    const int* hyp_count = d.zone + (size_t)f * d.zone_stride + d.off_hyp;
+    cnts[threadIdx.x] = hyp_count[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double* plane = d.plane + 8 * (size_t)f;
+    const int nb = d.band_n[f], n_hyp = d.n_hyp, it1 = min(n_hyp, kHypPerBlock);
+    PickState s = {0, -1, (double)n_hyp};
+    if (nb >= 3) pick_range(d, cnts, nb, 0, it1, s);
+    plane[5] = s.best;
+    plane[6] = (nb >= 3 && it1 < n_hyp && s.k_needed > (double)it1) ? 1.0 : 0.0;  // the sequential loop would go on
+    plane[7] = s.k_needed;
+    d.pick[2 * f] = s.bi;
+    d.pick[2 * f + 1] = s.best;
+}
+
+// The RANSAC plane of a frame once all counts exist (any lane may call it; every caller gets the same bits): the pick of
+// k_pick, continued over the remaining hypotheses if that pick asked for them.
+__device__ bool ransac_plane(const DepthView& d, int f, double* pl, int* inliers) {
+    const double* plane = d.plane + 8 * (size_t)f;
+    const int nb = d.band_n[f];
+    PickState s = {d.pick[2 * f + 1], d.pick[2 * f], plane[7]};
+    if (plane[6] != 0.0) pick_range(d, d.zone + (size_t)f * d.zone_stride + d.off_hyp, nb, kHypPerBlock, d.n_hyp, s);
+    *inliers = s.best;
+    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
+    if (s.best < 3 || s.bi < 0) return false;
+    return hyp_plane(d, f, nb, s.bi, pl);
+}
+
+// Refinement of the RANSAC plane over the band returns within refinement_treshold of it (yaml:138-140): centroid and
+// scatter matrix from the moments of e = p - a around the point a = -d n of the RANSAC plane, accumulated in fixed point
+// (round-to-nearest-even of e * 2^30 and of (e_i * e_j) * 2^20 into int64; integer sums are exact and order-free).
+__device__ __forceinline__ long long fx(double v, double scale) { return __double2ll_rn(v * scale); }
+
+__global__ __launch_bounds__(256) void k_refine(DepthView d) {
+    const int f = blockIdx.y;
+    if (!((d.ground_mask >> f) & 1u) || !d.p.ransac_plane_use_refinement) return;
+    const int n_pts = d.n_pts[f];
+    const int q0 = blockIdx.x * kChunk;
+    if (q0 >= n_pts) return;
+    __shared__ double s_pl[4];
+    __shared__ int s_ok;
+    __shared__ long long s_part[4][kMomVals];
+    float4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = q0 + 4 * (int)threadIdx.x + k;
+        r[k] = {0.f, 0.f, 0.f, 0.f};
+        if (q < n_pts) r[k] = load_return(d.cloud[f], q);
+    }
+    if (threadIdx.x == 0) {
+        double pl[4];
+        int inl;
+        s_ok = ransac_plane(d, f, pl, &inl);
+        for (int k = 0; k < 4; ++k) s_pl[k] = pl[k];
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const double pl[4] = {s_pl[0], s_pl[1], s_pl[2], s_pl[3]};
+    const double a[3] = {-pl[3] * pl[0], -pl[3] * pl[1], -pl[3] * pl[2]};
+    long long acc[kMomVals] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = q0 + 4 * (int)threadIdx.x + k;
+        if (q >= n_pts || !in_band(d, r[k])) continue;
+        const Cam c = cam_point(d, r[k]);
+        if (!(fabs(pl[0] * c.x + pl[1] * c.y + pl[2] * c.z + pl[3]) < d.p.ransac_plane_refinement_treshold)) continue;
+        const double e[3] = {c.x - a[0], c.y - a[1], c.z - a[2]};
+        if (!(fabs(e[0]) < kMomRange && fabs(e[1]) < kMomRange && fabs(e[2]) < kMomRange)) continue;
+        acc[0] += 1;
+        acc[1] += fx(e[0], kMomScale1);
+        acc[2] += fx(e[1], kMomScale1);
+        acc[3] += fx(e[2], kMomScale1);
+        acc[4] += fx(e[0] * e[0], kMomScale2);
+        acc[5] += fx(e[0] * e[1], kMomScale2);
+        acc[6] += fx(e[0] * e[2], kMomScale2);
+        acc[7] += fx(e[1] * e[1], kMomScale2);
+        acc[8] += fx(e[1] * e[2], kMomScale2);
+        acc[9] += fx(e[2] * e[2], kMomScale2);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kMomVals; ++k) {
+        long long v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) s_part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMomVals) {
+        const long long v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+        unsigned long long* mom = reinterpret_cast<unsigned long long*>(d.zone + (size_t)f * d.zone_stride + d.off_mom);
+        if (v) atomicAdd(&mom[threadIdx.x], (unsigned long long)v);
+    }
+}
+
+// One Jacobi rotation of the symmetric 3x3 matrix in the (I,J) plane, eigenvectors in V; indices are compile-time
+// constants so that everything stays in registers.
 template <int I, int J>
 __device__ __forceinline__ void jacobi_rot(double (&a)[3][3], double (&V)[3][3]) {
     if (a[I][J] == 0.0) return;
@@ -390,81 +480,28 @@ __device__ void smallest_eigvec(const double* C6, double* n) {  // C6 = xx xy xz
     n[2] = v2 / nn;
 }
 
-// least-squares refinement of the RANSAC plane over the band returns within refinement_treshold of it: centroid c and
-// scatter matrix S = sum (p-c)(p-c)^T, then the smallest eigenvector of S.  One pass: moments m0 = n, m1 = sum e,
-// m2 = sum e e^T of e = p - a around a point a ON the RANSAC plane (a = -d n; the returns lie around it, so nothing
-// cancels), then c = a + m1/m0 and S = m2 - m0 (m1/m0)(m1/m0)^T.  Two levels in a FIXED order (deterministic): a
-// workgroup reduces a chunk of kRefineChunk returns (4 consecutive ones per lane, then a tree); the last workgroup of the
-// frame adds the chunk sums in a fixed partition + tree and finishes the plane (d >= 0).
-constexpr int kRefVals = 10;
-__global__ __launch_bounds__(256) void k_refine(DepthView d) {
-    const int f = blockIdx.y;
-    if (!((d.ground_mask >> f) & 1u)) return;
+// One wave per frame, after k_refine: the ground plane of the frame (n, d with n.p + d = 0, d >= 0: the camera is on the
+// positive side).
+__global__ __launch_bounds__(64) void k_plane(DepthView d) {
+    const int f = blockIdx.x;
+    if (!((d.ground_mask >> f) & 1u) || threadIdx.x != 0) return;
     double* plane = d.plane + 8 * (size_t)f;
-    if (plane[4] == 0.0) return;  // no plane: the same for every workgroup of the frame
-    const double pl[4] = {plane[0], plane[1], plane[2], plane[3]};
-    if (!d.p.ransac_plane_use_refinement) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && pl[3] < 0)
-            for (int k = 0; k < 4; ++k) plane[k] = -pl[k];
-        return;
-    }
-    __shared__ double sh[256];
-    int* zone = d.zone + (size_t)f * d.zone_stride;
-    const size_t fo = (size_t)f * d.pt_stride;
-    const int nb = d.band_n[f];
-    const int q0 = blockIdx.x * kRefineChunk;
-    double* part = d.ref_part + (size_t)f * d.ref_stride;
-    const int n_chunk = max(1, (nb + kRefineChunk - 1) / kRefineChunk);  // the grid is sized for the whole sweep
-    if ((int)blockIdx.x >= n_chunk) return;
-    const double a[3] = {-pl[3] * pl[0], -pl[3] * pl[1], -pl[3] * pl[2]};
-    if (q0 < nb) {
-        double acc[kRefVals] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < 4; ++k) {
-            const int q = q0 + 4 * threadIdx.x + k;
-            if (q >= nb) break;
-            const double p[3] = {d.bx[fo + q], d.by[fo + q], d.bz[fo + q]};
-            if (!(fabs(pl[0] * p[0] + pl[1] * p[1] + pl[2] * p[2] + pl[3]) < d.p.ransac_plane_refinement_treshold)) continue;
-            const double e[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
-            acc[0] += 1.0;
-            acc[1] += e[0];
-            acc[2] += e[1];
-            acc[3] += e[2];
-            acc[4] += e[0] * e[0];
-            acc[5] += e[0] * e[1];
-            acc[6] += e[0] * e[2];
-            acc[7] += e[1] * e[1];
-            acc[8] += e[1] * e[2];
-            acc[9] += e[2] * e[2];
-        }
-        for (int k = 0; k < kRefVals; ++k) {
-            sh[threadIdx.x] = acc[k];
-            __syncthreads();
-            for (int st = 128; st > 0; st >>= 1) {
-                if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) st_agent_f64(&part[(size_t)blockIdx.x * kRefVals + k], sh[0]);
-            __syncthreads();
-        }
-    }
-    if (!last_block_done(&zone[d.off_ctr + CTR_REFINE], n_chunk)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int v = wave; v < kRefVals; v += 4) {  // one wave per value
-        double s = 0.0;
-        for (int b = lane; b < n_chunk; b += 64) s += ld_agent_f64(&part[(size_t)b * kRefVals + v]);  // fixed partition ...
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);                        // ... fixed tree
-        if (lane == 0) sh[v] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    double pl[4];
+    int inliers;
+    const bool ok = ransac_plane(d, f, pl, &inliers);
     double n[3] = {pl[0], pl[1], pl[2]}, dd = pl[3];
-    const double m0 = sh[0];
-    if (m0 >= 3.0) {
-        const double c[3] = {sh[1] / m0, sh[2] / m0, sh[3] / m0};  // centroid - a
-        const double S[6] = {sh[4] - m0 * c[0] * c[0], sh[5] - m0 * c[0] * c[1], sh[6] - m0 * c[0] * c[2],
-                             sh[7] - m0 * c[1] * c[1], sh[8] - m0 * c[1] * c[2], sh[9] - m0 * c[2] * c[2]};
-        smallest_eigvec(S, n);
-        dd = -(n[0] * (a[0] + c[0]) + n[1] * (a[1] + c[1]) + n[2] * (a[2] + c[2]));
+    if (ok && d.p.ransac_plane_use_refinement) {
+        const long long* mom = reinterpret_cast<const long long*>(d.zone + (size_t)f * d.zone_stride + d.off_mom);
+        const double m0 = (double)mom[0];
+        if (m0 >= 3.0) {
+            const double a[3] = {-pl[3] * pl[0], -pl[3] * pl[1], -pl[3] * pl[2]};
+            const double c[3] = {((double)mom[1] / kMomScale1) / m0, ((double)mom[2] / kMomScale1) / m0, ((double)mom[3] / kMomScale1) / m0};  // centroid - a
+            const double S[6] = {(double)mom[4] / kMomScale2 - m0 * c[0] * c[0], (double)mom[5] / kMomScale2 - m0 * c[0] * c[1],
+                                 (double)mom[6] / kMomScale2 - m0 * c[0] * c[2], (double)mom[7] / kMomScale2 - m0 * c[1] * c[1],
+                                 (double)mom[8] / kMomScale2 - m0 * c[1] * c[2], (double)mom[9] / kMomScale2 - m0 * c[2] * c[2]};
+            smallest_eigvec(S, n);
+            dd = -(n[0] * (a[0] + c[0]) + n[1] * (a[1] + c[1]) + n[2] * (a[2] + c[2]));
+        }
     }
     if (dd < 0) {
         n[0] = -n[0];
@@ -476,8 +513,8 @@ __global__ __launch_bounds__(256) void k_refine(DepthView d) {
     plane[1] = n[1];
     plane[2] = n[2];
     plane[3] = dd;
-    double* red = d.red + 16 * (size_t)f;
-    for (int k = 0; k < kRefVals; ++k) red[k] = sh[k];
+    plane[4] = ok ? 1.0 : 0.0;
+    plane[5] = inliers;
 }
 
 // ------------------------------------------------------------------------------------------ D2–D5, D6b
@@ -500,11 +537,13 @@ __device__ __forceinline__ double sin_at(const double* o, const double* a, const
 }
 
 struct WaveLds {
-    int nb_idx[kMaxNb];     // neighbour return indices (sorted)
-    int tmp_idx[kMaxNb];
+    int cell_off[65];       // exclusive prefix of the candidate counts of the cells under the rectangle
+    int tmp_idx[kMaxNb];    // neighbours in arrival order
+    double tmp_xyz[kMaxNb][3];
+    int nb_idx[kMaxNb];     // neighbours ordered by return index
+    double nb_xyz[kMaxNb][3];
     double seg[kMaxNb][3];  // points of the selected histogram bin / ground patch
     int bins[kMaxBins];
-    int n_nb, n_seg;
 };
 
 __global__ __launch_bounds__(256) void k_features(DepthView d) {
@@ -514,34 +553,80 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
     const int k = blockIdx.x * 4 + wave;
     if (k >= d.n_feat[fr]) return;  // whole wave exits together
     WaveLds& L = lds[wave];
-    const FrameView F = frame_view(d, fr);
+    const int* cell_count = d.zone + (size_t)fr * d.zone_stride;
+    const int* cell_pts = d.cell_pts + (size_t)fr * d.n_cells * kCellCap;
+    const double* plane = d.plane + 8 * (size_t)fr;
+    const float* cloud = d.cloud[fr];
     const float* feat_uv = d.feat_uv[fr];
     const uint8_t* feat_ground = d.feat_ground[fr];
     const double fu = feat_uv[2 * (size_t)k], fv = feat_uv[2 * (size_t)k + 1];
     const double hw = 0.5 * d.p.pixelarea_search_width, hh = 0.5 * d.p.pixelarea_search_height;
     const double cu = fu + d.p.pixelarea_search_offset_x, cv = fv + d.p.pixelarea_search_offset_y;
-    // ---- D2: candidates from the cells under the rectangle, ballot compaction
+    // ---- D2: candidates = the returns listed in the cells under the rectangle.  All cells in one pass: lane c takes the
+    //      count of cell c, a wave prefix sum gives every candidate a lane (three dependent loads per pass - count, index,
+    //      record - instead of three per cell); the rectangle test uses the pixel recomputed from the record.
     const int cx0 = max(0, (int)floor((cu - hw) / kCell)), cx1 = min(d.cells_x - 1, (int)floor((cu + hw) / kCell));
     const int cy0 = max(0, (int)floor((cv - hh) / kCell)), cy1 = min(d.cells_y - 1, (int)floor((cv + hh) / kCell));
+    const int ncx = max(0, cx1 - cx0 + 1), ncell = ncx * max(0, cy1 - cy0 + 1);
     int n = 0;
-    for (int cy = cy0; cy <= cy1; ++cy)
-        for (int cx = cx0; cx <= cx1; ++cx) {
-            const int cell = cy * d.cells_x + cx;
-            const int cnt = min(kCellCap, F.cell_count[cell]);
+    unsigned ovf = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        int cell = 0, cnt = 0;
+        if (c < ncell) {
+            cell = (cy0 + c / ncx) * d.cells_x + cx0 + c % ncx;
+            cnt = cell_count[cell];
+            if (cnt > kCellCap) {
+                ovf |= OVF_CELL;
+                cnt = kCellCap;
+            }
+        }
+        int incl = cnt;  // inclusive prefix sum over the lanes
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        L.cell_off[lane] = incl - cnt;
+        if (lane == 63) L.cell_off[64] = total;
+        __builtin_amdgcn_wave_barrier();
+        for (int j0 = 0; j0 < total; j0 += 64) {
+            const int j = j0 + lane;
             bool in = false;
             int idx = -1;
-            if (lane < cnt) {
-                idx = F.cell_pts[cell * kCellCap + lane];
-                in = fabs(F.pu[idx] - cu) <= hw && fabs(F.pv[idx] - cv) <= hh;
+            Cam P = {0.0, 0.0, 0.0};
+            if (j < total) {
+                int lo = 0, hi = 63;  // the cell of candidate j: last lane whose offset is <= j
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (L.cell_off[mid] <= j) lo = mid; else hi = mid - 1;
+                }
+                const int cc = c0 + lo;
+                const int cl = (cy0 + cc / ncx) * d.cells_x + cx0 + cc % ncx;
+                idx = cell_pts[(size_t)cl * kCellCap + (j - L.cell_off[lo])];
+                P = cam_point(d, load_return(cloud, idx));
+                double u, v;
+                in = pixel_of(d, P, &u, &v) && fabs(u - cu) <= hw && fabs(v - cv) <= hh;
             }
             const unsigned long long m = __ballot(in);
             if (in) {
                 const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < kMaxNb) L.tmp_idx[pos] = idx;
+                if (pos < kMaxNb) {
+                    L.tmp_idx[pos] = idx;
+                    L.tmp_xyz[pos][0] = P.x;
+                    L.tmp_xyz[pos][1] = P.y;
+                    L.tmp_xyz[pos][2] = P.z;
+                }
             }
             n += __popcll(m);
         }
-    n = min(n, kMaxNb);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (n > kMaxNb) {
+        ovf |= OVF_NEIGHBOURS;
+        n = kMaxNb;
+    }
+    if (ovf) *reinterpret_cast<volatile int*>(d.overflow) = (int)ovf;  // pinned host word; the call then fails with LIMO_ERR_INVALID
     // order by return index (rank sort inside the wave) so every later step sees the lidar order the oracle sees
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {
@@ -549,32 +634,35 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
         int rank = 0;
         for (int q = 0; q < n; ++q) rank += L.tmp_idx[q] < mine;
         L.nb_idx[rank] = mine;
+        L.nb_xyz[rank][0] = L.tmp_xyz[lane][0];
+        L.nb_xyz[rank][1] = L.tmp_xyz[lane][1];
+        L.nb_xyz[rank][2] = L.tmp_xyz[lane][2];
     }
     __builtin_amdgcn_wave_barrier();
     float result = -1.0f;
     if (n >= d.p.neighbors_count_min) {
-        const bool ground_feat = feat_ground && feat_ground[k] && F.plane[4] != 0.0;
+        const bool ground_feat = feat_ground && feat_ground[k] && plane[4] != 0.0;
         double depth = -1.0, zlo = 0.0, zhi = 0.0;
         bool have = false;
         if (ground_feat) {
             // ---- D6b: inverse-distance weighted patch over the neighbours close to the sweep's ground plane (lane 0,
-            //      sequential in return order: identical summation order to the oracle)
+            //      sequential in return order: the oracle's summation order)
             if (lane == 0) {
-                const double gn[3] = {F.plane[0], F.plane[1], F.plane[2]}, gd = F.plane[3];
+                const double gn[3] = {plane[0], plane[1], plane[2]}, gd = plane[3];
                 double sw = 0, c[3] = {0, 0, 0};
                 int m = 0;
                 zlo = 1.79769313486231570e308;
                 zhi = -zlo;
+                double* wgt = reinterpret_cast<double*>(L.bins);  // weights parked in the (unused) histogram storage
                 for (int q = 0; q < n; ++q) {
-                    const int i = L.nb_idx[q];
-                    const double p[3] = {F.px[i], F.py[i], F.pz[i]};
+                    const double p[3] = {L.nb_xyz[q][0], L.nb_xyz[q][1], L.nb_xyz[q][2]};
                     const double dist = gn[0] * p[0] + gn[1] * p[1] + gn[2] * p[2] + gd;
                     if (fabs(dist) < d.p.ransac_plane_point_distance_treshold) {
                         const double w = d.p.plane_estimator_use_mestimator ? 1.0 / (fabs(dist) + 0.01) : 1.0;
                         L.seg[m][0] = p[0];
                         L.seg[m][1] = p[1];
                         L.seg[m][2] = p[2];
-                        reinterpret_cast<double*>(L.bins)[m] = w;  // weights parked in the (unused) histogram storage
+                        wgt[m] = w;
                         sw += w;
                         for (int a = 0; a < 3; ++a) c[a] += w * p[a];
                         zlo = fmin(zlo, p[2]);
@@ -588,7 +676,7 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
                     for (int a = 0; a < 3; ++a) c[a] /= sw;
                     double C6[6] = {0, 0, 0, 0, 0, 0};
                     for (int q = 0; q < m; ++q) {
-                        const double w = reinterpret_cast<double*>(L.bins)[q];
+                        const double w = wgt[q];
                         const double e[3] = {L.seg[q][0] - c[0], L.seg[q][1] - c[1], L.seg[q][2] - c[2]};
                         C6[0] += w * e[0] * e[0];
                         C6[1] += w * e[0] * e[1];
@@ -618,7 +706,7 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
             double zmin = 1.79769313486231570e308, zmax = -1.79769313486231570e308;
             double myz = 0.0;
             if (lane < n) {
-                myz = F.pz[L.nb_idx[lane]];
+                myz = L.nb_xyz[lane][2];
                 zmin = zmax = myz;
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -629,10 +717,11 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
             bool seg_ok = true;
             if (d.p.do_use_histogram_segmentation) {
                 const double bw = d.p.histogram_segmentation_bin_width;
-                const int nbins = (int)floor((zmax - zmin) / bw) + 1;
-                if (nbins > kMaxBins) {
+                const double span = floor((zmax - zmin) / bw);
+                if (!(span < (double)kMaxBins)) {
                     seg_ok = false;  // depth span beyond 150 m inside one 6x9 px window: treat as unsegmentable
                 } else {
+                    const int nbins = (int)span + 1;
                     for (int b = lane; b < nbins; b += 64) L.bins[b] = 0;
                     __builtin_amdgcn_wave_barrier();
                     int mybin = -1;
@@ -654,20 +743,18 @@ __global__ __launch_bounds__(256) void k_features(DepthView d) {
                         const unsigned long long m = __ballot(mine);
                         if (mine) {
                             const int pos = __popcll(m & ((1ull << lane) - 1ull));
-                            const int i = L.nb_idx[lane];
-                            L.seg[pos][0] = F.px[i];
-                            L.seg[pos][1] = F.py[i];
-                            L.seg[pos][2] = F.pz[i];
+                            L.seg[pos][0] = L.nb_xyz[lane][0];
+                            L.seg[pos][1] = L.nb_xyz[lane][1];
+                            L.seg[pos][2] = L.nb_xyz[lane][2];
                         }
                         nseg = __popcll(m);
                     }
                 }
             } else {
                 if (lane < n) {
-                    const int i = L.nb_idx[lane];
-                    L.seg[lane][0] = F.px[i];
-                    L.seg[lane][1] = F.py[i];
-                    L.seg[lane][2] = F.pz[i];
+                    L.seg[lane][0] = L.nb_xyz[lane][0];
+                    L.seg[lane][1] = L.nb_xyz[lane][1];
+                    L.seg[lane][2] = L.nb_xyz[lane][2];
                 }
                 nseg = n;
             }
@@ -755,24 +842,26 @@ struct DepthWs {
     size_t cap_pts = 0, cap_feat = 0, cap_cells = 0;
     int cap_frames = 0;
     size_t zone_stride = 0;          // ints per frame
-    int off_hyp = 0, off_ctr = 0, off_scan = 0;
+    int off_hyp = 0, off_ctr = 0, off_mom = 0, off_scan = 0;
     int zone_used[2] = {0, 0};       // frames of each zone a call has written into since it was last cleared
     int cur = 0;                     // zone of the next call
+    int last_frames = 0;             // frames of the last launch group (limo_depth_last_ground_plane)
+    uint32_t last_ground_mask = 0;
     float* cloud = nullptr;
-    double *pu = nullptr, *pv = nullptr, *px = nullptr, *py = nullptr, *pz = nullptr;
-    int *cell_pts = nullptr, *band_idx = nullptr, *band_n = nullptr, *zone[2] = {nullptr, nullptr};
-    double *plane = nullptr, *red = nullptr, *bx = nullptr, *by = nullptr, *bz = nullptr, *ref_part = nullptr;
+    int *cell_pts = nullptr, *band_idx = nullptr, *band_n = nullptr, *pick = nullptr, *zone[2] = {nullptr, nullptr};
+    double* plane = nullptr;
     float *feat_uv = nullptr, *out = nullptr;
     uint8_t* feat_ground = nullptr;
     float* h_feat = nullptr;   // pinned staging: uv of every frame, then the ground labels; and the depths coming back
     float* h_out = nullptr;
+    int* h_ovf = nullptr;      // pinned word the kernels raise when a capacity of this file is exceeded
     void release() {
-        void* ptrs[] = {cloud, pu, pv, px, py, pz, cell_pts, band_idx, band_n, zone[0], zone[1], plane, red, bx, by, bz, ref_part,
-                        feat_uv, out, feat_ground};
+        void* ptrs[] = {cloud, cell_pts, band_idx, band_n, pick, zone[0], zone[1], plane, feat_uv, out, feat_ground};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (h_feat) (void)hipHostFree(h_feat);
         if (h_out) (void)hipHostFree(h_out);
+        if (h_ovf) (void)hipHostFree(h_ovf);
         *this = DepthWs();
     }
 };
@@ -812,27 +901,19 @@ int ensure_capacity(limo_ctx* ctx, DepthWs& W, int frames, size_t n_pts, size_t 
     const size_t nblk = P / 256;
     int rc = LIMO_OK;
     rc |= grow(ctx, &W.cloud, (size_t)F * P * 4);
-    rc |= grow(ctx, &W.pu, (size_t)F * P);
-    rc |= grow(ctx, &W.pv, (size_t)F * P);
-    rc |= grow(ctx, &W.px, (size_t)F * P);
-    rc |= grow(ctx, &W.py, (size_t)F * P);
-    rc |= grow(ctx, &W.pz, (size_t)F * P);
     rc |= grow(ctx, &W.band_idx, (size_t)F * P);
-    rc |= grow(ctx, &W.bx, (size_t)F * P);
-    rc |= grow(ctx, &W.by, (size_t)F * P);
-    rc |= grow(ctx, &W.bz, (size_t)F * P);
-    rc |= grow(ctx, &W.ref_part, (size_t)F * (P / kRefineChunk + 1) * kRefVals);
     rc |= grow(ctx, &W.cell_pts, (size_t)F * C * kCellCap);
     rc |= grow(ctx, &W.band_n, (size_t)F);
+    rc |= grow(ctx, &W.pick, (size_t)F * 2);
     rc |= grow(ctx, &W.plane, (size_t)F * 8);
-    rc |= grow(ctx, &W.red, (size_t)F * 16);
     rc |= grow(ctx, &W.feat_uv, (size_t)F * Q * 2);
     rc |= grow(ctx, &W.feat_ground, (size_t)F * Q);
     rc |= grow(ctx, &W.out, (size_t)F * Q);
-    // zone of a frame: cell counters | inlier counts | counters | scan words (64-bit, 8-byte aligned)
+    // zone of a frame: cell counters | inlier counts | counters | moments (64-bit) | scan words (64-bit, 8-byte aligned)
     W.off_hyp = (int)round_up(C, 2);
     W.off_ctr = W.off_hyp + kMaxHyp;
-    W.off_scan = W.off_ctr + CTR_COUNT;
+    W.off_mom = W.off_ctr + CTR_COUNT;
+    W.off_scan = W.off_mom + 2 * kMomVals;
     W.zone_stride = round_up((size_t)W.off_scan + 2 * nblk, 2);
     for (int z = 0; z < 2; ++z) {
         rc |= grow(ctx, &W.zone[z], (size_t)F * W.zone_stride);
@@ -845,6 +926,7 @@ int ensure_capacity(limo_ctx* ctx, DepthWs& W, int frames, size_t n_pts, size_t 
     if (rc == LIMO_OK) {
         HIP_TRY(ctx, hipHostMalloc((void**)&W.h_feat, (size_t)F * Q * (2 * sizeof(float) + 1)));
         HIP_TRY(ctx, hipHostMalloc((void**)&W.h_out, (size_t)F * Q * sizeof(float)));
+        if (!W.h_ovf) HIP_TRY(ctx, hipHostMalloc((void**)&W.h_ovf, sizeof(int)));
     }
     if (rc != LIMO_OK) {
         W.cap_frames = 0;
@@ -856,6 +938,20 @@ int ensure_capacity(limo_ctx* ctx, DepthWs& W, int frames, size_t n_pts, size_t 
     W.cap_feat = Q;
     W.cap_cells = C;
     return LIMO_OK;
+}
+
+// camera <- lidar rotation from the quaternion (w,x,y,z): the statements of the oracle's quat_to_R (contraction off)
+void quat_to_R(const double* q, double* R) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z);
+    R[1] = 2 * (x * y - w * z);
+    R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);
+    R[4] = 1 - 2 * (x * x + z * z);
+    R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);
+    R[7] = 2 * (y * z + w * x);
+    R[8] = 1 - 2 * (x * x + y * y);
 }
 
 // One launch group: 1..kMaxBatch frames.
@@ -874,12 +970,15 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
         max_pts = std::max(max_pts, frames[k].n_pts);
         max_feat = std::max(max_feat, frames[k].n_feat);
     }
-    if (max_pts > 0x7fffff00u || max_feat > 0x7fffff00u) return LIMO_ERR_INVALID;
+    if (max_pts > (1u << 22) || max_feat > 0x7fffff00u) {  // 2^22 returns: the fixed-point moments cannot overflow
+        ctx->err = "limo_depth_estimate: more than 2^22 returns in one sweep";
+        return LIMO_ERR_INVALID;
+    }
     if (int rc = ensure_capacity(ctx, W, n_frames, max_pts, max_feat, cells)) return rc;
 
     DepthView d;
     std::memset(&d, 0, sizeof(d));
-    kba::quat_R(T_cam_lidar, d.R);
+    quat_to_R(T_cam_lidar, d.R);
     for (int i = 0; i < 3; ++i) d.t[i] = T_cam_lidar[4 + i];
     d.f = f;
     d.cx = cx;
@@ -893,21 +992,12 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
     d.n_hyp = std::max(1, p.ransac_plane_max_iterations);
     d.p = p;
     d.pt_stride = W.cap_pts;
-    d.pu = W.pu;
-    d.pv = W.pv;
-    d.px = W.px;
-    d.py = W.py;
-    d.pz = W.pz;
     d.cell_pts = W.cell_pts;
     d.band_idx = W.band_idx;
-    d.bx = W.bx;
-    d.by = W.by;
-    d.bz = W.bz;
-    d.ref_part = W.ref_part;
-    d.ref_stride = (W.cap_pts / kRefineChunk + 1) * kRefVals;
     d.band_n = W.band_n;
     d.plane = W.plane;
-    d.red = W.red;
+    d.pick = W.pick;
+    d.overflow = W.h_ovf;
     const int z = W.cur;
     d.zone = W.zone[z];
     d.zone_next = W.zone[z ^ 1];
@@ -915,7 +1005,9 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
     d.zone_next_clear = (size_t)W.zone_used[z ^ 1] * W.zone_stride;
     d.off_hyp = W.off_hyp;
     d.off_ctr = W.off_ctr;
+    d.off_mom = W.off_mom;
     d.off_scan = W.off_scan;
+    *W.h_ovf = 0;
 
     const size_t Q = W.cap_feat;
     float* h_uv = W.h_feat;
@@ -954,16 +1046,19 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
     W.zone_used[z] = std::max(W.zone_used[z], n_frames);
     W.zone_used[z ^ 1] = 0;  // cleared by this call's k_project (or already clean)
     W.cur = z ^ 1;
+    W.last_frames = n_frames;
+    W.last_ground_mask = d.ground_mask;
     const unsigned F = (unsigned)n_frames;
     // the projection kernel also clears the other zone: it runs even for a call without returns
     hipLaunchKernelGGL(k_project, dim3((unsigned)std::max<size_t>(1, (max_pts + 255) / 256), F), dim3(256), 0, s, d);
     if (d.ground_mask) {
-        const unsigned n_chunk_r = (unsigned)((max_pts + kRansacChunk - 1) / kRansacChunk), n_chunk_f = (unsigned)((max_pts + kRefineChunk - 1) / kRefineChunk);
-        // upper bounds: the band sizes are only known on the device
+        const unsigned n_chunk = (unsigned)((max_pts + kChunk - 1) / kChunk);
         const unsigned n_groups = (unsigned)((d.n_hyp + kHypPerBlock - 1) / kHypPerBlock);
-        hipLaunchKernelGGL(k_ransac<true>, dim3(1, n_chunk_r, F), dim3(256), 0, s, d);
-        if (n_groups > 1) hipLaunchKernelGGL(k_ransac<false>, dim3(n_groups - 1, n_chunk_r, F), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k_refine, dim3(n_chunk_f, F), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_ransac<true>, dim3(1, n_chunk, F), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_pick, dim3(F), dim3(64), 0, s, d);
+        if (n_groups > 1) hipLaunchKernelGGL(k_ransac<false>, dim3(n_groups - 1, n_chunk, F), dim3(256), 0, s, d);
+        if (p.ransac_plane_use_refinement) hipLaunchKernelGGL(k_refine, dim3(n_chunk, F), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_plane, dim3(F), dim3(64), 0, s, d);
     }
     if (max_feat) {
         hipLaunchKernelGGL(k_features, dim3((unsigned)((max_feat + 3) / 4), F), dim3(256), 0, s, d);
@@ -971,6 +1066,11 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (*W.h_ovf) {
+        ctx->err = std::string("limo_depth_estimate: ") + ((*W.h_ovf & OVF_CELL) ? "more than 48 returns project into one 8x8 px image cell" : "more than 64 returns inside one search rectangle") +
+                   " (not a single sweep of a spinning scanner?)";
+        return LIMO_ERR_INVALID;
+    }
     if (!device_ptrs)
         for (int k = 0; k < n_frames; ++k)
             if (frames[k].n_feat) std::memcpy(frames[k].depth_out, W.h_out + (size_t)k * Q, sizeof(float) * frames[k].n_feat);
@@ -1033,6 +1133,22 @@ int limo_depth_estimate_batch(limo_ctx* ctx, int32_t n_frames, const limo_depth_
         if (int rc = run_group(ctx, std::min(kMaxBatch, n_frames - k0), frames + k0, T_cam_lidar, f, cx, cy, img_w, img_h, p,
                                (flags & LIMO_DEPTH_DEVICE_POINTERS) != 0))
             return rc;
+    return LIMO_OK;
+}
+
+int limo_depth_last_ground_plane(limo_ctx* ctx, int32_t frame, double* plane4, int32_t* inliers) {
+    if (!ctx || !plane4 || !ctx->depth_ws) return LIMO_ERR_INVALID;
+    DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    if (frame < 0 || frame >= W.last_frames) return LIMO_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    double pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((W.last_ground_mask >> frame) & 1u) {
+        HIP_TRY(ctx, hipMemcpyAsync(pl, W.plane + 8 * (size_t)frame, sizeof(pl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const bool ok = pl[4] != 0.0;
+    for (int k = 0; k < 4; ++k) plane4[k] = ok ? pl[k] : 0.0;
+    if (inliers) *inliers = ok ? (int32_t)pl[5] : 0;
     return LIMO_OK;
 }
 

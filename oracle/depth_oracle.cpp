@@ -10,7 +10,16 @@
 // float metres along camera z, -1 = none) and the method description of the LIMO paper cited at README.md:45
 // ("nearest significant histogram bin", "plane through the three points spanning the largest triangle").
 // Where the parameter file leaves a choice open, the choice made here is spelled out next to the code; the HIP
-// implementation (limo_amd/csrc/depth.hip) makes the same choices and is tested against this file.
+// implementation (limo_amd/csrc/depth.hip) makes the same choices and is tested against this file BIT FOR BIT
+// (accept / reject decisions and depths).  What makes that possible is part of this file's contract:
+//   * it is compiled with -ffp-contract=off (oracle/Makefile): every + - * / sqrt below is one IEEE-754 operation in
+//     the order written;
+//   * the one long floating-point sum of the path, the moments of the ground-plane refinement, is specified in FIXED
+//     POINT (int64; units 2^-30 m for first, 2^-20 m^2 for second moments, round-to-nearest-even per term): integer
+//     sums do not depend on the order of summation, so a parallel implementation can form the same numbers.  The
+//     rounding per term (<= 2^-21 m^2) is 10 orders of magnitude below the scatter of a ground band.
+// An implementation written independently of this file (tests/depth_bruteforce.py: numpy, from the parameter file only)
+// cross-checks the choices on analytic and synthetic scenes.
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -56,12 +65,13 @@ inline uint64_t splitmix64(uint64_t x) {
 }
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 matrix (cyclic Jacobi)
-void smallest_eigvec(const double C[9], double* n) {
-    double a[3][3] = {{C[0], C[1], C[2]}, {C[3], C[4], C[5]}, {C[6], C[7], C[8]}};
+void smallest_eigvec(const double C[6], double* n) {  // C = xx xy xz yy yz zz (upper triangle, mirrored)
+    double a[3][3] = {{C[0], C[1], C[2]}, {C[1], C[3], C[4]}, {C[2], C[4], C[5]}};
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 50; ++sweep) {
         const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off < 1e-300) break;
+        const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-40 * diag || off < 1e-300) break;  // converged to far below the rounding of the entries
         for (int i = 0; i < 2; ++i)
             for (int j = i + 1; j < 3; ++j) {
                 if (a[i][j] == 0.0) continue;
@@ -103,11 +113,15 @@ Plane4 fit_plane(const std::vector<const double*>& pts, const std::vector<double
         for (int k = 0; k < 3; ++k) c[k] += w[i] * pts[i][k];
     }
     for (int k = 0; k < 3; ++k) c[k] /= sw;
-    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double C[6] = {0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < pts.size(); ++i) {
         const double d[3] = {pts[i][0] - c[0], pts[i][1] - c[1], pts[i][2] - c[2]};
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) C[a * 3 + b] += w[i] * d[a] * d[b];
+        C[0] += w[i] * d[0] * d[0];
+        C[1] += w[i] * d[0] * d[1];
+        C[2] += w[i] * d[0] * d[2];
+        C[3] += w[i] * d[1] * d[1];
+        C[4] += w[i] * d[1] * d[2];
+        C[5] += w[i] * d[2] * d[2];
     }
     smallest_eigvec(C, P.n);
     P.d = -(P.n[0] * c[0] + P.n[1] * c[1] + P.n[2] * c[2]);
@@ -174,7 +188,7 @@ int oracle_ground_plane(const float* cloud, size_t n_pts, const double* T_cam_li
     std::vector<std::array<double, 3>> band;
     for (size_t i = 0; i < n_pts; ++i) {
         const double z = cloud[4 * i + 2];
-        if (z < p->ransac_plane_min_z || z > p->ransac_plane_max_z) continue;
+        if (!(z >= p->ransac_plane_min_z && z <= p->ransac_plane_max_z)) continue;  // NaN returns are dropped
         const double x = cloud[4 * i], y = cloud[4 * i + 1];
         band.push_back({R[0] * x + R[1] * y + R[2] * z + t[0], R[3] * x + R[4] * y + R[5] * z + t[1],
                         R[6] * x + R[7] * y + R[8] * z + t[2]});
@@ -212,17 +226,36 @@ int oracle_ground_plane(const float* cloud, size_t n_pts, const double* T_cam_li
     }
     if (best < 3) return 0;
     if (p->ransac_plane_use_refinement) {
-        std::vector<const double*> pts;
-        std::vector<double> w;
-        for (size_t q = 0; q < nb; ++q)
-            if (std::fabs(bn[0] * band[q][0] + bn[1] * band[q][1] + bn[2] * band[q][2] + bd) < p->ransac_plane_refinement_treshold) {
-                pts.push_back(band[q].data());
-                w.push_back(1.0);
-            }
-        Plane4 P = fit_plane(pts, w);
-        if (P.ok) {
-            for (int k = 0; k < 3; ++k) bn[k] = P.n[k];
-            bd = P.d;
+        // centroid and scatter matrix from the moments of e = p - a around the point a = -d n of the RANSAC plane (the
+        // returns lie around it, so nothing cancels), accumulated in fixed point (see the header): first moments in units
+        // of 2^-30 m, second moments in units of 2^-20 m^2, each term rounded to nearest-even; a return further than
+        // 1024 m from a in any coordinate does not take part.
+        const double kScale1 = 1073741824.0, kScale2 = 1048576.0, kRange = 1024.0;
+        const double a[3] = {-bd * bn[0], -bd * bn[1], -bd * bn[2]};
+        long long mom[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t q = 0; q < nb; ++q) {
+            if (!(std::fabs(bn[0] * band[q][0] + bn[1] * band[q][1] + bn[2] * band[q][2] + bd) < p->ransac_plane_refinement_treshold)) continue;
+            const double e[3] = {band[q][0] - a[0], band[q][1] - a[1], band[q][2] - a[2]};
+            if (!(std::fabs(e[0]) < kRange && std::fabs(e[1]) < kRange && std::fabs(e[2]) < kRange)) continue;
+            mom[0] += 1;
+            mom[1] += std::llrint(e[0] * kScale1);
+            mom[2] += std::llrint(e[1] * kScale1);
+            mom[3] += std::llrint(e[2] * kScale1);
+            mom[4] += std::llrint(e[0] * e[0] * kScale2);
+            mom[5] += std::llrint(e[0] * e[1] * kScale2);
+            mom[6] += std::llrint(e[0] * e[2] * kScale2);
+            mom[7] += std::llrint(e[1] * e[1] * kScale2);
+            mom[8] += std::llrint(e[1] * e[2] * kScale2);
+            mom[9] += std::llrint(e[2] * e[2] * kScale2);
+        }
+        const double m0 = (double)mom[0];
+        if (m0 >= 3.0) {
+            const double c[3] = {((double)mom[1] / kScale1) / m0, ((double)mom[2] / kScale1) / m0, ((double)mom[3] / kScale1) / m0};  // centroid - a
+            const double S[6] = {(double)mom[4] / kScale2 - m0 * c[0] * c[0], (double)mom[5] / kScale2 - m0 * c[0] * c[1],
+                                 (double)mom[6] / kScale2 - m0 * c[0] * c[2], (double)mom[7] / kScale2 - m0 * c[1] * c[1],
+                                 (double)mom[8] / kScale2 - m0 * c[1] * c[2], (double)mom[9] / kScale2 - m0 * c[2] * c[2]};
+            smallest_eigvec(S, bn);
+            bd = -(bn[0] * (a[0] + c[0]) + bn[1] * (a[1] + c[1]) + bn[2] * (a[2] + c[2]));
         }
     }
     if (bd < 0) {  // orient: the camera (origin) is on the positive side

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Per-kernel register / LDS / scratch table of the gfx950 code object (hipcc --save-temps of limo_hip.hip).
-# usage: scripts/isa_resources.sh [extra hipcc flags]   -> prints name vgpr agpr sgpr lds scratch occupancy
+# usage: [ISA_SRC=depth.hip] scripts/isa_resources.sh [extra hipcc flags]   -> prints name vgpr agpr sgpr lds scratch occupancy
 set -e
 D=${ISA_DIR:-/tmp/isa}
 mkdir -p $D && cd $D
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c --save-temps -Wno-unused-function "$@" /root/repo/limo_amd/csrc/limo_hip.hip -o limo_hip.o
+SRC=${ISA_SRC:-limo_hip.hip}
+export ISA_BASE=${SRC%.*}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c --save-temps -Wno-unused-function "$@" /root/repo/limo_amd/csrc/$SRC -o $ISA_BASE.o
 python3 - <<'PY'
-import re,subprocess
-s=open('/tmp/isa/limo_hip-hip-amdgcn-amd-amdhsa-gfx950.s').read() if True else ''
+import os,re,subprocess
+s=open('%s-hip-amdgcn-amd-amdhsa-gfx950.s' % os.environ['ISA_BASE']).read()
 # metadata blocks
 for m in re.finditer(r'\.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.vgpr_count:\s+(\d+)', s, re.S):
     ag,lds,name,scr,sg,vg=m.groups()
