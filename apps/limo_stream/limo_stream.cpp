@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 7;
     std::string poses_path, gt_path, dump_dir, replay_dir;
     bool use_depth = true, quiet = false;
+    double min_flow = -1., time_between_keyframes = -1.;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("--frames")) n_frames = std::atoi(argv[++i]);
@@ -38,6 +39,8 @@ int main(int argc, char** argv) {
         else if (arg("--az")) n_az = std::atoi(argv[++i]);
         else if (arg("--seed")) seed = std::strtoull(argv[++i], nullptr, 10);
         else if (arg("--window")) window = std::atoi(argv[++i]);
+        else if (arg("--min-flow")) min_flow = std::atof(argv[++i]);
+        else if (arg("--time-between-keyframes")) time_between_keyframes = std::atof(argv[++i]);
         else if (arg("--poses")) poses_path = argv[++i];
         else if (arg("--gt-poses")) gt_path = argv[++i];
         else if (arg("--dump-velodyne")) dump_dir = argv[++i];
@@ -45,7 +48,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else {
-            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--quiet]\n");
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--quiet]\n");
             return 2;
         }
     }
@@ -56,6 +59,8 @@ int main(int argc, char** argv) {
     StreamParams sp;
     sp.max_size_optimization_window = window;
     sp.assign_depth = use_depth;
+    if (min_flow >= 0.) sp.min_median_flow = min_flow;
+    if (time_between_keyframes > 0.) sp.time_between_keyframes_sec = time_between_keyframes;
     sp.solver_time_sec = -1.;  // no wall-clock cap: the drive is reproducible
     sp.image_width = (int)world.W;
     sp.image_height = (int)world.H;
@@ -171,7 +176,7 @@ int main(int argc, char** argv) {
     if (te.rel_samples)
         std::printf("limo_stream: relative errors over 100..800 m sub-paths (KITTI devkit measure, %d samples): translation %.3f %%, rotation %.5f deg/m\n",
                     te.rel_samples, 100. * te.rel_trans, te.rel_rot * 180. / M_PI);
-    std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\n", n_frames, n_frames / sec_pipeline, ate, worst,
-                (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves);
+    std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\nsolves_on_non_keyframes %d\n", n_frames, n_frames / sec_pipeline, ate, worst,
+                (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves, st.solves_on_non_keyframes);
     return 0;
 }

@@ -13,6 +13,7 @@
 // The very first frame is a Pose-fixed keyframe at the identity (:305-326).
 // Everything numerical happens behind the C-ABI; this file is host-side control flow only.
 #pragma once
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,9 +42,13 @@ struct StreamParams {
     double solver_time_sec = 20.;               // wall-clock cap of a solve; <= 0: none (deterministic)
     double prior_speed = 11.;                   // m/s along the vehicle's x axis while no motion has been estimated yet (the
                                                 // node scales its five-point direction by interface_.prior_speed, :160-165)
-    // landmark selection (keyframe_ba_monolid.launch:36-38, mono_lidar.cpp:396-430)
+    // landmark selection (keyframe_ba_monolid.launch:36-38; wiring of MonoLidar::reconfigureRequest, mono_lidar.cpp:396-430)
     unsigned max_number_landmarks_near_bin = 200, max_number_landmarks_middle_bin = 200, max_number_landmarks_far_bin = 100;
-    double roi_middle = 15., roi_far = 40.;
+    double roi_middle = 15., roi_far = 40.;                            // :405-408
+    std::array<double, 3> voxel_size_xyz{{0.5, 0.5, 0.3}};             // :404
+    int add_ground_landmarks_per_keyframe = 50;                        // :421-423: for EVERY index of the window the 50
+                                                                       // nearest ground-plane landmarks are kept
+    int add_depth_landmarks_newest = 0;                                // the node has this rule commented out (:412-416)
     // depth assignment
     bool assign_depth = true;
     int image_width = 1241, image_height = 376;
@@ -53,7 +58,7 @@ struct StreamParams {
 class StreamDriver {
 public:
     struct Stats {
-        int frames = 0, keyframes = 0, solves = 0, features = 0, features_with_depth = 0;
+        int frames = 0, keyframes = 0, solves = 0, solves_on_non_keyframes = 0, features = 0, features_with_depth = 0;
         double sec_depth = 0., sec_pose_only = 0., sec_push = 0., sec_solve = 0., sec_total = 0.;
     };
 
@@ -66,14 +71,17 @@ public:
         vp.max_num_landmarks_near = p.max_number_landmarks_near_bin;
         vp.max_num_landmarks_middle = p.max_number_landmarks_middle_bin;
         vp.max_num_landmarks_far = p.max_number_landmarks_far_bin;
+        vp.voxel_size_xyz = p.voxel_size_xyz;
         vp.roi_far_xyz = {{p.roi_far, p.roi_far, p.roi_far}};
         vp.roi_middle_xyz = {{p.roi_middle, p.roi_middle, p.roi_middle}};
         ba_.landmark_selector_->addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
-        LandmarkSelectionSchemeAddDepth::Parameters ap;  // always keep the 20 nearest depth / ground landmarks of the oldest keyframe
-        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
-                                                         [](const Measurement& m, const Vector3d&) { return m.d; }));
-        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
-                                                         [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
+        LandmarkSelectionSchemeAddDepth::Parameters ap;  // "depth assurance" (:409-426)
+        if (p.add_depth_landmarks_newest > 0)
+            ap.params_per_keyframe.push_back(std::make_tuple(0, p.add_depth_landmarks_newest, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
+                                                             [](const Measurement& m, const Vector3d&) { return m.d; }));
+        for (int i = 0; i < p.max_size_optimization_window && p.add_ground_landmarks_per_keyframe > 0; ++i)
+            ap.params_per_keyframe.push_back(std::make_tuple(i, p.add_ground_landmarks_per_keyframe, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
+                                                             [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
         ba_.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
         if (limo_ctx_create(0, &ctx_) != LIMO_OK) throw std::runtime_error("StreamDriver: no HIP device (limo_ctx_create)");
         limo_depth_default_params(&depth_params_);
@@ -113,7 +121,8 @@ public:
                 prior = convert(q);
             }
             auto cur = std::make_shared<Keyframe>(stamp, tracklets, camera_, prior, Keyframe::FixationStatus::None, ground_plane);
-            if (!external_prior && ba_.keyframes_.size() >= 3) {  // refine the prior against the fixed landmarks (:200-211)
+            if (!external_prior) {  // a prior without scale is always refined against the fixed landmarks of the last
+                                    // selection (:200-211; before the first solve() that selection is empty)
                 const auto t0 = clk::now();
                 ba_.adjustPoseOnly(*cur);
                 stats_.sec_pose_only += std::chrono::duration<double>(clk::now() - t0).count();
@@ -125,13 +134,15 @@ public:
             stats_.sec_push += std::chrono::duration<double>(clk::now() - t1).count();
             is_keyframe = !selected.empty();
             const double now_sec = convert(stamp);
-            if (ba_.keyframes_.size() > 2 && is_keyframe && now_sec - last_solved_sec_ > 0.98 * p_.time_between_keyframes_sec) {
+            // bundle adjustment every time_between_keyframes, whether or not THIS frame became a keyframe (:245-246)
+            if (ba_.keyframes_.size() > 2 && now_sec - last_solved_sec_ > 0.98 * p_.time_between_keyframes_sec) {
                 ba_.deactivateKeyframes(p_.min_number_connecting_landmarks, 3, p_.max_size_optimization_window);
                 ba_.updateLabels(tracklets, p_.shrubbery_weight);
                 const auto t2 = clk::now();
                 last_summary_ = ba_.solve();
                 stats_.sec_solve += std::chrono::duration<double>(clk::now() - t2).count();
                 ++stats_.solves;
+                stats_.solves_on_non_keyframes += !is_keyframe;
                 last_solved_sec_ = now_sec;
             }
             // the optimised pose if the frame became a keyframe, its prior otherwise (:281-294)

@@ -415,6 +415,26 @@ struct Minimizer {
         it.step_is_valid = false;
         bool ok = LinearSolve(lm_diagonal, step);
         reuse_diagonal = true;
+        if (opt.probe && !opt.probe->filled) {
+            StepProbe& pr = *opt.probe;
+            pr.filled = true;
+            pr.num_residuals = prog.num_residuals;
+            pr.num_eff = prog.num_eff;
+            pr.num_e = prog.num_e;
+            pr.J.assign((size_t)prog.num_residuals * prog.num_eff, 0.0);
+            for (const RowInfo& ri : prog.rows)
+                for (int i = 0; i < ri.np; ++i) {
+                    if (ri.jac_sub[i] < 0) continue;
+                    const ParamBlock* pb = ri.b->params[i];
+                    const int l = pb->lsize();
+                    const double* J = jac.data() + ri.b->jac_off + ri.jac_sub[i];
+                    for (int k = 0; k < ri.nres; ++k)
+                        for (int c = 0; c < l; ++c) pr.J[(size_t)(ri.b->res_off + k) * prog.num_eff + pb->delta_off + c] = J[k * l + c];
+                }
+            pr.r = residuals;
+            pr.D = lm_diagonal;
+            pr.y = ok ? step : std::vector<double>();
+        }
         if (!ok) return;
         for (auto& s : step) s = -s;
         // model_cost_change = -(J step)'(f + J step / 2)

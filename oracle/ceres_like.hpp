@@ -281,7 +281,17 @@ struct SolverSummary {
     double time_eval = 0, time_schur = 0, time_chol = 0, time_total = 0;
 };
 
+// Test probe (tests/test_oracle_crosscheck.py): the linear least-squares problem of the FIRST trust-region step as the
+// Schur-based LinearSolve saw it - dense (column-scaled) Jacobian, residuals, LM diagonal - and the step it returned, so
+// that a dense solver outside this library can solve  min |J y - r|^2 + |D y|^2  independently.
+struct StepProbe {
+    bool filled = false;
+    int num_residuals = 0, num_eff = 0, num_e = 0;
+    std::vector<double> J, r, D, y;  // J row-major num_residuals x num_eff; e-blocks (landmarks) first
+};
+
 struct SolverOptions {  // ceres::Solver::Options defaults (1.13) + the reference's overrides
+    StepProbe* probe = nullptr;
     int max_num_iterations = 100;
     double max_solver_time_in_seconds = -1;  // <= 0: no wall-clock stop
     double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;

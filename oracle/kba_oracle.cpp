@@ -706,6 +706,66 @@ int oracle_functor(int kind, const double* consts, const double* p0, const doubl
     return -1;
 }
 
+// Ambient Jacobians of the functors of oracle_functor kinds 0 (reprojection), 1 (depth), 3 (ground height) by dual
+// numbers, for the sympy cross-check (tests/test_oracle_crosscheck.py): jac = concatenation over the parameter blocks
+// of row-major nres x size matrices.  Returns nres, 0 if the functor returned false, <0 on a bad kind.
+int oracle_functor_jacobian(int kind, const double* consts, const double* p0, const double* p1, const double* p2,
+                            const double* p3, double* residuals, double* jac) {
+    const double* ps[4] = {p0, p1, p2, p3};
+    std::unique_ptr<CostFunction> cost;
+    if (kind == 0) {
+        ReprojectionErrorWithQuaternions f{consts[0], consts[1], consts[2], consts[3], consts[4], {}};
+        for (int i = 0; i < 7; ++i) f.pose_C_X[i] = consts[5 + i];
+        cost.reset(new AutoDiffCost<ReprojectionErrorWithQuaternions, 2, 7, 3>(f));
+    } else if (kind == 1) {
+        LandmarkDepthError f{consts[0], {}};
+        for (int i = 0; i < 7; ++i) f.pose_C_X_[i] = consts[1 + i];
+        cost.reset(new AutoDiffCost<LandmarkDepthError, 1, 7, 3>(f));
+    } else if (kind == 3) {
+        cost.reset(new AutoDiffCost<GroundPlaneHeightRegularization, 1, 7, 3, 1, 3>(GroundPlaneHeightRegularization()));
+    } else {
+        return -1;
+    }
+    double* jj[4] = {nullptr, nullptr, nullptr, nullptr};
+    int off = 0;
+    for (size_t i = 0; i < cost->sizes.size(); ++i) {
+        jj[i] = jac + off;
+        off += cost->nres * cost->sizes[i];
+    }
+    return cost->Evaluate(ps, residuals, jj) ? cost->nres : 0;
+}
+
+// First trust-region step of the solve() problem of `w` (w is left at its input values): fills the probe arrays (see
+// StepProbe).  sizes3 = (num_residuals, num_eff, num_e); arrays may be null to query the sizes first.
+int oracle_ba_first_step(const limo_ba_window* w, const limo_ba_options* o, int32_t* sizes3, double* J, double* r, double* D, double* y) {
+    if (!w || !o || !sizes3) return LIMO_ERR_INVALID;
+    // private copies of the parameter arrays: Solve() writes the result of its one iteration back
+    std::vector<double> pose(w->kf_pose, w->kf_pose + 7 * (size_t)w->n_kf), dir(w->kf_plane_dir, w->kf_plane_dir + 3 * (size_t)w->n_kf),
+        dist(w->kf_plane_dist, w->kf_plane_dist + w->n_kf), lm(w->lm_pos, w->lm_pos + 3 * (size_t)w->n_lm);
+    limo_ba_window c = *w;
+    c.kf_pose = pose.data();
+    c.kf_plane_dir = dir.data();
+    c.kf_plane_dist = dist.data();
+    c.lm_pos = lm.data();
+    Built B;
+    build_solve_problem(c, *o, B);
+    SolverOptions so = make_options(*o, 1, 1);
+    so.max_num_iterations = 1;
+    StepProbe probe;
+    so.probe = &probe;
+    SolverSummary sum;
+    Solve(so, &B.problem, &sum);
+    if (!probe.filled || probe.y.empty()) return 1;
+    sizes3[0] = probe.num_residuals;
+    sizes3[1] = probe.num_eff;
+    sizes3[2] = probe.num_e;
+    if (J) std::memcpy(J, probe.J.data(), sizeof(double) * probe.J.size());
+    if (r) std::memcpy(r, probe.r.data(), sizeof(double) * probe.r.size());
+    if (D) std::memcpy(D, probe.D.data(), sizeof(double) * probe.D.size());
+    if (y) std::memcpy(y, probe.y.data(), sizeof(double) * probe.y.size());
+    return LIMO_OK;
+}
+
 // loss function known-answer access: kind 0 trivial, 1 huber, 2 cauchy; scaled by weight
 void oracle_loss(int kind, double a, double weight, double s, double* rho3) {
     Loss l;

@@ -47,6 +47,8 @@ def load():
     lib.oracle_robust_test_solve_trimmed.argtypes = [C.c_int, C.c_int, C.c_double, ip, C.c_int, C.c_double]
     lib.oracle_robust_test_solve_trimmed.restype = C.c_double
     lib.oracle_num_procs.restype = C.c_int
+    lib.oracle_functor_jacobian.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, dp]
+    lib.oracle_ba_first_step.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), ip, dp, dp, dp, dp]
     _lib = lib
     return lib
 
@@ -117,6 +119,40 @@ def functor(kind, consts, *params, nres=3):
     out = np.zeros(3)
     ok = lib.oracle_functor(kind, _dp(consts), _dp(ps[0]), _dp(ps[1]), _dp(ps[2]), _dp(ps[3]), _dp(out))
     return ok, out[:nres]
+
+
+def functor_jacobian(kind, consts, *params):
+    """(residuals, [ambient Jacobian per parameter block]) of functor kinds 0, 1, 3 by the oracle's dual numbers."""
+    lib = load()
+    consts = np.ascontiguousarray(consts if consts is not None else [0.0], np.float64)
+    ps = [np.ascontiguousarray(p, np.float64) for p in params] + [None] * (4 - len(params))
+    res = np.zeros(3)
+    jac = np.zeros(64)
+    n = lib.oracle_functor_jacobian(kind, _dp(consts), _dp(ps[0]), _dp(ps[1]), _dp(ps[2]), _dp(ps[3]), _dp(res), _dp(jac))
+    if n <= 0:
+        raise RuntimeError("oracle_functor_jacobian rc=%d" % n)
+    out, off = [], 0
+    for p in params:
+        out.append(jac[off:off + n * len(p)].reshape(n, len(p)).copy())
+        off += n * len(p)
+    return res[:n], out
+
+
+def first_step(window, opts):
+    """The linear least-squares problem of the first LM step of solve() and the Schur-based solution: dict with J
+    (column-scaled, landmarks first), r, D, y, num_e."""
+    lib = load()
+    s = window.as_struct()
+    sizes = np.zeros(3, np.int32)
+    rc = lib.oracle_ba_first_step(C.byref(s), C.byref(opts), sizes.ctypes.data_as(_ffi.c_int32_p), None, None, None, None)
+    if rc != 0:
+        raise RuntimeError("oracle_ba_first_step rc=%d" % rc)
+    m, n = int(sizes[0]), int(sizes[1])
+    J, r, D, y = np.zeros((m, n)), np.zeros(m), np.zeros(n), np.zeros(n)
+    rc = lib.oracle_ba_first_step(C.byref(s), C.byref(opts), sizes.ctypes.data_as(_ffi.c_int32_p), _dp(J), _dp(r), _dp(D), _dp(y))
+    if rc != 0:
+        raise RuntimeError("oracle_ba_first_step rc=%d" % rc)
+    return {"J": J, "r": r, "D": D, "y": y, "num_e": int(sizes[2])}
 
 
 def loss(kind, a, weight, s):

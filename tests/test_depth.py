@@ -175,3 +175,63 @@ def test_gpu_depth_batch_equals_single_calls(ctx, oracle):
     pinned["cloud"][:] = frames[0]["cloud"]
     assert np.array_equal(ba.depth_estimate(ctx, pinned), singles[0])
     assert np.array_equal(ba.depth_estimate(ctx, frames[0], use_ground_labels=False), ba.depth_estimate_batch(ctx, frames[:1], use_ground_labels=False)[0])
+
+
+def cluttered_band_frame(seed, ground_share=0.2, n=60000):
+    """A sweep whose z band is mostly clutter: the ground carries only `ground_share` of the band returns, so the adaptive
+    RANSAC bound stays above 64 hypotheses and the second count launch (k_ransac<rest>) has to run."""
+    rng = np.random.default_rng(seed)
+    fr = synth_lidar.make_frame(seed)
+    n_g = int(n * ground_share)
+    xy = rng.uniform(-40, 40, (n, 2))
+    z = np.where(np.arange(n) < n_g, -synth_lidar.LIDAR_HEIGHT + rng.normal(0, 0.02, n), rng.uniform(-3.4, -1.1, n))
+    cloud = np.concatenate([xy, z[:, None], np.zeros((n, 1))], axis=1).astype(np.float32)
+    fr["cloud"] = cloud[rng.permutation(n)]
+    return fr
+
+
+@pytest.mark.gpu
+def test_gpu_depth_edge_cases_match_oracle(ctx, oracle):
+    from limo_amd import ba
+
+    def same(fr, params=None, **kw):
+        dg = ba.depth_estimate(ctx, fr, params=params, **kw)
+        do = oracle.depth_estimate(fr, params=params, **kw)
+        assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+        if kw.get("use_ground_labels", True):
+            n_g, pl_g = ba.depth_last_ground_plane(ctx, 0)
+            n_o, pl_o = oracle.ground_plane(fr, params)
+            assert n_g == n_o and np.array_equal(pl_g, pl_o)
+            return n_o
+        return 0
+
+    # more than 64 RANSAC hypotheses needed (inlier share < 0.41 => bound > 64)
+    fr = cluttered_band_frame(21)
+    n_in = same(fr)
+    band = ((fr["cloud"][:, 2] >= -3.5) & (fr["cloud"][:, 2] <= -1.0)).sum()
+    assert 0.2 < n_in / band < 0.41
+    # NaN / inf returns are dropped everywhere
+    fr = synth_lidar.make_frame(6)
+    bad = np.random.default_rng(0).choice(fr["cloud"].shape[0], 500, replace=False)
+    fr["cloud"][bad[:200], 0] = np.nan
+    fr["cloud"][bad[200:350], 2] = np.nan
+    fr["cloud"][bad[350:], 1] = np.inf
+    same(fr)
+    # parameter variants: no refinement, window offsets and a larger window (more cells per feature), no histogram
+    # segmentation, absolute local gate, unweighted ground patches
+    fr = synth_lidar.make_frame(7)
+    for changes in ({"ransac_plane_use_refinement": 0}, {"pixelarea_search_offset_x": 3, "pixelarea_search_offset_y": -2},
+                    {"pixelarea_search_width": 14, "pixelarea_search_height": 20}, {"do_use_histogram_segmentation": 0},
+                    {"treshold_depth_local_valuetype": 0, "treshold_depth_local_value": 0.2}, {"plane_estimator_use_mestimator": 0},
+                    {"do_check_triangleplanar_condition": 0, "neighbors_count_min": 5}, {"ransac_seed": 99}):
+        p = ba.depth_default_params()
+        for k, v in changes.items():
+            setattr(p, k, v)
+        same(fr, params=p)
+    # a cloud that is not one sweep of a spinning scanner (20 sweeps stacked) exceeds the cell lists: an error, not a
+    # silently different answer
+    fr = synth_lidar.make_frame(8)
+    fr["cloud"] = np.concatenate([fr["cloud"]] * 20)
+    with pytest.raises(RuntimeError, match="returns"):
+        ba.depth_estimate(ctx, fr)
+    assert np.array_equal(ba.depth_estimate(ctx, synth_lidar.make_frame(7)), oracle.depth_estimate(synth_lidar.make_frame(7)))  # context still usable

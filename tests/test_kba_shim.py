@@ -76,7 +76,7 @@ def run_limo_stream(exe, frames, az, poses_path=None, extra=()):
     print(r.stdout[-1500:])
     print(r.stderr[-800:])
     assert r.returncode == 0
-    return {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("frames", "fps", "ate_rmse", "ate_max", "depth_fraction", "keyframes", "solves")}
+    return {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("frames", "fps", "ate_rmse", "ate_max", "depth_fraction", "keyframes", "solves", "solves_on_non_keyframes")}
 
 
 def test_limo_stream_with_emulated_backend(tmp_path):
@@ -86,6 +86,11 @@ def test_limo_stream_with_emulated_backend(tmp_path):
     poses = str(tmp_path / "poses.txt")
     out = run_limo_stream(exe, 40, 2000, poses)
     assert out["frames"] == 40 and out["keyframes"] >= 15 and out["solves"] >= 12
+    # the node solves every time_between_keyframes on whatever frame arrives, keyframe or not (mono_lidar.cpp:245-246): with
+    # a flow threshold that rejects most frames as keyframes the solves go on between them
+    sparse = run_limo_stream(exe, 40, 2000, extra=["--min-flow", "30"])
+    assert sparse["keyframes"] < out["keyframes"] and sparse["solves_on_non_keyframes"] >= 5 and sparse["solves"] > sparse["keyframes"]
+    assert sparse["ate_rmse"] < 0.1
     assert out["depth_fraction"] > 0.3          # the features' depths come from the sweep, nowhere else
     assert out["ate_rmse"] < 0.05 and out["ate_max"] < 0.12
     rows = [l.split() for l in open(poses).read().splitlines() if l.strip()]
@@ -124,10 +129,10 @@ def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
     og = run_limo_stream(gpu, 80, 2000, pg)
     oe = run_limo_stream(emu, 80, 2000, pe)
     assert og["ate_rmse"] < 0.05 and og["depth_fraction"] > 0.35
-    assert abs(og["depth_fraction"] - oe["depth_fraction"]) < 0.01
+    assert og["depth_fraction"] == oe["depth_fraction"]  # the depth assignment is bit-exact against its oracle (test_depth.py)
     a = np.array([l.split() for l in open(pg).read().splitlines() if l.strip()], float)
     b = np.array([l.split() for l in open(pe).read().splitlines() if l.strip()], float)
     assert a.shape == b.shape == (80, 12)
-    # the two depth assigners agree on >= 99.9 % of the accept / reject decisions (test_depth.py), not on all of them, and
-    # the drive feeds every difference back through selection and trimming: positions agree to the level of the ATE
-    assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() < 2e-2 and abs(og["ate_rmse"] - oe["ate_rmse"]) < 1e-2
+    # identical depths go into both drives; what is left is the arithmetic of the two BA implementations (block summation
+    # orders), fed back through selection and trimming over 80 frames: 1 mm on a 44 m path
+    assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() < 1e-3 and abs(og["ate_rmse"] - oe["ate_rmse"]) < 1e-3
