@@ -1,6 +1,8 @@
 // landmark_init.hip — limo_landmark_init on gfx950: one lane per landmark over the CSR ray list (landmark_init.hpp).
 // A keyframe brings a few thousand new landmarks at once (every track the frame starts); the caller hands them over
 // in ONE call (limo_amd/kba push()).  HBM-side this is a 64-byte-per-ray scan; nothing to tile.
+// Compiled with floating-point contraction off (pragma + -ffp-contract=off in the build): see landmark_init.hpp.
+#pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
 #include <cstring>

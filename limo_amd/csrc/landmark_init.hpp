@@ -9,7 +9,11 @@
 //                                                                        solved like Eigen's JacobiSVD (minimum norm),
 //   convertMeasurementToRay, src/definitions.cpp:98-102.
 // Same statements on gfx950 (landmark_init.hip, one lane per landmark) and on the host (the emulated ABI of the
-// CPU test tier).
+// CPU test tier) - and the same statements, in the same order, as the oracle's restatement of the reference lines
+// (oracle/exact_oracle.cpp:oracle_landmark_init).  BIT-EXACT CONTRACT: landmark_init.hip is compiled with floating-point
+// contraction off, so the positions equal the oracle's bit for bit - a two-view triangulation at 0.5 m baseline amplifies
+// the last bits by its condition number, and the positions feed the landmark selection (cheirality, voxel cells,
+// distance ranks), whose decisions would otherwise differ between two drives of the same data.
 #pragma once
 #include "../../include/limo_hip.h"
 #include "kba_math.hpp"
@@ -31,9 +35,9 @@ KBA_HD void lminit_invert_pose(const double* pose_cam_origin, double* R_oc, doub
 KBA_HD void lminit_solve_sym3_pinv(const double* A, const double* b, double* p) {
     double a[3][3] = {{A[0], A[1], A[2]}, {A[3], A[4], A[5]}, {A[6], A[7], A[8]}};
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 50; ++sweep) {
+    for (int sweep = 0; sweep < 64; ++sweep) {
         const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off == 0.0) break;
+        if (off < 1e-300) break;
         for (int i = 0; i < 2; ++i)
             for (int j = i + 1; j < 3; ++j) {
                 if (a[i][j] == 0.0) continue;
@@ -62,8 +66,8 @@ KBA_HD void lminit_solve_sym3_pinv(const double* A, const double* b, double* p) 
     p[0] = p[1] = p[2] = 0.0;
     for (int j = 0; j < 3; ++j) {
         if (fabs(a[j][j]) <= thr) continue;
-        const double dot = (V[0][j] * b[0] + V[1][j] * b[1] + V[2][j] * b[2]) / a[j][j];
-        for (int k = 0; k < 3; ++k) p[k] += V[k][j] * dot;
+        const double dot = V[0][j] * b[0] + V[1][j] * b[1] + V[2][j] * b[2];
+        for (int k = 0; k < 3; ++k) p[k] += V[k][j] * dot / a[j][j];
     }
 }
 
@@ -87,16 +91,18 @@ KBA_HD bool lminit_one(const int32_t* ray_off, const limo_ray* rays, const uint8
     double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0};
     for (int r = b; r < e; ++r) {
         const limo_ray& m = rays[r];
-        const double ray[3] = {(static_cast<double>(m.u) - m.cx) / m.f, (static_cast<double>(m.v) - m.cy) / m.f, 1.0};
+        // convertMeasurementToRay, definitions.cpp:98-102: (K^-1 (u,v,1)).normalized()
+        double ray[3] = {(static_cast<double>(m.u) - m.cx) / m.f, (static_cast<double>(m.v) - m.cy) / m.f, 1.0};
         const double nn = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        for (int k = 0; k < 3; ++k) ray[k] /= nn;
         double R_oc[9], c_o[3], ro[3];
         lminit_invert_pose(m.pose_cam_origin, R_oc, c_o);
-        for (int k = 0; k < 3; ++k) ro[k] = (R_oc[k * 3] * ray[0] + R_oc[k * 3 + 1] * ray[1] + R_oc[k * 3 + 2] * ray[2]) / nn;
-        const double rc = ro[0] * c_o[0] + ro[1] * c_o[1] + ro[2] * c_o[2];  // (I - r r^T) accumulated, rhs += (I - r r^T) c
-        for (int a = 0; a < 3; ++a) {
-            for (int c = 0; c < 3; ++c) A[a * 3 + c] += (a == c ? 1.0 : 0.0) - ro[a] * ro[c];
-            rhs[a] += c_o[a] - ro[a] * rc;
-        }
+        for (int k = 0; k < 3; ++k) ro[k] = R_oc[k * 3] * ray[0] + R_oc[k * 3 + 1] * ray[1] + R_oc[k * 3 + 2] * ray[2];
+        double cur[9];  // I - r r^T (triangulator.hpp:60-66)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) cur[a * 3 + c] = (a == c ? 1.0 : 0.0) - ro[a] * ro[c];
+        for (int k = 0; k < 9; ++k) A[k] += cur[k];
+        for (int a = 0; a < 3; ++a) rhs[a] += cur[a * 3] * c_o[0] + cur[a * 3 + 1] * c_o[1] + cur[a * 3 + 2] * c_o[2];
     }
     lminit_solve_sym3_pinv(A, rhs, pos);
     return true;

@@ -85,11 +85,23 @@ inline std::vector<LandmarkId> chooseNearLmIds(size_t max_num, const std::vector
     ids.resize(std::min(max_num, ids.size()));
     return ids;
 }
+// A uniformly random subset of max_num ids, deterministic in (ids, seed) and STABLE: every id gets the rank
+// hash(id, seed) and the max_num smallest ranks are kept, so adding or removing one candidate changes the subset by at
+// most one element.  (A shuffle of the candidate list - what std::random_shuffle does in the reference - reorders
+// everything when the list grows by one, and a candidate list differs by one as soon as a voxel boundary or a
+// representative flips with the last bits of a pose.)
 inline std::vector<LandmarkId> chooseMiddleLmIds(size_t max_num, const std::vector<LandmarkId>& middle_ids, uint64_t seed = 0) {
+    auto rank = [seed](LandmarkId id) {
+        uint64_t x = (uint64_t)id * 0x9E3779B97F4A7C15ull + seed;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
     std::vector<LandmarkId> a(middle_ids);
-    std::sort(a.begin(), a.end());
-    std::mt19937_64 rng(seed);
-    std::shuffle(a.begin(), a.end(), rng);
+    std::sort(a.begin(), a.end(), [&](LandmarkId x, LandmarkId y) {
+        const uint64_t rx = rank(x), ry = rank(y);
+        return rx < ry || (rx == ry && x < y);
+    });
     a.resize(std::min(max_num, a.size()));
     return a;
 }
@@ -193,9 +205,13 @@ public:
             const Vector3d centroid(c.sx / n, c.sy / n, c.sz / n);
             size_t best = c.members[0];
             double bd = std::numeric_limits<double>::max();
+            // nearest member to the centroid; members whose distances agree to 1e-9 relative count as equidistant and the
+            // smaller id wins - the two members of a 2-member voxel are ALWAYS equidistant from their midpoint, and which
+            // of the two computed distances comes out smaller is rounding noise
             for (size_t i : c.members) {
                 const double d = (pipe[i].p - centroid).norm();
-                if (d < bd || (d == bd && pipe[i].id < pipe[best].id)) {
+                const bool tie = std::fabs(d - bd) <= 1e-9 * (d + bd);
+                if ((!tie && d < bd) || (tie && pipe[i].id < pipe[best].id)) {
                     bd = d;
                     best = i;
                 }

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -126,6 +127,7 @@ public:
                 const auto t0 = clk::now();
                 ba_.adjustPoseOnly(*cur);
                 stats_.sec_pose_only += std::chrono::duration<double>(clk::now() - t0).count();
+                trace("pose-only", stamp, cur->pose_, ba_.last_report_.final_cost);
             }
             pose = cur->getEigenPose();
             const auto selected = selector_.select({cur}, ba_.getActiveKeyframePtrs());
@@ -142,6 +144,7 @@ public:
                 last_summary_ = ba_.solve();
                 stats_.sec_solve += std::chrono::duration<double>(clk::now() - t2).count();
                 ++stats_.solves;
+                trace("solve", stamp, ba_.getKeyframe().pose_, ba_.last_report_.final_cost);
                 stats_.solves_on_non_keyframes += !is_keyframe;
                 last_solved_sec_ = now_sec;
             }
@@ -181,6 +184,14 @@ public:
     limo_depth_params& depthParams() { return depth_params_; }
 
 private:
+    // LIMO_STREAM_TRACE=1: one line per adjustPoseOnly / solve with the resulting pose at full precision (two drives on
+    // different back ends are compared call by call with it)
+    void trace(const char* what, TimestampNSec stamp, const Pose& p, double cost) const {
+        static const bool on = std::getenv("LIMO_STREAM_TRACE") != nullptr;
+        if (on)
+            std::fprintf(stderr, "trace %s %llu cost %.17g pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g selected %zu\n", what, (unsigned long long)stamp, cost, p[0],
+                         p[1], p[2], p[3], p[4], p[5], p[6], ba_.selected_landmark_ids_.size());
+    }
     // constant velocity from the last two poses; before there are two: straight ahead at prior_speed
     EigenPose constantVelocityPrior(TimestampNSec stamp) const {
         if (have_motion_) return last_motion_ * last_pose_;
