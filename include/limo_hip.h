@@ -205,8 +205,10 @@ int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int6
  * Landmark-sharded solve of ONE (large) window, SURVEY §8e / BASELINE.json configs[3]: shard s owns the landmarks
  * whose index in the window satisfies  index mod n_shards == s  together with all their observations and
  * ground-plane rows; camera-side parameters are replicated.  Per LM iteration the shards exchange their partial
- * camera blocks (U_k, g_k, cost), Schur-complement slabs and step-norm parts by all-reduce (3 exchanges), then every
- * shard factors the reduced camera system redundantly and back-substitutes its own landmarks.  Every partial entry
+ * camera blocks (U_k, g_k, cost), Schur-complement slabs and step-norm parts in THREE all-reduces - one packed,
+ * contiguous buffer per exchange point, before the camera assembly, the camera solve and the step decision (one more
+ * per trimming round, one at the end for the landmarks) -, then every shard factors the reduced camera system
+ * redundantly and back-substitutes its own landmarks.  Every partial entry
  * has exactly one owner, so the sum is exact and the result does not depend on the reduction order.
  *   - with a communicator (limo_ctx_comm_init): one process per GPU, shard s lives on rank s mod world (n_shards a
  *     multiple of world, normally == world); every rank calls with the same window; the exchange is a local sum
@@ -220,6 +222,9 @@ int limo_comm_unique_id(unsigned char id[LIMO_COMM_ID_BYTES]);            /* ran
 int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES], int rank, int world);
 int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
                           limo_ba_report* report);
+/* Exchange accounting of the last limo_ba_solve_sharded on this context: stats3 = (exchange steps = all-reduce calls
+ * with a communicator, bytes entering them on this rank, LM iterations of the solve). */
+int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3);
 
 /*
  * Evaluate the reprojection / depth residual blocks of a window at its current parameters
@@ -359,6 +364,13 @@ int limo_depth_estimate_batch(limo_ctx* ctx, int32_t n_frames, const limo_depth_
  * can look at it.
  */
 int limo_depth_last_ground_plane(limo_ctx* ctx, int32_t frame, double* plane4, int32_t* inliers /* may be NULL */);
+/*
+ * Measurement aid (bench.py `roofline_depth`): with timing on, every launch group records HIP events on the context's
+ * stream around its kernels; limo_depth_last_kernel_ms returns the device time of the last group in milliseconds:
+ * ms4 = (k_project, ground-plane kernels k_ransac / k_pick / k_refine / k_plane, k_features, their sum).
+ */
+int limo_depth_set_timing(limo_ctx* ctx, int32_t on);
+int limo_depth_last_kernel_ms(limo_ctx* ctx, double* ms4);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,7 @@ ABI_SYMBOLS = [
     "limo_comm_unique_id",
     "limo_ctx_comm_init",
     "limo_ba_solve_sharded",
+    "limo_ctx_exchange_stats",
     "limo_ba_evaluate",
     "limo_ba_evaluate_batch_time",
     "limo_ba_adjust_pose_only",
@@ -192,6 +193,8 @@ ABI_SYMBOLS = [
     "limo_depth_estimate",
     "limo_depth_estimate_batch",
     "limo_depth_last_ground_plane",
+    "limo_depth_set_timing",
+    "limo_depth_last_kernel_ms",
 ]
 
 _lib = None
@@ -283,6 +286,9 @@ def load():
     lib.limo_host_free.restype = None
     lib.limo_depth_estimate_batch.argtypes = [vp, C.c_int32, C.POINTER(DepthFrame), c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                               C.POINTER(DepthParams), C.c_uint32]
+    lib.limo_ctx_exchange_stats.argtypes = [vp, c_int64_p]
+    lib.limo_depth_set_timing.argtypes = [vp, C.c_int32]
+    lib.limo_depth_last_kernel_ms.argtypes = [vp, c_double_p]
     lib.limo_depth_last_ground_plane.argtypes = [vp, C.c_int32, c_double_p, c_int32_p]
     _lib = lib
     return lib

@@ -69,6 +69,12 @@ class Context:
         _check(self.lib.limo_ba_solve_sharded(self.ptr, C.byref(s), C.byref(opts), int(n_shards), C.byref(rep)), self.ptr, "limo_ba_solve_sharded")
         return rep.as_dict()
 
+    def exchange_stats(self):
+        """limo_ctx_exchange_stats of the last solve_sharded: dict(exchanges, bytes, iterations)."""
+        st = (C.c_int64 * 3)()
+        _check(self.lib.limo_ctx_exchange_stats(self.ptr, st), self.ptr, "limo_ctx_exchange_stats")
+        return {"exchanges": int(st[0]), "bytes": int(st[1]), "iterations": int(st[2])}
+
     def comm_init(self, unique_id, rank, world):
         _check(self.lib.limo_ctx_comm_init(self.ptr, unique_id, int(rank), int(world)), self.ptr, "limo_ctx_comm_init")
 
@@ -203,6 +209,13 @@ def depth_estimate(ctx, frame, params=None, use_ground_labels=True):
     )
     _check(rc, ctx.ptr, "limo_depth_estimate")
     return out
+
+
+def depth_kernel_ms(ctx):
+    """limo_depth_last_kernel_ms (after limo_depth_set_timing(ctx, 1)): dict of device milliseconds of the last launch group."""
+    ms = np.zeros(4)
+    _check(ctx.lib.limo_depth_last_kernel_ms(ctx.ptr, ms.ctypes.data_as(_ffi.c_double_p)), ctx.ptr, "limo_depth_last_kernel_ms")
+    return {"k_project": ms[0], "ground_plane": ms[1], "k_features": ms[2], "total": ms[3]}
 
 
 def depth_last_ground_plane(ctx, frame=0):

@@ -847,6 +847,9 @@ struct DepthWs {
     int cur = 0;                     // zone of the next call
     int last_frames = 0;             // frames of the last launch group (limo_depth_last_ground_plane)
     uint32_t last_ground_mask = 0;
+    bool timing = false;             // limo_depth_set_timing: HIP events around the kernels of a launch group
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // before k_project | k_ransac.. | k_features | copy back | end
+    double last_ms[4] = {0, 0, 0, 0};  // k_project, ground-plane kernels, k_features, all kernels
     float* cloud = nullptr;
     int *cell_pts = nullptr, *band_idx = nullptr, *band_n = nullptr, *pick = nullptr, *zone[2] = {nullptr, nullptr};
     double* plane = nullptr;
@@ -862,6 +865,8 @@ struct DepthWs {
         if (h_feat) (void)hipHostFree(h_feat);
         if (h_out) (void)hipHostFree(h_out);
         if (h_ovf) (void)hipHostFree(h_ovf);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
         *this = DepthWs();
     }
 };
@@ -1049,8 +1054,13 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
     W.last_frames = n_frames;
     W.last_ground_mask = d.ground_mask;
     const unsigned F = (unsigned)n_frames;
+    auto mark = [&](int k) {
+        if (W.timing) (void)hipEventRecord(W.ev[k], s);
+    };
+    mark(0);
     // the projection kernel also clears the other zone: it runs even for a call without returns
     hipLaunchKernelGGL(k_project, dim3((unsigned)std::max<size_t>(1, (max_pts + 255) / 256), F), dim3(256), 0, s, d);
+    mark(1);
     if (d.ground_mask) {
         const unsigned n_chunk = (unsigned)((max_pts + kChunk - 1) / kChunk);
         const unsigned n_groups = (unsigned)((d.n_hyp + kHypPerBlock - 1) / kHypPerBlock);
@@ -1060,12 +1070,24 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
         if (p.ransac_plane_use_refinement) hipLaunchKernelGGL(k_refine, dim3(n_chunk, F), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k_plane, dim3(F), dim3(64), 0, s, d);
     }
+    mark(2);
     if (max_feat) {
         hipLaunchKernelGGL(k_features, dim3((unsigned)((max_feat + 3) / 4), F), dim3(256), 0, s, d);
+        mark(3);
         if (!device_ptrs) HIP_TRY(ctx, hipMemcpyAsync(W.h_out, W.out, sizeof(float) * Q * n_frames, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (W.timing && max_feat) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        (void)hipEventElapsedTime(&a, W.ev[0], W.ev[1]);
+        (void)hipEventElapsedTime(&b, W.ev[1], W.ev[2]);
+        (void)hipEventElapsedTime(&c, W.ev[2], W.ev[3]);
+        W.last_ms[0] = a;
+        W.last_ms[1] = b;
+        W.last_ms[2] = c;
+        W.last_ms[3] = (double)a + b + c;
+    }
     if (*W.h_ovf) {
         ctx->err = std::string("limo_depth_estimate: ") + ((*W.h_ovf & OVF_CELL) ? "more than 48 returns project into one 8x8 px image cell" : "more than 64 returns inside one search rectangle") +
                    " (not a single sweep of a spinning scanner?)";
@@ -1133,6 +1155,27 @@ int limo_depth_estimate_batch(limo_ctx* ctx, int32_t n_frames, const limo_depth_
         if (int rc = run_group(ctx, std::min(kMaxBatch, n_frames - k0), frames + k0, T_cam_lidar, f, cx, cy, img_w, img_h, p,
                                (flags & LIMO_DEPTH_DEVICE_POINTERS) != 0))
             return rc;
+    return LIMO_OK;
+}
+
+int limo_depth_set_timing(limo_ctx* ctx, int32_t on) {
+    if (!ctx) return LIMO_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    if (!ctx->depth_ws) {
+        ctx->depth_ws = new DepthWs();
+        ctx->depth_ws_free = depth_ws_free;
+    }
+    DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    if (on && !W.ev[0])
+        for (hipEvent_t& e : W.ev) HIP_TRY(ctx, hipEventCreate(&e));
+    W.timing = on != 0;
+    return LIMO_OK;
+}
+
+int limo_depth_last_kernel_ms(limo_ctx* ctx, double* ms4) {
+    if (!ctx || !ms4 || !ctx->depth_ws) return LIMO_ERR_INVALID;
+    const DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    for (int k = 0; k < 4; ++k) ms4[k] = W.last_ms[k];
     return LIMO_OK;
 }
 

@@ -88,7 +88,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
     KBA_BUF(lv_part, (size_t)(P.lvpart_total > 0 ? P.lvpart_total : 1) * D, nullptr);
-    KBA_BUF(lblk_linfail, NL * I, nullptr);
+    KBA_BUF(lblk_linfail, NL * D, nullptr);
     KBA_BUF(lm_V, (size_t)P.SL * 6 * D, nullptr);
     KBA_BUF(lm_g, (size_t)P.SL * 3 * D, nullptr);
     KBA_BUF(lm_scale, (size_t)P.SL * 3 * D, nullptr);
@@ -111,30 +111,65 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
 }
 
 // Per-workgroup partial arrays that cross from the landmark-side kernels (owned by ONE shard of a landmark-sharded
-// solve) to the window-level kernels (replicated on every shard): the exchange set of SURVEY §8e.  `point` bits:
-// 1 = before k_cam_assemble, 2 = before k_cam_solve, 4 = before k_step_decide, 8 = before k_trim_select.
-struct PartialArray {
-    size_t member;  // offset of the pointer inside BatchView
-    size_t count;   // elements
-    bool is_int;    // int32 (else double)
-    int point;
-};
-inline std::vector<PartialArray> partial_arrays(const PackedBatch& P) {
-    const size_t NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG),
-                 TL = (size_t)std::max(1, P.TL);
-    return {
-        {offsetof(BatchView, lv_part), (size_t)std::max<int64_t>(1, P.lvpart_total), false, 1},
-        {offsetof(BatchView, lblk_linfail), NL, true, 1},
-        {offsetof(BatchView, gp_r), (size_t)P.SG, false, 1},
-        {offsetof(BatchView, gp_F), (size_t)P.SG * 10, false, 1},
-        {offsetof(BatchView, gp_cost), TG, false, 1},
-        {offsetof(BatchView, lblk_part), NL * 8, false, 1 | 2 | 4},
-        {offsetof(BatchView, S_part), (size_t)std::max<int64_t>(1, P.spart_total), false, 0},  // private per shard, never exchanged
-        {offsetof(BatchView, S_red), (size_t)std::max<int64_t>(1, P.sred_total), false, 2},
-        {offsetof(BatchView, gp_cost_c), TG, false, 4},
-        {offsetof(BatchView, trim_rep), TL, false, 8},
-        {offsetof(BatchView, trim_dep), TL, false, 8},
+// solve) to the window-level kernels (replicated on every shard): the exchange set of SURVEY §8e.
+//
+// A sharded solve keeps them in ONE contiguous arena of doubles per view (the consumer view and every local shard), laid
+// out so that each exchange point is ONE contiguous range: one k_sum_shards launch + one all-reduce per point, three per
+// LM iteration (before k_cam_assemble / k_cam_solve / k_step_decide) and one per trimming round:
+//   [ lv_part | lblk_linfail | gp_r | gp_F | gp_cost | gp_cost_c | lblk_part | S_red ]   [ trim_rep | trim_dep ]
+//     point 1 ------------------------------------------------------------>|
+//     point 4                                          |<-------------------|
+//     point 2                                                      |<-------------->|          point 8 (own range)
+// (gp_cost_c rides along at point 1: its values there are the previous iteration's, nobody reads them before point 4
+// rewrites them).  Every entry has exactly one owner and is zero elsewhere, so the sums are exact in any order.
+// S_part (the per-workgroup Schur slabs) is private to a shard and never exchanged: k_slab_reduce folds it into S_red.
+struct ExchangeLayout {
+    struct Slot {
+        size_t member;  // offset of the pointer inside BatchView
+        size_t off, count;  // doubles inside the arena
     };
+    std::vector<Slot> slots;
+    size_t total = 0;                    // doubles per arena
+    size_t off[4] = {0, 0, 0, 0};        // range of exchange point 1, 2, 4, 8 (index = log2 of the point)
+    size_t count[4] = {0, 0, 0, 0};
+    size_t spart_count = 1;              // doubles of the private S_part
+};
+inline ExchangeLayout exchange_layout(const PackedBatch& P) {
+    const size_t NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG), TL = (size_t)std::max(1, P.TL);
+    ExchangeLayout L;
+    auto add = [&](size_t member, size_t count) {
+        const size_t o = L.total;
+        L.slots.push_back({member, o, count});
+        L.total += (count + 31) / 32 * 32;  // 256-byte steps; the padding stays zero in every view
+        return o;
+    };
+    const size_t o_lv = add(offsetof(BatchView, lv_part), (size_t)std::max<int64_t>(1, P.lvpart_total));
+    add(offsetof(BatchView, lblk_linfail), NL);
+    add(offsetof(BatchView, gp_r), (size_t)P.SG);
+    add(offsetof(BatchView, gp_F), (size_t)P.SG * 10);
+    add(offsetof(BatchView, gp_cost), TG);
+    const size_t o_gcc = add(offsetof(BatchView, gp_cost_c), TG);
+    const size_t o_lp = add(offsetof(BatchView, lblk_part), NL * 8);
+    const size_t e_lp = L.total;
+    add(offsetof(BatchView, S_red), (size_t)std::max<int64_t>(1, P.sred_total));
+    const size_t e_sred = L.total;
+    const size_t o_trim = add(offsetof(BatchView, trim_rep), TL);
+    add(offsetof(BatchView, trim_dep), TL);
+    L.off[0] = o_lv;
+    L.count[0] = e_lp - o_lv;
+    L.off[1] = o_lp;
+    L.count[1] = e_sred - o_lp;
+    L.off[2] = o_gcc;
+    L.count[2] = e_lp - o_gcc;
+    L.off[3] = o_trim;
+    L.count[3] = L.total - o_trim;
+    L.spart_count = (size_t)std::max<int64_t>(1, P.spart_total);
+    return L;
+}
+inline int exchange_index(int point) { return point == 1 ? 0 : point == 2 ? 1 : point == 4 ? 2 : 3; }
+// point `view` at the slices of `arena`
+inline void exchange_bind(const ExchangeLayout& L, BatchView& view, double* arena) {
+    for (const ExchangeLayout::Slot& sl : L.slots) *reinterpret_cast<double**>(reinterpret_cast<char*>(&view) + sl.member) = arena + sl.off;
 }
 
 }  // namespace kba

@@ -1090,7 +1090,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     double cost = 0.0, failf = 0.0, gmax = 0.0, xn2 = 0.0, reg_free = 0.0, reg_fixed = 0.0;
     for (int i = tid; i < wd.n_lblk * wd.n_view; i += nt) cost += bv.lv_part[wd.lvpart_off + (int64_t)i * kLinPartial];
     for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt)
-        if (bv.lblk_linfail[b]) failf = 1.0;
+        if (bv.lblk_linfail[b] != 0.0) failf = 1.0;
     for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost[g];
     for (int i = tid; i < nrows; i += nt) {
         if (rows[i].n < 0)

@@ -189,7 +189,7 @@ struct BatchView {
     double *obs_r, *obs_c;            // [3|4][SO]
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
-    int32_t* lblk_linfail;      // [n_lblk] a functor failed in this landmark workgroup
+    double* lblk_linfail;       // [n_lblk] 1.0: a functor failed in this landmark workgroup (a double: it travels in the exchange arena)
     // --- landmark side
     double *lm_V, *lm_g;        // planes [6|3][SL]  (unscaled E^T E, E^T r incl. ground-plane rows)
     double *lm_scale;           // [3][SL] Jacobi scaling

@@ -98,7 +98,9 @@ struct limo_ba_batch : Executor {
     bool shard_virtual = true;
     std::vector<int> local_shards;
     std::vector<BatchView> pv;
-    std::vector<PartialArray> parts;
+    ExchangeLayout xl;
+    std::vector<double*> arenas;  // exchange arenas: [0] = consumer view, [1 + i] = local shard i
+    int64_t n_exchanges = 0, exchange_bytes = 0;  // all-reduce calls / bytes of this batch so far (limo_ba_batch_exchange_stats)
     struct RankLists {
         int32_t *full_blk = nullptr, *full_lblk = nullptr, *full_sblk = nullptr;  // every window listed
         int32_t *act_blk = nullptr, *act_lblk = nullptr, *act_sblk = nullptr;     // re-batched active set
@@ -227,17 +229,23 @@ struct limo_ba_batch : Executor {
         if (status != LIMO_OK) return status;
         pv.assign(1, bv);
         if (shard_P > 1) {
-            parts = partial_arrays(P);
+            xl = exchange_layout(P);
             pv.assign(local_shards.size(), bv);
+            auto arena = [&](double** out) -> int {
+                if (dmalloc((void**)out, sizeof(double) * xl.total)) return LIMO_ERR_RUNTIME;
+                HIP_TRY(ctx, hipMemsetAsync(*out, 0, sizeof(double) * xl.total, ctx->stream));
+                arenas.push_back(*out);
+                return LIMO_OK;
+            };
+            double* q = nullptr;
+            if (arena(&q)) return LIMO_ERR_RUNTIME;
+            exchange_bind(xl, bv, q);
             rl.assign(local_shards.size(), RankLists());
             for (size_t i = 0; i < local_shards.size(); ++i) {
-                for (const PartialArray& pa : parts) {  // private, zero-initialised partial arrays of this shard
-                    void* q = nullptr;
-                    const size_t bytes = pa.count * (pa.is_int ? sizeof(int32_t) : sizeof(double));
-                    if (dmalloc(&q, bytes)) return LIMO_ERR_RUNTIME;
-                    HIP_TRY(ctx, hipMemsetAsync(q, 0, bytes, ctx->stream));
-                    *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member) = q;
-                }
+                if (arena(&q)) return LIMO_ERR_RUNTIME;  // the shard's own exchange arena ...
+                exchange_bind(xl, pv[i], q);
+                if (dmalloc((void**)&pv[i].S_part, sizeof(double) * xl.spart_count)) return LIMO_ERR_RUNTIME;  // ... and its private Schur slabs
+                HIP_TRY(ctx, hipMemsetAsync(pv[i].S_part, 0, sizeof(double) * xl.spart_count, ctx->stream));
                 const int r = local_shards[i];
                 auto make = [&](const std::vector<int32_t>& owner, int32_t** full, int32_t** act, int* n) -> int {
                     std::vector<int32_t> v;
@@ -384,32 +392,27 @@ struct limo_ba_batch : Executor {
     int count_sblk_fgp(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_fgp : n_wl_sblk_fgp; }
     int shard_of(size_t i) const { return shard_P > 1 ? local_shards[i] : 0; }
 
-    // Exchange step: sum the shards' partial arrays of `point` into the consumer view.
+    // Exchange step: sum the shards' partial arrays of `point` into the consumer view - ONE contiguous range of the
+    // exchange arenas per point (kba_buffers.hpp:exchange_layout): one k_sum_shards launch, one all-reduce.
     void allreduce(int point) {
         if (shard_P == 1) return;
         hipStream_t s = ctx->stream;
-        for (const PartialArray& pa : parts) {
-            if (!(pa.point & point)) continue;
-            void* dst = *reinterpret_cast<void**>(reinterpret_cast<char*>(&bv) + pa.member);
-            {   // sum of the local shards, in shard order
-                ShardPtrs sp;
-                for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member);
-                const int nb = cdiv((int64_t)pa.count, 256);
-                const int nl = (int)pv.size();
-                if (pa.is_int)
-                    hipLaunchKernelGGL(k_sum_shards<int32_t>, dim3(nb), dim3(256), 0, s, (int32_t*)dst, sp, nl, (int64_t)pa.count);
-                else
-                    hipLaunchKernelGGL(k_sum_shards<double>, dim3(nb), dim3(256), 0, s, (double*)dst, sp, nl, (int64_t)pa.count);
-                LAUNCH_CHECK("k_sum_shards");
-            }
-            if (!shard_virtual) {  // ... then over the ranks (in place)
-                ncclResult_t r = ncclAllReduce(dst, dst, pa.count, pa.is_int ? ncclInt32 : ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
-                if (r != ncclSuccess && rc == LIMO_OK) {
-                    rc = LIMO_ERR_RUNTIME;
-                    ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
-                }
+        const int x = exchange_index(point);
+        double* dst = arenas[0] + xl.off[x];
+        const int64_t n = (int64_t)xl.count[x];
+        ShardPtrs sp;
+        for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = arenas[1 + i] + xl.off[x];
+        hipLaunchKernelGGL(k_sum_shards<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, dst, sp, (int)pv.size(), n);  // local shards, in shard order
+        LAUNCH_CHECK("k_sum_shards");
+        if (!shard_virtual) {  // ... then over the ranks (in place)
+            ncclResult_t r = ncclAllReduce(dst, dst, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+            if (r != ncclSuccess && rc == LIMO_OK) {
+                rc = LIMO_ERR_RUNTIME;
+                ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
             }
         }
+        ++n_exchanges;
+        exchange_bytes += n * (int64_t)sizeof(double);
     }
 
     void full_lists() {
@@ -1046,6 +1049,8 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
             ctx->err = std::string("ncclAllReduce(landmarks): ") + ncclGetErrorString(r);
             return LIMO_ERR_RUNTIME;
         }
+        ++b->n_exchanges;
+        b->exchange_bytes += (int64_t)sizeof(double) * 3 * b->P.TL;
     }
     HIP_TRY(ctx, hipEventRecord(b->ev_total_b, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1204,9 +1209,20 @@ int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_o
     int rc = batch_create_impl(ctx, 1, window, opts, po, &b, ranks);
     if (rc != LIMO_OK) return rc;
     rc = limo_ba_batch_solve(b, opts);
-    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
+    limo_ba_report rep;
+    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, &rep);
+    if (rc == LIMO_OK && report) *report = rep;
+    ctx->exchange_stats[0] = b->n_exchanges;
+    ctx->exchange_stats[1] = b->exchange_bytes;
+    ctx->exchange_stats[2] = rc == LIMO_OK ? rep.iterations_total : 0;
     limo_ba_batch_destroy(b);
     return rc;
+}
+
+int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3) {
+    if (!ctx || !stats3) return LIMO_ERR_INVALID;
+    for (int i = 0; i < 3; ++i) stats3[i] = ctx->exchange_stats[i];
+    return LIMO_OK;
 }
 
 int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report) {

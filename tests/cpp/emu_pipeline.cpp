@@ -33,7 +33,9 @@ struct EmuBatch : Executor {
     int shard_P = 1;
     std::vector<int> local_shards;
     std::vector<BatchView> pv;
-    std::vector<PartialArray> parts;
+    ExchangeLayout xl;
+    std::vector<double*> arenas;  // [0] = consumer view, [1 + i] = local shard i
+    long n_exchanges = 0;
     emu_allreduce_fn cb = nullptr;
     void* cb_user = nullptr;
 
@@ -58,14 +60,20 @@ struct EmuBatch : Executor {
         if (shard_P > 1) {
             if (local_shards.empty())
                 for (int r = 0; r < shard_P; ++r) local_shards.push_back(r);
-            parts = partial_arrays(P);
+            xl = exchange_layout(P);
             pv.assign(local_shards.size(), bv);
-            for (BatchView& v : pv)
-                for (const PartialArray& pa : parts) {
-                    void* q = std::calloc(pa.count, pa.is_int ? sizeof(int32_t) : sizeof(double));
-                    allocs.push_back(q);
-                    *reinterpret_cast<void**>(reinterpret_cast<char*>(&v) + pa.member) = q;
-                }
+            auto arena = [&]() {
+                double* q = static_cast<double*>(std::calloc(xl.total, sizeof(double)));
+                allocs.push_back(q);
+                arenas.push_back(q);
+                return q;
+            };
+            exchange_bind(xl, bv, arena());
+            for (BatchView& v : pv) {
+                exchange_bind(xl, v, arena());
+                v.S_part = static_cast<double*>(std::calloc(xl.spart_count, sizeof(double)));  // private per shard
+                allocs.push_back(v.S_part);
+            }
         }
     }
     bool owns(size_t i, int owner) const { return shard_P == 1 || owner == local_shards[i]; }
@@ -77,25 +85,15 @@ struct EmuBatch : Executor {
     }
     void exchange(int point) {
         if (shard_P == 1) return;
-        for (const PartialArray& pa : parts) {
-            if (!(pa.point & point)) continue;
-            void* dst = *reinterpret_cast<void**>(reinterpret_cast<char*>(&bv) + pa.member);
-            auto src = [&](size_t i) { return *reinterpret_cast<void**>(reinterpret_cast<char*>(&pv[i]) + pa.member); };
-            if (pa.is_int) {  // sum of the local shards, in shard order ...
-                for (size_t k = 0; k < pa.count; ++k) {
-                    int32_t a = 0;
-                    for (size_t i = 0; i < pv.size(); ++i) a += static_cast<int32_t*>(src(i))[k];
-                    static_cast<int32_t*>(dst)[k] = a;
-                }
-            } else {
-                for (size_t k = 0; k < pa.count; ++k) {
-                    double a = static_cast<double*>(src(0))[k];
-                    for (size_t i = 1; i < pv.size(); ++i) a += static_cast<double*>(src(i))[k];
-                    static_cast<double*>(dst)[k] = a;
-                }
-            }
-            if (cb) cb(dst, dst, (int64_t)pa.count, pa.is_int ? 1 : 0, cb_user);  // ... then over the ranks, in place
+        const int x = exchange_index(point);
+        double* dst = arenas[0] + xl.off[x];
+        for (size_t k = 0; k < xl.count[x]; ++k) {  // sum of the local shards, in shard order ...
+            double a = arenas[1][xl.off[x] + k];
+            for (size_t i = 1; i < pv.size(); ++i) a += arenas[1 + i][xl.off[x] + k];
+            dst[k] = a;
         }
+        ++n_exchanges;
+        if (cb) cb(dst, dst, (int64_t)xl.count[x], 0, cb_user);  // ... then over the ranks, in place: ONE call per point
     }
 
     void solve_init(int max_iter, int select) override {

@@ -47,14 +47,19 @@ def _rank_main(rank, world, n_shards, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    calls = {"n": 0, "bytes": 0}
+
     def allreduce(send, recv):
+        calls["n"] += 1
+        calls["bytes"] += send.nbytes
         t = torch.from_numpy(np.array(send, copy=True))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         recv[:] = t.numpy()
 
     w = _window()
     rep = emu_ffi.solve_sharded(w, default_options(), n_shards, rank=rank, world=world, allreduce=allreduce)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kf_pose=w.kf_pose, lm_pos=w.lm_pos, final_cost=rep["final_cost"], iters=rep["iterations_total"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kf_pose=w.kf_pose, lm_pos=w.lm_pos, final_cost=rep["final_cost"], iters=rep["iterations_total"],
+             allreduce_calls=calls["n"], allreduce_bytes=calls["bytes"], num_solves=rep["num_solves"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,3 +82,9 @@ def test_two_ranks_gloo_match_virtual_shards(emu, tmp_path, n_shards):
         assert np.array_equal(r["lm_pos"], wv.lm_pos)
         assert float(r["final_cost"]) == rv["final_cost"]
         assert int(r["iters"]) == rv["iterations_total"]
+        # the exchange is packed: THREE all-reduces per LM iteration (before the camera assembly, the camera solve and the
+        # step decision), + the first linearisation of every solve of the schedule, one per trimming round and
+        # the landmarks at the end
+        iters, solves = int(r["iters"]), int(r["num_solves"])
+        assert int(r["allreduce_calls"]) <= 3 * (iters + solves) + solves + 2, (int(r["allreduce_calls"]), iters, solves)
+        assert int(r["allreduce_bytes"]) / max(1, int(r["allreduce_calls"])) < 1 << 20
