@@ -990,10 +990,21 @@ __global__ __launch_bounds__(64) void k_step_decide(BatchView bv, SolveConsts c,
     reduce_step(bv, w, threadIdx.x, blockDim.x, red);
     __syncthreads();
     if (threadIdx.x == 0) lm_decide_step(bv.st[w], bv.red[w], c);
+    if (!bv.counted) return;
+    // streaming solve: the accepted keyframe parameters move here, per window (k_accept works per landmark workgroup and
+    // a window WITHOUT landmark workgroups - every landmark filtered out, regularisers only - would never get them)
+    __syncthreads();
+    const WinDesc& wd = bv.win[w];
+    if (bv.st[w].accept && (int)threadIdx.x < wd.n_kf) {
+        const int64_t i = wd.kf0 + threadIdx.x;
+        for (int q = 0; q < 7; ++q) bv.pose[7 * i + q] = bv.pose_c[7 * i + q];
+        for (int q = 0; q < 3; ++q) bv.pdir[3 * i + q] = bv.pdir_c[3 * i + q];
+        bv.pdist[i] = bv.pdist_c[i];
+    }
 }
 
 // candidate -> current for accepted windows (keyframe part: first TK threads, landmark part: the rest)
-// (streaming solve: one workgroup per listed landmark workgroup; the window's first one also moves its keyframes)
+// (streaming solve: one workgroup per listed landmark workgroup; the keyframes moved in k_step_decide)
 __global__ void k_accept(BatchView bv) {
     if (bv.counted) {
         const int32_t* wl = bv.sched_lists + bv.sched_off[SL_LBLK] + 1;
@@ -1003,13 +1014,6 @@ __global__ void k_accept(BatchView bv) {
         if ((int)threadIdx.x < bv.lblk_n[b]) {
             const int64_t l = bv.lblk_lm0[b] + threadIdx.x;
             for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
-        }
-        const WinDesc& wd = bv.win[w];
-        if (b == wd.lblk0 && (int)threadIdx.x < wd.n_kf) {
-            const int64_t i = wd.kf0 + threadIdx.x;
-            for (int q = 0; q < 7; ++q) bv.pose[7 * i + q] = bv.pose_c[7 * i + q];
-            for (int q = 0; q < 3; ++q) bv.pdir[3 * i + q] = bv.pdir_c[3 * i + q];
-            bv.pdist[i] = bv.pdist_c[i];
         }
         return;
     }

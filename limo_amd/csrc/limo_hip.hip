@@ -1036,7 +1036,7 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     // Windows of a batch converge after very different numbers of iterations: from a few windows on they stream through
     // slots (k_sched) instead of advancing in lock-step.  Not for sharded solves (exchange steps between the kernels)
     // and not with a wall-clock cap (a per-solve clock, run_schedule keeps it).
-    static const int stream_min = std::getenv("KBA_STREAM_MIN") ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;
+    const int stream_min = std::getenv("KBA_STREAM_MIN") ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;  // (read per call: the tests switch paths)
     if (b->shard_P == 1 && b->opts.max_solver_time_sec <= 0.0 && b->P.n_win >= stream_min && !b->P.evaluate_only)
         b->solve_streaming();
     else

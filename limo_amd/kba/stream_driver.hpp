@@ -84,7 +84,9 @@ public:
             ap.params_per_keyframe.push_back(std::make_tuple(i, p.add_ground_landmarks_per_keyframe, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
                                                              [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
         ba_.landmark_selector_->addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
-        if (limo_ctx_create(0, &ctx_) != LIMO_OK) throw std::runtime_error("StreamDriver: no HIP device (limo_ctx_create)");
+        int dev = 0;  // LIMO_DEVICE: the GPU of this sequence (one process per GPU and sequence, scripts/stream_replicas.py)
+        if (const char* e = std::getenv("LIMO_DEVICE")) dev = std::atoi(e);
+        if (limo_ctx_create(dev, &ctx_) != LIMO_OK) throw std::runtime_error("StreamDriver: no HIP device (limo_ctx_create)");
         limo_depth_default_params(&depth_params_);
     }
     ~StreamDriver() {

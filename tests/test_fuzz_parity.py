@@ -71,7 +71,7 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
         return ctx.solve(w, opts)
 
     cases = fc.random_windows(n, seed)
-    singles, n_plateau, worst_c, worst_p = [], 0, 0.0, 0.0
+    singles, n_plateau, n_ill, worst_c, worst_p = [], 0, 0, 0.0, 0.0
     for i, (kw, w) in enumerate(cases):
         wg, wo = w.copy(), w.copy()
         b = ba.Batch(ctx, [wg])  # a batch of one: same kernels as limo_ba_solve, and the trimmed set can be read back
@@ -84,11 +84,15 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
         ok, detail, plateau = fc.check_parity(w, rg, wg, tg, sg, ro, wo, to, so)
         assert ok, "seed %d window %d %r: %s" % (seed, i, kw, detail)
         n_plateau += plateau
+        n_ill += not fc.well_posed(w)
         if not plateau:
             worst_c = max(worst_c, fc.rel_cost_err(rg, ro))
         worst_p = max(worst_p, fc.rel_pose_err(wg.kf_pose, wo.kf_pose))
         singles.append(wg)
     assert n_plateau <= max(1, n // 50)  # the plateau case is rare (1 in 290 / 1 in 60 at full size)
+    # windows that only get the weak checks (a keyframe with < 8 observations: 9 of 290 / 1 of 60 at full size) stay few:
+    # the strict rule (sets, termination, pose and cost to 1e-4) covers >= 95 % of the sweep
+    assert n_ill <= max(1, n // 20), n_ill
     # kernel variants are chosen per window: a mixed batch reproduces every single solve bit for bit
     b = ba.Batch(ctx, [w.copy() for _, w in cases])
     b.solve(o)
@@ -96,4 +100,4 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
     for i, (ws, wb) in enumerate(zip(singles, b.windows)):
         assert np.array_equal(ws.kf_pose, wb.kf_pose) and np.array_equal(ws.lm_pos, wb.lm_pos), "batch != single, window %d" % i
     b.close()
-    print("fuzz seed %d: %d windows, %d plateau cases, worst rel cost %.2e, worst rel pose %.2e" % (seed, n, n_plateau, worst_c, worst_p))
+    print("fuzz seed %d: %d windows, %d plateau cases, %d ill-posed (weak checks), worst rel cost %.2e, worst rel pose %.2e" % (seed, n, n_plateau, n_ill, worst_c, worst_p))

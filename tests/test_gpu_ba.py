@@ -79,6 +79,36 @@ def test_batch_ragged_matches_single(ctx, oracle):
     b.close()
 
 
+def test_streaming_and_lock_step_schedules_give_the_same_bits(ctx, monkeypatch):
+    """The same batch through the device-side scheduler (windows stream through slots, KBA_STREAM_MIN=1) and through the
+    host-driven lock-step schedule (KBA_STREAM_MIN above the batch size): identical parameters and reports.  The batch mixes
+    window shapes, trimming and non-trimming windows, and one window WITHOUT landmarks (regularisers only), whose keyframe
+    bookkeeping runs through the per-window kernels alone."""
+    from limo_amd.window import Window
+
+    ws = [synth.make_window(300 + i, n_kf=3 + (i % 5), n_lm=(60, 150, 400, 900)[i % 4], ground_frac=(0.0, 0.2)[i % 2]) for i in range(23)]
+    d = {name: getattr(ws[0], name).copy() for name, _ in Window.FIELDS}
+    for k in ("lm_pos", "lm_weight", "lm_is_ground", "obs_kf", "obs_lm", "obs_cam", "obs_u", "obs_v", "obs_d"):
+        d[k] = d[k][:0]
+    ws.insert(7, Window(**d))
+    o = default_options()
+    results = []
+    for stream_min in ("1", "1000"):
+        monkeypatch.setenv("KBA_STREAM_MIN", stream_min)
+        b = ba.Batch(ctx, [w.copy() for w in ws])
+        b.solve(o)
+        reps = b.download()
+        results.append((reps, [(w.kf_pose.copy(), w.kf_plane_dir.copy(), w.kf_plane_dist.copy(), w.lm_pos.copy()) for w in b.windows], [b.trimmed(i) for i in range(len(ws))]))
+        b.close()
+    (ra, pa, ta), (rb, pb, tb) = results
+    for i in range(len(ws)):
+        for key in ("termination", "iterations_total", "successful_steps", "n_trimmed_landmarks", "final_cost", "initial_cost"):
+            assert ra[i][key] == rb[i][key], (i, key)
+        assert all(np.array_equal(x, y) for x, y in zip(pa[i], pb[i])), i
+        assert np.array_equal(ta[i], tb[i])
+    assert ra[7]["iterations_total"] == 0 and ra[7]["termination"] == 0
+
+
 def test_not_enough_keyframes(ctx):
     """Only a window without active keyframes is refused; two (or one) active keyframes are solved like the reference
     does (its NotEnoughKeyframesException counts PUSHED keyframes: the shim's check) - cases kf2 / kf1 below."""

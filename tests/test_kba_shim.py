@@ -136,3 +136,20 @@ def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
     # identical depths go into both drives; what is left is the arithmetic of the two BA implementations (block summation
     # orders), fed back through selection and trimming over 80 frames: 1 mm on a 44 m path
     assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() < 1e-3 and abs(og["ate_rmse"] - oe["ate_rmse"]) < 1e-3
+
+
+def test_stream_replicas_launcher_with_emulated_backend():
+    """scripts/stream_replicas.py (config 5 on N GPUs = N independent sequences, one process each): two sequences on the
+    emulated backend; each reports its own fps / ATE, different seeds give different drives."""
+    import json
+    import sys
+
+    exe = emu_ffi.build_stream_app(gpu=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stream_replicas.py"), "--gpus", "2", "--frames", "12", "--exe", exe],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and len(out["sequences"]) == 2
+    assert all(s["frames"] == 12 and s["ate_rmse"] < 0.05 for s in out["sequences"])
+    assert out["sequences"][0]["ate_rmse"] != out["sequences"][1]["ate_rmse"]
