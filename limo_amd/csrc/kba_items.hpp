@@ -898,6 +898,9 @@ KBA_HD void coop_reduce(double* v, int tid, int nt, double* red) {
     KBA_SYNC();
 }
 
+// doubles coop_reduce<N, .> needs in `red` for nt lanes: one slot per wave on the device, a full tree on the host
+KBA_HD int coop_red_doubles(int n, int nt) { return n * ((nt >= 64 && (nt & 63) == 0) ? nt >> 6 : nt); }
+
 // scratch doubles needed by cam_assemble / cam_solve for a system of nc slots and nt lanes
 constexpr int kGpChunk = 128;  // ground-plane rows staged in LDS per pass of cam_assemble
 // A regulariser row touches at most two neighbouring keyframes: kept dense over their 2 x kCamSlots columns as
@@ -916,12 +919,14 @@ KBA_HD int cam_assemble_union(int nc) {
 }
 KBA_HD int cam_assemble_scratch(int nc, int nt) {
     const int dense = cam_max_reg_rows(nc) * kRegDense;
-    return nc * nc + cam_assemble_union(nc) + (6 * nt > dense ? 6 * nt : dense);
+    const int red = coop_red_doubles(6, nt);
+    return nc * nc + cam_assemble_union(nc) + (red > dense ? red : dense);
 }
 // Windows whose scratch exceeds this many bytes work in global memory (WinDesc::cam_scr_off) instead of LDS (160 KB / CU).
 constexpr int kCamLdsCapBytes = 150 * 1024;
-KBA_HD int cam_solve_scratch(int nc, int nt) {
-    return nc * (nc + 1) + nc + nc + (nc + 1) / 2 + 1 + 3 * nt;  // A | y | dl | fl | red, sized for nf == nc
+KBA_HD int cam_solve_scratch(int nc, int nt, int nf = -1) {
+    if (nf < 0) nf = nc;  // (nf: free slots of the compact system, <= nc)
+    return nf * (nf + 1) + nf + nc + (nf + 1) / 2 + 1 + coop_red_doubles(3, nt);  // A | y | dl | fl | red
 }
 
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the

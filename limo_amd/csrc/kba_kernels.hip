@@ -1,18 +1,19 @@
 // kba_kernels.hip — gfx950 kernels of the batched keyframe-BA pipeline (CDNA4, wave64).
 //
 // Kernel          lanes                      bound   what it replaces (reference / Ceres)
-// k_linearize     1 per observation          HBM     AutoDiff evaluation of ReprojectionErrorWithQuaternions +
-//                                                    LandmarkDepthError incl. loss corrector and local
-//                                                    parameterisation (cost_functors_ceres.hpp:53-222,
-//                                                    bundle_adjuster_keyframes.cpp:584-620) + F^T F / F^T r block sums
-// k_gp            1 per ground-plane row     -       GroundPlaneHeightRegularization (cost_functors_ceres.hpp:355-392)
-// k_lm_accum      1 per landmark             HBM     E^T E, E^T r (SchurEliminator chunk), Jacobi column scale
-// k_lm_damp       1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark
-// k_schur<T>      wave per 256 lm            MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
+// k_lin_lm        1 per landmark, loop views fp64    AutoDiff evaluation of ReprojectionErrorWithQuaternions + LandmarkDepthError
+//                                            VALU    incl. loss corrector and local parameterisation (cost_functors_ceres.hpp:
+//                                                    53-222, bundle_adjuster_keyframes.cpp:584-620): factored Jacobian planes,
+//                                                    F^T F / F^T r camera sums; the landmark's ground-plane row
+//                                                    (GroundPlaneHeightRegularization, cost_functors_ceres.hpp:355-392); E^T E,
+//                                                    E^T r (SchurEliminator chunk), Jacobi column scale, damped 3x3 Cholesky
+// k_lm_damp       1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark after a REJECTED step
+// k_schur_lean/_wide  wave / 512 lanes       MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
 // k_cam_assemble  workgroup per window       -       camera-camera blocks, regularisers, IterationZero / step tail
 // k_cam_solve     workgroup per window       -       reduced camera system: dense Cholesky in LDS, camera step
 // k_backsub       1 per landmark             HBM     BackSubstitute + candidate point + model-cost-change parts +
-//                                                    Evaluator::Evaluate(cost only) of its observations at the candidate
+//                                                    Evaluator::Evaluate(cost only) of its observations and of its
+//                                                    ground-plane row at the candidate
 // k_step_decide   1 per window               -       TrustRegionMinimizer step acceptance (kba_lm.hpp)
 // k_trim_*        1 per obs / lm / window    HBM     robust_optimization::solveTrimmed residual evaluation + quantile
 //
@@ -434,6 +435,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
     }
     double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // the landmark's ground-plane row (B3) is linearised by its own lane right here, before lin_lm_finish adds it to the
+    // landmark block (a separate k_gp launch per linearisation did this before: one launch per iteration less)
+    if (in_block) {
+        const int gg = bv.lm_gp[gl];
+        if (gg >= 0) gp_lane(bv, gg, false, bv.gp_cost);
+    }
     if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
     __shared__ double lds[8];
     const double m = wave_max(part[0]);
@@ -457,29 +464,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
 }
 __host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }
 
-// shard / n_shards: landmark sharding - a shard evaluates only the rows of its own landmarks.
-// (streaming solve: grid = (listed windows, chunks of 256 rows of a window))
-__global__ void k_gp(BatchView bv, int candidate, int shard, int n_shards) {
-    int g;
-    if (bv.counted) {
-        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_WIN] + 1;
-        if ((int)blockIdx.x >= wl[-1]) return;
-        const WinDesc& wd = bv.win[wl[blockIdx.x]];
-        const int i = blockIdx.y * blockDim.x + threadIdx.x;
-        if (i >= wd.n_gp) return;
-        g = wd.gp0 + i;
-    } else {
-        g = blockIdx.x * blockDim.x + threadIdx.x;
-        if (g >= bv.TG) return;
-    }
-    if (n_shards > 1 && bv.lm_id[bv.gp_lm[g]] % n_shards != shard) return;
-    const int w = bv.lm_win[bv.gp_lm[g]];
-    const WinState& st = bv.st[w];
-    if (!st.active) return;
-    if (!candidate && !st.need_lin) return;
-    gp_lane(bv, g, candidate != 0, candidate ? bv.gp_cost_c : bv.gp_cost);
-}
-
 // ------------------------------------------------------------------------------------------ landmarks
 __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
@@ -501,7 +485,12 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c,
     __shared__ double lds[16];
     double part[8];
     part[2] = part[3] = part[4] = part[6] = part[7] = 0.0;
-    if ((int)threadIdx.x < bv.lblk_n[b]) backsub_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x, part);
+    if ((int)threadIdx.x < bv.lblk_n[b]) {
+        const int gl = bv.lblk_lm0[b] + threadIdx.x;
+        backsub_lane(bv, c, w, gl, part);
+        const int gg = bv.lm_gp[gl];  // cost of the landmark's ground-plane row at the candidate point (former k_gp(candidate) launch)
+        if (gg >= 0) gp_lane(bv, gg, true, bv.gp_cost_c);
+    }
     const int any_fail = __syncthreads_or(part[7] != 0.0);
     const double v4[4] = {part[2], part[3], part[4], part[6]};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

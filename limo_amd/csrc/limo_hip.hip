@@ -87,7 +87,6 @@ struct limo_ba_batch : Executor {
     // ---- streaming solve (device-side scheduler k_sched): windows move through n_slots slots, a finished window is
     // replaced by the next pending one, so every launch round works on a full set (kba_kernels.hip:k_sched)
     int n_slots = 0;
-    int max_gp_chunks = 1;
     int32_t* d_sched_ctl = nullptr;   // [0] cursor over the batch's windows, [1] windows finished (shared by the groups)
     // ---- landmark sharding.  shard_P == 1: everything below is inert (pv = {bv}).
     // Every shard holds the same global layout and owns the observation / landmark / Schur workgroups of its
@@ -323,11 +322,14 @@ struct limo_ba_batch : Executor {
             }
         }
         {   // LDS of the window-level kernels: the largest window that still works in LDS (the others: cam_scr_off)
-            int nc_lds = kCamSlots;
+            int nc_lds = kCamSlots, nf_lds = 1;
             for (const WinDesc& d : P.win)
-                if (d.cam_scr_off < 0) nc_lds = std::max(nc_lds, (int)d.nc);
+                if (d.cam_scr_off < 0) {
+                    nc_lds = std::max(nc_lds, (int)d.nc);
+                    nf_lds = std::max(nf_lds, (int)d.nf);
+                }
             asm_bytes = cam_assemble_scratch(nc_lds, kBlock) * (int)sizeof(double);
-            solve_bytes = cam_solve_scratch(nc_lds, kBlock) * (int)sizeof(double);
+            solve_bytes = cam_solve_scratch(nc_lds, kBlock, nf_lds) * (int)sizeof(double);  // the compact system: nf <= nc free slots
         }
         int max_lm = 1;
         for (const WinDesc& d : P.win) max_lm = std::max(max_lm, (int)d.n_lm);
@@ -536,11 +538,6 @@ struct limo_ba_batch : Executor {
                 LAUNCH_CHECK("k_view_consts");
             }
             // ground-plane rows first: the landmark pass adds them to the landmark blocks
-            for (size_t i = 0; i < pv.size(); ++i)
-                if (P.TG) {
-                    hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 0, shard_of(i), shard_P);
-                    LAUNCH_CHECK("k_gp");
-                }
             EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
             for (size_t i = 0; i < pv.size(); ++i)
                 if (count_lblk(i)) {
@@ -630,10 +627,6 @@ struct limo_ba_batch : Executor {
                 hipLaunchKernelGGL(k_backsub, dim3(count_lblk(i)), dim3(kBlock), 0, s, pv[i], c, list_lblk(i));
                 LAUNCH_CHECK("k_backsub");
             }
-            if (P.TG) {
-                hipLaunchKernelGGL(k_gp, dim3(cdiv(P.TG, 256)), dim3(256), 0, s, pv[i], 1, shard_of(i), shard_P);
-                LAUNCH_CHECK("k_gp(cand)");
-            }
         }
         allreduce(4);
         if (n_wl_win) hipLaunchKernelGGL(k_step_decide, dim3(n_wl_win), dim3(64), 0, s, bv, c, use_wl ? d_wl_win : nullptr);
@@ -709,7 +702,6 @@ struct limo_ba_batch : Executor {
         if (const char* e = std::getenv("KBA_SLOTS")) n_slots = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedMaxSlots}));
         set_span(P.n_win);
         int mx[SL_COUNT] = {0};
-        int max_gp = 0;
         for (const WinDesc& d : P.win) {
             const int plg = (d.n_sblk_plain + c.schur_span - 1) / c.schur_span, gpg = (d.n_sblk - d.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
             mx[SL_LBLK] = std::max(mx[SL_LBLK], (int)d.n_lblk);
@@ -717,12 +709,10 @@ struct limo_ba_batch : Executor {
             mx[SL_SPLAIN] = std::max(mx[SL_SPLAIN], d.schur_fast ? plg : 0);
             mx[SL_SFGP] = std::max(mx[SL_SFGP], d.schur_fast ? gpg : 0);
             mx[SL_SGEN] = std::max(mx[SL_SGEN], d.schur_fast ? 0 : plg + gpg);
-            max_gp = std::max(max_gp, (int)d.n_gp);
         }
         mx[SL_WIN] = 1;
         mx[SL_TLBLK] = mx[SL_LBLK];
         mx[SL_TWIN] = 1;
-        max_gp_chunks = std::max(1, cdiv(max_gp, 256));
         if (!d_sched_ctl && dmalloc((void**)&d_sched_ctl, sizeof(int32_t) * 8)) return LIMO_ERR_RUNTIME;
         HIP_TRY(ctx, hipEventCreateWithFlags(&start_ev, hipEventDisableTiming));
         groups.resize(n_groups);
@@ -792,7 +782,6 @@ struct limo_ba_batch : Executor {
         // ---- linearisation of the windows that need it
         hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
         {
-            if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 0, 0, 1);
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_LINEARIZE, s) : nullptr;
             if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lin_lm<3>, dim3(cap[SL_LBLK]), dim3(kBlock), lin_lm_lds_bytes(P.Vmax), s, sv, c, L(SL_LBLK));
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
@@ -823,7 +812,6 @@ struct limo_ba_batch : Executor {
         }
         hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
         if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
-        if (P.TG) hipLaunchKernelGGL(k_gp, dim3(cap[SL_WIN], max_gp_chunks), dim3(256), 0, s, sv, 1, 0, 1);
         hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
         if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
         LAUNCH_CHECK("step kernels");
