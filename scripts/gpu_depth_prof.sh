@@ -41,11 +41,12 @@ if mode in ("all", "single"): res["ms_per_frame_single_device"] = rate(lambda: b
 res["visible_points"] = int(synth_lidar.visible_points(fr))
 print(json.dumps(res))
 PY
-for mode in single batch; do
+for mode in ${DEPTH_ONLY_PMC:+none} single batch; do
+  [ "$mode" = none ] && break
   DEPTH_MODE=$mode rocprofv3 --kernel-trace --stats -d gpurun_out/prof_depth -o dep_$mode -- python /tmp/dep.py > gpurun_out/prof_depth_$mode.log 2>&1
   echo "--- $mode-frame calls under rocprofv3 --kernel-trace"; python scripts/prof_summary.py gpurun_out/prof_depth/dep_${mode}_results.db | tee gpurun_out/rocprof_depth_$mode.txt | head -9
 done
-python /tmp/dep.py 2>/dev/null | grep "^{" | tee gpurun_out/depth_rates.json
+[ -z "${DEPTH_ONLY_PMC:-}" ] && python /tmp/dep.py 2>/dev/null | grep "^{" | tee gpurun_out/depth_rates.json
 if [ "${PMC:-0}" = "1" ]; then
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE"; do
@@ -64,6 +65,7 @@ for db_path in sorted(glob.glob("gpurun_out/pmc_depth/*_results.db")):
         k[ctr] = val
         k["launch_us_under_counters"] = max(k.get("launch_us_under_counters", 0.0), dur / 1e3)
 for n, k in out["kernels"].items():
+    k["frames"] = 32  # the largest dispatch of each kernel is the one of the 32-frame call
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         k["hbm_MB"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / 1e6
         k["hbm_TBps_under_counters"] = k["hbm_MB"] / k["launch_us_under_counters"]
