@@ -83,7 +83,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(gp_E, (size_t)P.SG * 3 * D, nullptr);
     KBA_BUF(gp_cost, TG * D, nullptr);
     KBA_BUF(gp_cost_c, TG * D, nullptr);
-    KBA_BUF(obs_r, (size_t)P.SO * 3 * D, nullptr);
+    KBA_BUF(obs_r, (size_t)(P.evaluate_only ? P.SO * 3 : 1) * D, nullptr);  // residual planes: limo_ba_evaluate only
     KBA_BUF(obs_c, (size_t)(P.evaluate_only ? 1 : P.SO * 4) * D, nullptr);
     KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);

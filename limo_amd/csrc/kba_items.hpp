@@ -233,8 +233,7 @@ KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl,
         const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);
         double r3[3], c4[4];
         if (!lin_obs(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
-        for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + s] = r3[i];
-        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + s] = c4[i];
+        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + s] = c4[i];  // (the residual stays in the lane: nobody reads it back)
         lin_lm_accum(vl, r3, c4, acc);
     }
     if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);

@@ -416,10 +416,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
         double r3[3], c4[4];
         if (!lin_obs(vl, c, in, want_cost, r3, c4, l)) fail = 1;
-        {
+        {   // the four scalars of the factored Jacobian are what the Schur / back-substitution kernels read; the residual
+            // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
+            // (limo_ba_evaluate has its own kernel), so it is not stored: 32 instead of 56 B written per pair
             const int64_t o = have ? s : dump;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = r3[i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
         }

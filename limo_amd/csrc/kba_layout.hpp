@@ -186,7 +186,7 @@ struct BatchView {
     // of 240 B for J_pose 3x6 + J_point 3x3; the landmark-parallel kernels rebuild Ft = c^T Rc, F = Ft [M | I],
     // E = Ft R from the view / pose / landmark they hold anyway.  Evaluate-only batches (Problem::Evaluate)
     // materialise Jp / Jl in full.
-    double *obs_r, *obs_c;            // [3|4][SO]
+    double *obs_r, *obs_c;            // [3|4][SO]; obs_r exists in evaluate-only batches only (the solve keeps residuals in registers)
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
     double* lblk_linfail;       // [n_lblk] 1.0: a functor failed in this landmark workgroup (a double: it travels in the exchange arena)
