@@ -1283,8 +1283,9 @@ __device__ __forceinline__ void evaluate_lane(const BatchView& bv, const SolveCo
 
 __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* obs_cost,
                                                      uint8_t* obs_valid) {
-    const int b = blockIdx.x;
-    for (int q = 0; q < kObsPerLane; ++q) evaluate_lane(bv, c, b, threadIdx.x + q * kBlock, apply_loss, obs_cost, obs_valid);
+    // one observation per lane (grid: (observation blocks, kObsPerLane quarters of a block)): 31 plane stores per
+    // observation and nothing to reduce - the more independent lanes in flight, the better the stores overlap
+    evaluate_lane(bv, c, blockIdx.x, threadIdx.x + blockIdx.y * kBlock, apply_loss, obs_cost, obs_valid);
 }
 
 }  // namespace kba

@@ -1258,7 +1258,7 @@ int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_
     rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, M));
     if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, std::max(1, M));
     if (rc == LIMO_OK && P.n_blk) {
-        hipLaunchKernelGGL(k_evaluate, dim3(P.n_blk), dim3(kBlock), 0, ctx->stream, b->bv, b->c, apply_loss, d_cost, d_valid);
+        hipLaunchKernelGGL(k_evaluate, dim3(P.n_blk, kObsPerLane), dim3(kBlock), 0, ctx->stream, b->bv, b->c, apply_loss, d_cost, d_valid);
         if (hipGetLastError() != hipSuccess) rc = LIMO_ERR_RUNTIME;
     }
     std::vector<double> hr((size_t)3 * P.SO), hjp((size_t)18 * P.SO), hjl((size_t)9 * P.SO), hc(std::max(1, M));
@@ -1311,9 +1311,9 @@ int limo_ba_evaluate_batch_time(limo_ctx* ctx, int32_t n, const limo_ba_window* 
     if (rc == LIMO_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = LIMO_ERR_RUNTIME;
     if (rc == LIMO_OK && b->P.n_blk) {
         hipStream_t s = ctx->stream;
-        hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);  // warm-up
+        hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk, kObsPerLane), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);  // warm-up
         (void)hipEventRecord(e0, s);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk, kObsPerLane), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);
         (void)hipEventRecord(e1, s);
         float ms = 0.f;
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
