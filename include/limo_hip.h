@@ -197,8 +197,8 @@ int limo_ba_batch_trimmed(limo_ba_batch* batch, int32_t window, uint8_t* removed
 int limo_ba_batch_kernel_stats(limo_ba_batch* batch, int reset, double* linearize_ms, int64_t* linearize_launches,
                                double* total_ms);
 /* Same accumulation window, per timed kernel (the two that dominate an LM iteration). */
-#define LIMO_KERNEL_LINEARIZE 0 /* k_linearize: residuals + (factored) Jacobians of every observation          */
-#define LIMO_KERNEL_SCHUR 1     /* k_schur: Schur complement of the landmark blocks (f64 MFMA)                   */
+#define LIMO_KERNEL_LINEARIZE 0 /* k_lin_lm: residuals + (factored) Jacobians of every observation, landmark blocks */
+#define LIMO_KERNEL_SCHUR 1     /* k_schur_lean / k_schur_wide: Schur complement of the landmark blocks (f64 MFMA) */
 int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int64_t* launches);
 
 /*
