@@ -675,6 +675,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const int ncol = GP ? wd.nf + 1 : nfq + 1;  // columns of the tile, the rhs (column nfq) included
     const int ld = schur_lean_ld(ncol);
     const int Tt = (ncol + 15) / 16;
+    // Two-tile Gram (plain blocks, 17..25 columns): the <= 24 pose columns are covered by TWO 16x16 products instead of
+    // the three of a 2 x 2 upper tiling - rows {0..15} x columns {8..23}, then {0..7, 16..23} squared: every pair
+    // (a <= b) of 24 columns lies in one of them - and the rhs column leaves the Gram: every (landmark, keyframe) lane
+    // keeps Y'^T t' of its six slots over the tiles of the group, one 16-lane reduction at the end.  2 x 64 instead of
+    // 3 x 64 MFMA cycles per k-step for 18 FMAs per lane and tile on the idle vector pipe.  The Gram entries keep their
+    // bits (same products, same k order); the rhs entries are summed in another order.
+    constexpr bool kTT = !GP && TM == 2;  // (plain blocks of fast windows have <= 4 free keyframes: nfq <= 24)
+    const bool two_tile = kTT && Tt == 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Z = smem;                                   // [48][ld] + 16 zeros (the last row's panel overrun)
     double* kc = Z + 3 * kSchurLm * ld + 16;            // [4][kSpKf]
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const int lm_first = bv.sblk_lm0[sb];
     const int n_lm_blk = bv.sblk_lm0[sb_last] + bv.sblk_n[sb_last] - lm_first;
 
-    constexpr int NT = TM * (TM + 1) / 2;
+    constexpr int NT = (!GP && TM == 2) ? 2 : TM * (TM + 1) / 2;
     v4f64 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #pragma unroll
             for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];
         }
-        if (live && kq == 0) {
+        if (live && (kq == 0 || two_tile)) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) t3[i] = bv.lm_t[i * bv.SL + gl];
         }
@@ -773,9 +781,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         fetch_data(0, st0, slot0, gg0);
     }
     constexpr int NS = GP ? kCamSlots : 6;  // slots of a keyframe this kernel fills
+    double yt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // two-tile path: this lane's share of the rhs, slots of its keyframe
+    const int mq = li < 8 ? li : li + 8;            // two-tile path: column of lane li in the second operand {0..7, 16..23}
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         // ---- fill: this lane's 3 x NS block of Y' (zeros where the landmark has no row with the keyframe)
-        if (kq == 0) {
+        if (kq == 0 && !two_tile) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? t3[cc] : 0.0;
         }
@@ -788,6 +798,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 rot_tangent_jac(mine + 18, p, M);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block(Ft, mine, M, Bt, mine + 22, Y);
+                if (two_tile) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) yt[a] += Y[a * 3 + 0] * t3[0] + Y[a * 3 + 1] * t3[1] + Y[a * 3 + 2] * t3[2];
+                }
             }
             if constexpr (GP) {
                 if (att) {  // the landmark's ground-plane row hangs on this keyframe: rank-one term over its free slots
@@ -838,8 +852,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #pragma unroll
                 for (int j = 0; j < kSpBatch; ++j) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pa[j], acc[0], 0, 0, 0);
             }
+        } else if (kTT) {
+            if constexpr (kTT) {
+                constexpr int kB = 3;  // k-steps whose three panel reads are in flight together
+#pragma unroll
+                for (int h = 0; h < 12; h += kB) {
+                    double pa[kB], pb[kB], pq[kB];
+#pragma unroll
+                    for (int j = 0; j < kB; ++j) {
+                        pa[j] = zp[(h + j) * 4 * ld];
+                        pb[j] = zp[(h + j) * 4 * ld + 8];
+                        pq[j] = Z[((h + j) * 4 + kq) * ld + mq];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kB; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[j], pb[j], acc[0], 0, 0, 0);  // rows 0..15 x cols 8..23
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(pq[j], pq[j], acc[1], 0, 0, 0);  // {0..7,16..23}^2
+                    }
+                }
+            }
         } else if (TM == 2 || Tt == 2) {
-            if constexpr (TM >= 2) {
+            if constexpr (TM >= 2 && !kTT) {
                 // tile order of acc for TM panels: (0,0) (0,1) .. (0,TM-1) (1,1) ..
                 constexpr int i11 = TM;
 #pragma unroll
@@ -886,26 +919,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     //      another granularity.
     double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span, span_gp) * ((int64_t)nfp * nfp);
     const int T = nfp / 16;
-    int idx = 0;
+    if (two_tile) {
+        // the two products and the rhs sums meet in a 32 x 32 staging matrix in LDS (the Z tile is free now), from where
+        // the slab is written in the layout of the three-tile path (upper tiles, zeros outside the Gram)
+        double* St = Z;  // 1024 doubles <= 48 * ld
+        for (int i = lane; i < 1024; i += 64) St[i] = 0.0;
+        __syncthreads();
 #pragma unroll
-    for (int tr = 0; tr < TM; ++tr)
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq + 4 * r;
+            {   // first product: entry (row, 8 + li)
+                const int col = 8 + li;
+                if (row <= col && col < nfq) St[row * 32 + col] = acc[0][r];
+            }
+            {   // second product: entry (m(row), m(li)); the block {0..7} x {16..23} is already there
+                const int a = row < 8 ? row : row + 8, b = mq;
+                if (a <= b && b < nfq && !(a < 8 && b >= 16)) St[a * 32 + b] = acc[1][r];
+            }
+        }
+        if (have) {  // rhs: sum of this keyframe's six slot values over the 16 landmark lanes
 #pragma unroll
-        for (int tc = tr; tc < TM; ++tc) {
-            if (tc < T) {
+            for (int a = 0; a < 6; ++a) {
+                double v = yt[a];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (li == 0) St[(zcs[kq * 12] + a) * 32 + nfq] = v;
+            }
+        }
+        __syncthreads();
+        for (int tc = 0; tc < T; ++tc)
+            for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
                     const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
-                    out[row * nfp + col] = (row < ncol && col < ncol) ? acc[idx][r] : 0.0;
+                    out[row * nfp + col] = (tc < 2) ? St[row * 32 + col] : 0.0;
                 }
             }
-            ++idx;
-        }
-    for (int tc = TM; tc < T; ++tc)
-        for (int tr = 0; tr <= tc; ++tr) {
+        return;
+    }
+    if constexpr (kTT) {  // (one 16-column tile: windows of this batch with <= 2 free keyframes)
+        for (int tc = 0; tc < T; ++tc)
+            for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
-        }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
+                    out[row * nfp + col] = (tc == 0 && row < ncol && col < ncol) ? acc[0][r] : 0.0;
+                }
+            }
+    } else {
+        int idx = 0;
+#pragma unroll
+        for (int tr = 0; tr < TM; ++tr)
+#pragma unroll
+            for (int tc = tr; tc < TM; ++tc) {
+                if (tc < T) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // f64 16x16x4 C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+                        const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
+                        out[row * nfp + col] = (row < ncol && col < ncol) ? acc[idx][r] : 0.0;
+                    }
+                }
+                ++idx;
+            }
+        for (int tc = TM; tc < T; ++tc)
+            for (int tr = 0; tr <= tc; ++tr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ camera system

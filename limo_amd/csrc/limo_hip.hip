@@ -301,7 +301,7 @@ struct limo_ba_batch : Executor {
                 }
             }
             if (any_fast) {
-                schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_lean<1, false, 4> : (const void*)k_schur_lean<2, false, 4>;
+                schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_lean<1, false, 4> : (const void*)k_schur_lean<2, false, 3>;
                 plain_lds_bytes = schur_lean_lds_bytes(max_nfq + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_plain, hipFuncAttributeMaxDynamicSharedMemorySize, plain_lds_bytes));
                 const int tg = (max_nf + 16) / 16;
