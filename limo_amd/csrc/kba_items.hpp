@@ -11,6 +11,9 @@
 #include "kba_lm.hpp"
 #include "kba_math.hpp"
 
+#ifndef KBA_SLAB_ENTRIES
+#define KBA_SLAB_ENTRIES 4
+#endif
 #ifndef KBA_SYNC
 #define KBA_SYNC() ((void)0)
 #endif
@@ -1177,11 +1180,12 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     // alone on the GPU is bound by exactly this latency chain).  Per entry the order of the sum stays q mod 4.
     const int n_need = nf * (nf + 1) / 2 + nf;
     const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : schur_slabs(wd, c.schur_span, c.schur_span_gp);
-    for (int i0 = tid; i0 < n_need; i0 += 4 * nt) {
-        double s[4], acc[4][4];
-        int64_t off[4];
-        int dst[4];
-        for (int e = 0; e < 4; ++e) {
+    constexpr int kE = KBA_SLAB_ENTRIES;  // entries a lane sums at once
+    for (int i0 = tid; i0 < n_need; i0 += kE * nt) {
+        double s[kE], acc[kE][4];
+        int64_t off[kE];
+        int dst[kE];
+        for (int e = 0; e < kE; ++e) {
             const int i = i0 + e * nt;
             dst[e] = -1;
             off[e] = 0;
@@ -1209,11 +1213,11 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
         int q = 0;
         for (; q + 4 <= n_slab; q += 4)
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < kE; ++e)
                 for (int r = 0; r < 4; ++r) acc[e][r] += sp[(int64_t)(q + r) * slab + off[e]];
         for (; q < n_slab; ++q)
-            for (int e = 0; e < 4; ++e) acc[e][0] += sp[(int64_t)q * slab + off[e]];
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < kE; ++e) acc[e][0] += sp[(int64_t)q * slab + off[e]];
+        for (int e = 0; e < kE; ++e)
             if (dst[e] >= 0) A[dst[e]] = s[e] - ((acc[e][0] + acc[e][1]) + (acc[e][2] + acc[e][3]));
     }
     KBA_SYNC();
