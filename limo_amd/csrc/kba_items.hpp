@@ -1392,22 +1392,26 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
 
 
 // After backsub + candidate cost kernels: fold the landmark / observation partials into WinRed (workgroup, red[nt]).
-KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red) {
+// n_work: the lanes that take entries (the first n_work of the nt lanes that meet in the reduction; default all).  The
+// lanes past n_work add zeros, so a 256-lane workgroup with n_work = 64 forms the sums of a 64-lane one (k_solve_wg).
+KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red, int n_work = -1) {
     const WinDesc& wd = bv.win[w];
+    if (n_work < 0) n_work = nt;
     double mcc = 0.0, s2 = 0.0, c2 = 0.0, lfail = 0.0, cost = 0.0, cfail = 0.0;
-    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt) {
+    const int t0 = tid < n_work ? tid : (1 << 28);  // lanes past n_work: every loop below is empty
+    for (int b = wd.lblk0 + t0; b < wd.lblk0 + wd.n_lblk; b += n_work) {
         mcc += bv.lblk_part[(int64_t)b * 8 + 2];
         s2 += bv.lblk_part[(int64_t)b * 8 + 3];
         c2 += bv.lblk_part[(int64_t)b * 8 + 4];
         if (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0) lfail = 1.0;
     }
-    for (int b = wd.lblk0 + tid; b < wd.lblk0 + wd.n_lblk; b += nt) {  // candidate cost of the observations (backsub_lane)
+    for (int b = wd.lblk0 + t0; b < wd.lblk0 + wd.n_lblk; b += n_work) {  // candidate cost of the observations (backsub_lane)
         cost += bv.lblk_part[(int64_t)b * 8 + 6];
         if (bv.lblk_part[(int64_t)b * 8 + 7] != 0.0) cfail = 1.0;
     }
-    for (int g = wd.gp0 + tid; g < wd.gp0 + wd.n_gp; g += nt) cost += bv.gp_cost_c[g];
+    for (int g = wd.gp0 + t0; g < wd.gp0 + wd.n_gp; g += n_work) cost += bv.gp_cost_c[g];
     const int nrows = reg_row_count(wd);
-    for (int i = tid; i < nrows; i += nt) {
+    for (int i = t0; i < nrows; i += n_work) {
         RegRow row;
         int all_const;
         reg_row_eval(wd, bv.cmask, bv.pose_c, bv.pdir_c, bv.pdist_c, i, false, row, all_const);

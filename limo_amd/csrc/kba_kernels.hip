@@ -347,10 +347,19 @@ __global__ void k_view_consts(BatchView bv) {
 // Bytes per pair: 4 (slot) + 12 (u, v, d) read, 56 (planes) written; per landmark 32 read + 72 written - the separate
 // view-major linearise + landmark-major accumulate pair moved 101 + 93 B per observation.
 typedef const double __attribute__((address_space(4))) cdouble;
-template <int WAVES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl_at(bv, wl, blockIdx.x);
-    if (b < 0) return;
+// (the body of k_lin_lm for landmark workgroup b; k_solve_wg runs it for the workgroups of its window one after the other)
+// KVIEW: the view constants are read through the constant address space (scalar loads) - only valid when they were
+// written by an EARLIER launch (k_view_consts); k_solve_wg writes them in the same launch and reads them as plain memory.
+template <bool KVIEW>
+struct ViewPtr {
+    typedef cdouble* type;
+};
+template <>
+struct ViewPtr<false> {
+    typedef const double* type;
+};
+template <bool KVIEW>
+__device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveConsts& c, int b) {
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     in.p[2] = bv.lm[3 * (int64_t)gl + 2];
     in.w = bv.lm_weight[gl];
     const int32_t* slot = bv.lm_slot + gl;
-    cdouble* vc = (cdouble*)(bv.view_lin + (int64_t)kViewLin * wd.view0);
+    typename ViewPtr<KVIEW>::type vc = (typename ViewPtr<KVIEW>::type)(bv.view_lin + (int64_t)kViewLin * wd.view0);
     double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
     extern __shared__ __attribute__((aligned(16))) double lv_lds[];  // [view][wave][kLinPartial]
     const int64_t dump = bv.SO - kObsBlock + threadIdx.x;
@@ -462,12 +471,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
         bv.lblk_linfail[b] = any_fail ? 1.0 : 0.0;
     }
 }
+template <int WAVES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
+    lin_lm_block<true>(bv, c, b);
+}
 __host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }
 
 // ------------------------------------------------------------------------------------------ landmarks
-__global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
-    const int b = wl_at(bv, wl, blockIdx.x);
-    if (b < 0) return;
+__device__ __forceinline__ void lm_damp_block(const BatchView& bv, const SolveConsts& c, int b) {
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active || !bv.st[w].redamp) return;  // after a linearisation k_lin_lm has damped already
     int fail = 0;
@@ -475,11 +488,14 @@ __global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c,
     const int any = __syncthreads_or(fail);
     if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 5] = any ? 1.0 : 0.0;
 }
-
-// back-substitution of the landmarks + the cost of their observations at the candidate point (kba_items.hpp:backsub_lane)
-__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c, const int32_t* wl) {
+__global__ __launch_bounds__(kBlock) void k_lm_damp(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
+    lm_damp_block(bv, c, b);
+}
+
+// back-substitution of the landmarks + the cost of their observations at the candidate point (kba_items.hpp:backsub_lane)
+__device__ __forceinline__ void backsub_block(const BatchView& bv, const SolveConsts& c, int b) {
     const int w = bv.lblk_win[b];
     if (!bv.st[w].active) return;
     __shared__ double lds[16];
@@ -505,6 +521,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c,
         bv.lblk_part[(int64_t)b * 8 + slot] = (lds[threadIdx.x] + lds[4 + threadIdx.x]) + (lds[8 + threadIdx.x] + lds[12 + threadIdx.x]);
     }
     if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 7] = any_fail ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
+    backsub_block(bv, c, b);
 }
 
 // ------------------------------------------------------------------------------------------ Schur complement (MFMA)
@@ -1141,13 +1162,7 @@ __device__ __forceinline__ bool trim_less(double ka, int ia, double kb, int ib) 
 }
 
 // (streaming solve: the windows whose trimming solve ended this round; afterwards their next solve is armed)
-__global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConsts c) {
-    int w = blockIdx.x;
-    if (bv.counted) {
-        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_TWIN] + 1;
-        if ((int)blockIdx.x >= wl[-1]) return;
-        w = wl[blockIdx.x];
-    }
+__device__ __forceinline__ void trim_select_win(const BatchView& bv, const SolveConsts& c, int w) {
     const WinDesc& wd = bv.win[w];
     if (!wd.do_trim) return;
     const int n = wd.n_lm;
@@ -1298,9 +1313,127 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
         }
     }
     if (removed) atomicAdd(&bv.st[w].n_trimmed, removed);
+}
+__global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConsts c) {
+    int w = blockIdx.x;
+    if (bv.counted) {
+        const int32_t* wl = bv.sched_lists + bv.sched_off[SL_TWIN] + 1;
+        if ((int)blockIdx.x >= wl[-1]) return;
+        w = wl[blockIdx.x];
+    }
+    if (!bv.win[w].do_trim) return;
+    trim_select_win(bv, c, w);
     if (bv.counted) {
         __syncthreads();
         if (threadIdx.x == 0) sched_after_trim(bv.st[w], c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ a whole solve in one launch
+// k_solve_wg: ONE 256-lane workgroup per window runs the complete solveTrimmed schedule of its window (kba_pack.cpp:
+// run_schedule: trimming solves, retries, quantile trimming, final solve) - the phases the lock-step solve launches as
+// kernels are the same device functions here, separated by workgroup barriers instead of launch boundaries, the landmark
+// workgroups of the window taken one after the other.  For windows WITHOUT free landmarks (adjustPoseOnly,
+// bundle_adjuster_keyframes.cpp:769-904: one keyframe against fixed landmarks, a few hundred observations): their
+// solve is 9 LM iterations of 8 launches that each run for 4-10 us and wait 3 us for the next one; here the iteration is a
+// few microseconds of work and six barriers.  Same arithmetic, same summation orders as the launches it replaces:
+// the results are bit-identical (tests/test_gpu_parity.py compares the two paths).
+//   * the view constants are written and read in the same launch: plain loads (lin_lm_block<false>), not the scalar
+//     cache the multi-launch kernel reads them through;
+//   * the step reduction of k_step_decide is a 64-lane sum: reduce_step(.., n_work = 64) forms exactly that one;
+//   * cap_ticks > 0: wall-clock cap of each solve in ticks of the 100 MHz constant clock (Solver::Options::
+//     max_solver_time_in_seconds as run_schedule applies it: checked once per iteration after the linearisation).
+__global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c, long long cap_ticks, double* plane_rep, double* plane_dep) {
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x;
+    const WinDesc& wd = bv.win[w];
+    WinState& st = bv.st[w];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int flag;
+    __shared__ double red[6 * (kBlock / 64)];
+    const int64_t so = wd.cam_scr_off;
+    const int lb0 = wd.lblk0, lb1 = wd.lblk0 + wd.n_lblk;
+    // The window's LM state is written by lane 0 only, and only behind a barrier that every lane passes AFTER its last
+    // read of the state: all lanes take the same branches.
+    // run_schedule: per trimming round [solve(trim_iters, windows that trim), solve(3 trim_iters, of those the ones whose
+    // cost did not drop), trim], then solve(max_iters, all) - one loop over the solves, so the body exists once.
+    const int n_solves = 2 * c.num_trim_rounds + 1;
+    for (int si = 0; si < n_solves; ++si) {
+        const bool final_solve = si == n_solves - 1, retry = !final_solve && (si & 1);
+        const int max_iter = final_solve ? c.max_iters : (retry ? 3 * c.trim_iters : c.trim_iters);
+        __syncthreads();
+        if (tid == 0) {  // k_solve_init
+            bool sel = true;
+            if (!final_solve) sel = wd.do_trim != 0;
+            if (retry) sel = sel && (st.solve_initial_cost - st.solve_final_cost <= 0.0);
+            lm_solve_init(st, sel, max_iter, c);
+        }
+        __syncthreads();
+        const long long t0 = cap_ticks > 0 ? (long long)wall_clock64() : 0ll;
+        for (;;) {
+            // ---- linearize(): k_view_consts, k_lin_lm, k_cam_assemble
+            if (st.active && st.need_lin) {
+                if (tid < wd.n_view) view_consts_item(bv, wd.view0 + tid);
+                __syncthreads();
+                for (int b = lb0; b < lb1; ++b) {
+                    lin_lm_block<false>(bv, c, b);
+                    __syncthreads();
+                }
+                if (so >= 0)
+                    cam_assemble(bv, c, w, tid, kBlock, bv.cam_scratch + so);
+                else
+                    cam_assemble(bv, c, w, tid, kBlock, smem);
+                __syncthreads();
+                if (tid == 0) lm_decide_lin(st, bv.red[w], bv.reg_cost[2 * w + 1], c);
+                __syncthreads();
+            }
+            int active = st.active;
+            if (cap_ticks > 0) {
+                __syncthreads();
+                if (tid == 0 && active && (long long)wall_clock64() - t0 >= cap_ticks) lm_terminate(st, LIMO_NO_CONVERGENCE);  // k_expire
+                __syncthreads();
+                active = st.active;
+            }
+            if (!active) break;
+            // ---- step(): k_lm_damp, (no Schur blocks: no free landmark), k_cam_solve, k_backsub, k_step_decide, k_accept
+            if (st.redamp) {
+                for (int b = lb0; b < lb1; ++b) lm_damp_block(bv, c, b);
+                __syncthreads();
+            }
+            if (so >= 0)
+                cam_solve(bv, c, w, tid, kBlock, bv.cam_scratch + so, &flag);
+            else
+                cam_solve(bv, c, w, tid, kBlock, smem, &flag);
+            __syncthreads();
+            for (int b = lb0; b < lb1; ++b) {
+                backsub_block(bv, c, b);
+                __syncthreads();
+            }
+            reduce_step(bv, w, tid, kBlock, red, 64);
+            __syncthreads();
+            if (tid == 0) lm_decide_step(st, bv.red[w], c);
+            __syncthreads();
+            if (st.accept) {
+                if (tid < wd.n_kf) {
+                    const int64_t i = wd.kf0 + tid;
+                    for (int q = 0; q < 7; ++q) bv.pose[7 * i + q] = bv.pose_c[7 * i + q];
+                    for (int q = 0; q < 3; ++q) bv.pdir[3 * i + q] = bv.pdir_c[3 * i + q];
+                    bv.pdist[i] = bv.pdist_c[i];
+                }
+                for (int64_t l = wd.lm0 + tid; l < wd.lm0 + wd.n_lm; l += kBlock)
+                    for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
+            }
+            __syncthreads();
+        }
+        if (retry && wd.do_trim) {  // trim(): k_trim_residual, k_trim_max, k_trim_select
+            __syncthreads();
+            for (int b = wd.blk0; b < wd.blk0 + wd.n_blk; ++b)
+                for (int q = 0; q < kObsPerLane; ++q) trim_residual_lane(bv, b, tid + q * kBlock, plane_rep, plane_dep);
+            __syncthreads();
+            for (int l = wd.lm0 + tid; l < wd.lm0 + wd.n_lm; l += kBlock) trim_max_lane(bv, l, plane_rep, plane_dep);
+            __syncthreads();
+            trim_select_win(bv, c, w);
+        }
     }
 }
 

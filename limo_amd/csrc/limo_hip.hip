@@ -53,6 +53,7 @@ struct limo_ba_batch : Executor {
     double *d_plane_rep = nullptr, *d_plane_dep = nullptr;
     double *d_pose0 = nullptr, *d_pdir0 = nullptr, *d_pdist0 = nullptr, *d_lm0 = nullptr;
     uint8_t* d_lm_state0 = nullptr;
+    std::vector<WinState> st0;  // reset image of the LM state
     int32_t* h_active = nullptr;  // pinned, 4 slots: written by k_cam_assemble, read by the host one iteration later
     int32_t* d_h_active = nullptr;  // the same words as the device sees them
     size_t h_flags_bytes = 0;
@@ -186,6 +187,13 @@ struct limo_ba_batch : Executor {
         };
         std::vector<Ent> ents;
         for_each_buffer(P, bv, [&](void** slot, size_t bytes, const void* init) { ents.push_back({slot, bytes ? bytes : 8, 0, init}); });
+        // the LM state starts from its reset image (reset_state restores exactly this), uploaded with everything else: a
+        // fresh batch needs no reset pass (six copies and a stream drain per single-window call)
+        st0.assign(P.n_win, WinState());
+        std::memset(st0.data(), 0, sizeof(WinState) * st0.size());
+        for (auto& q : st0) q.term = -1;
+        for (Ent& e : ents)
+            if (e.slot == (void**)&bv.st) e.init = st0.data();
         // the pristine copies limo_ba_batch_reset restores from
         ents.push_back({(void**)&d_pose0, sizeof(double) * 7 * std::max(1, P.TK), 0, P.pose.empty() ? nullptr : P.pose.data()});
         ents.push_back({(void**)&d_pdir0, sizeof(double) * 3 * std::max(1, P.TK), 0, P.pdir.empty() ? nullptr : P.pdir.data()});
@@ -344,20 +352,16 @@ struct limo_ba_batch : Executor {
         for (auto& e : act_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreate(&ev_total_a));
         HIP_TRY(ctx, hipEventCreate(&ev_total_b));
-        return reset_state();
+        return LIMO_OK;
     }
 
     int reset_state() {
-        std::vector<WinState> st(P.n_win);
-        std::memset(st.data(), 0, sizeof(WinState) * st.size());
-        for (auto& s : st) s.term = -1;
-        HIP_TRY(ctx, hipMemcpyAsync(bv.st, st.data(), sizeof(WinState) * st.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(bv.st, st0.data(), sizeof(WinState) * st0.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.pose, d_pose0, sizeof(double) * 7 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.pdir, d_pdir0, sizeof(double) * 3 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.pdist, d_pdist0, sizeof(double) * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.lm, d_lm0, sizeof(double) * 3 * P.TL, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.lm_state, d_lm_state0, P.TL, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // st vector goes out of scope
         return LIMO_OK;
     }
 
@@ -818,6 +822,28 @@ struct limo_ba_batch : Executor {
         note(hipEventRecord(g.round_ev[round & 3], s), "record round");
     }
 
+    // ---- a whole solve in ONE launch (kba_kernels.hip:k_solve_wg): windows without free landmarks - adjustPoseOnly -
+    // whose landmark workgroups a single workgroup walks through in a few microseconds.  KBA_NO_WG_SOLVE=1 (read per
+    // call) keeps the lock-step launches: the tests compare the two paths bit by bit.
+    static constexpr int kWgMaxLblk = 8;  // <= 2048 landmarks per window
+    bool wg_solve_applies() const {
+        if (shard_P != 1 || P.evaluate_only || P.n_sblk != 0 || P.n_win < 1) return false;
+        if (const char* e = std::getenv("KBA_NO_WG_SOLVE"))
+            if (std::atoi(e) != 0) return false;
+        for (const WinDesc& d : P.win)
+            if (d.n_lblk > kWgMaxLblk) return false;
+        return wg_lds_bytes() <= kCamLdsCapBytes;
+    }
+    int wg_lds_bytes() const { return std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax))); }
+    void solve_wg() {
+        const int lds = wg_lds_bytes();
+        set_span(P.n_win);
+        note(hipFuncSetAttribute((const void*)k_solve_wg, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(k_solve_wg)");
+        const long long cap_ticks = opts.max_solver_time_sec > 0.0 ? std::max(1ll, (long long)(opts.max_solver_time_sec * 1e8)) : 0ll;
+        hipLaunchKernelGGL(k_solve_wg, dim3(P.n_win), dim3(kBlock), lds, ctx->stream, bv, c, cap_ticks, d_plane_rep, d_plane_dep);
+        LAUNCH_CHECK("k_solve_wg");
+    }
+
     // The host only enqueues; it learns that all windows are done from a pinned word the scheduler writes, two rounds
     // late (so the streams never drain inside a solve).
     int solve_streaming() {
@@ -1027,6 +1053,8 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     const int stream_min = std::getenv("KBA_STREAM_MIN") ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;  // (read per call: the tests switch paths)
     if (b->shard_P == 1 && b->opts.max_solver_time_sec <= 0.0 && b->P.n_win >= stream_min && !b->P.evaluate_only)
         b->solve_streaming();
+    else if (b->wg_solve_applies())
+        b->solve_wg();
     else
         run_schedule(*b, b->opts);
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
@@ -1059,14 +1087,48 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
     if (!b) return LIMO_ERR_INVALID;
     limo_ctx* ctx = b->ctx;
     const PackedBatch& P = b->P;
-    std::vector<double> pose((size_t)P.TK * 7), pdir((size_t)P.TK * 3), pdist(P.TK), lm((size_t)P.TL * 3);
-    std::vector<WinState> st(P.n_win);
-    HIP_TRY(ctx, hipMemcpyAsync(pose.data(), b->bv.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(pdir.data(), b->bv.pdir, sizeof(double) * pdir.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(pdist.data(), b->bv.pdist, sizeof(double) * pdist.size(), hipMemcpyDeviceToHost, ctx->stream));
-    if (P.TL) HIP_TRY(ctx, hipMemcpyAsync(lm.data(), b->bv.lm, sizeof(double) * lm.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(st.data(), b->bv.st, sizeof(WinState) * st.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> pose_v, pdir_v, pdist_v, lm_v;
+    std::vector<WinState> st_v;
+    const double *pose = nullptr, *pdir = nullptr, *pdist = nullptr, *lm = nullptr;
+    const WinState* st = nullptr;
+    {
+        // [st | pose | pdir | pdist | lm] are neighbours in the batch's device block (kba_buffers.hpp order, upload()):
+        // a small batch comes back with ONE copy into the context's pinned staging buffer instead of five into pageable
+        // vectors (each of those is a blocking staged copy inside the runtime).
+        const char* lo = reinterpret_cast<const char*>(b->bv.st);
+        const char* hi = reinterpret_cast<const char*>(b->bv.lm) + sizeof(double) * 3 * (size_t)P.TL;
+        auto inside = [&](const void* q) { return reinterpret_cast<const char*>(q) >= lo && reinterpret_cast<const char*>(q) < hi; };
+        const bool one_span = hi > lo && (size_t)(hi - lo) <= ctx->staging_cap && ctx->staging && inside(b->bv.pose) && inside(b->bv.pdir) &&
+                              inside(b->bv.pdist) && (P.TL == 0 || inside(b->bv.lm));
+        if (one_span) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->staging, lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const char* h = static_cast<const char*>(ctx->staging);
+            auto at = [&](const void* q) { return h + (reinterpret_cast<const char*>(q) - lo); };
+            st = reinterpret_cast<const WinState*>(at(b->bv.st));
+            pose = reinterpret_cast<const double*>(at(b->bv.pose));
+            pdir = reinterpret_cast<const double*>(at(b->bv.pdir));
+            pdist = reinterpret_cast<const double*>(at(b->bv.pdist));
+            lm = reinterpret_cast<const double*>(at(b->bv.lm));
+        } else {
+            pose_v.resize((size_t)P.TK * 7);
+            pdir_v.resize((size_t)P.TK * 3);
+            pdist_v.resize(P.TK);
+            lm_v.resize((size_t)P.TL * 3);
+            st_v.resize(P.n_win);
+            HIP_TRY(ctx, hipMemcpyAsync(pose_v.data(), b->bv.pose, sizeof(double) * pose_v.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(pdir_v.data(), b->bv.pdir, sizeof(double) * pdir_v.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(pdist_v.data(), b->bv.pdist, sizeof(double) * pdist_v.size(), hipMemcpyDeviceToHost, ctx->stream));
+            if (P.TL) HIP_TRY(ctx, hipMemcpyAsync(lm_v.data(), b->bv.lm, sizeof(double) * lm_v.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(st_v.data(), b->bv.st, sizeof(WinState) * st_v.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            pose = pose_v.data();
+            pdir = pdir_v.data();
+            pdist = pdist_v.data();
+            lm = lm_v.data();
+            st = st_v.data();
+        }
+    }
     for (int w = 0; w < P.n_win; ++w) {
         const WinDesc& d = P.win[w];
         if (windows_out) {
@@ -1075,11 +1137,11 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
                 ctx->err = "download: window shape differs from create()";
                 return LIMO_ERR_INVALID;
             }
-            std::memcpy(W.kf_pose, pose.data() + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
-            std::memcpy(W.kf_plane_dir, pdir.data() + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
-            std::memcpy(W.kf_plane_dist, pdist.data() + d.kf0, sizeof(double) * d.n_kf);
+            std::memcpy(W.kf_pose, pose + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
+            std::memcpy(W.kf_plane_dir, pdir + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
+            std::memcpy(W.kf_plane_dist, pdist + d.kf0, sizeof(double) * d.n_kf);
             for (int l = 0; l < d.n_lm; ++l)  // packed order -> the caller's landmark order
-                std::memcpy(W.lm_pos + 3 * (size_t)P.lm_id[d.lm0 + l], lm.data() + 3 * (size_t)(d.lm0 + l), sizeof(double) * 3);
+                std::memcpy(W.lm_pos + 3 * (size_t)P.lm_id[d.lm0 + l], lm + 3 * (size_t)(d.lm0 + l), sizeof(double) * 3);
         }
         if (reports) {
             limo_ba_report& r = reports[w];
@@ -1207,6 +1269,31 @@ int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_o
     return rc;
 }
 
+// One window per call (limo_ba_solve, limo_ba_adjust_pose_only): create, solve, download, destroy.
+// KBA_HOST_TRACE=1 prints where the host time of the call goes.
+static int solve_one(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, const PackOptions& po, limo_ba_report* report,
+                     const char* what) {
+    using Clock = std::chrono::steady_clock;
+    static const bool trace = std::getenv("KBA_HOST_TRACE") != nullptr;
+    const auto t_a = Clock::now();
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, po, &b);
+    if (rc != LIMO_OK) return rc;
+    const auto t0 = Clock::now();
+    rc = limo_ba_batch_solve(b, nullptr);
+    const auto t1 = Clock::now();
+    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
+    const auto t2 = Clock::now();
+    if (report) report->time_sec = std::chrono::duration<double>(t2 - t0).count();
+    limo_ba_batch_destroy(b);
+    if (trace) {
+        auto us = [](Clock::time_point a, Clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+        std::fprintf(stderr, "[kba] %s: create %.0f us, solve %.0f us, download %.0f us, destroy %.0f us\n", what, us(t_a, t0), us(t0, t1), us(t1, t2),
+                     us(t2, Clock::now()));
+    }
+    return rc;
+}
+
 int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3) {
     if (!ctx || !stats3) return LIMO_ERR_INVALID;
     for (int i = 0; i < 3; ++i) stats3[i] = ctx->exchange_stats[i];
@@ -1215,15 +1302,7 @@ int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3) {
 
 int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report) {
     if (!ctx || !window) return LIMO_ERR_INVALID;
-    limo_ba_batch* b = nullptr;
-    int rc = batch_create_impl(ctx, 1, window, opts, PackOptions(), &b);
-    if (rc != LIMO_OK) return rc;
-    const auto t0 = std::chrono::steady_clock::now();
-    rc = limo_ba_batch_solve(b, nullptr);
-    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
-    if (report) report->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    limo_ba_batch_destroy(b);
-    return rc;
+    return solve_one(ctx, window, opts, PackOptions(), report, "limo_ba_solve");
 }
 
 int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_speed_prior* prior,
@@ -1232,15 +1311,7 @@ int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_s
     PackOptions po;
     po.pose_only = true;
     po.prior = prior;
-    limo_ba_batch* b = nullptr;
-    int rc = batch_create_impl(ctx, 1, window, opts, po, &b);
-    if (rc != LIMO_OK) return rc;
-    const auto t0 = std::chrono::steady_clock::now();
-    rc = limo_ba_batch_solve(b, nullptr);
-    if (rc == LIMO_OK) rc = limo_ba_batch_download(b, window, report);
-    if (report) report->time_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    limo_ba_batch_destroy(b);
-    return rc;
+    return solve_one(ctx, window, opts, po, report, "limo_ba_adjust_pose_only");
 }
 
 int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_options* opts, int apply_loss,

@@ -165,6 +165,29 @@ def test_pose_only_matches_oracle(ctx, oracle, with_prior):
     assert np.array_equal(pg.lm_pos, pw.lm_pos)
 
 
+@pytest.mark.parametrize("seed", [71, 72, 73, 74])
+@pytest.mark.parametrize("cap", [-1.0, 20.0])
+def test_pose_only_one_launch_equals_lock_step(ctx, seed, cap, monkeypatch):
+    """adjustPoseOnly runs its whole solveTrimmed schedule in ONE launch (kba_kernels.hip:k_solve_wg: the device functions
+    of the lock-step kernels behind workgroup barriers).  Same arithmetic, same summation orders: the result must be
+    bit-identical to the launch-per-phase path (KBA_NO_WG_SOLVE=1), with and without a wall-clock cap, with and without
+    the speed prior, trimming included."""
+    pw, prior, _ = make_pose_only_case(seed)
+    o = default_options(min_landmarks_for_trimming=30, max_solver_time_sec=cap)
+    for pr in (None, prior):
+        a, b = pw.copy(), pw.copy()
+        monkeypatch.delenv("KBA_NO_WG_SOLVE", raising=False)
+        ra = ctx.adjust_pose_only(a, pr, o)
+        monkeypatch.setenv("KBA_NO_WG_SOLVE", "1")
+        rb = ctx.adjust_pose_only(b, pr, o)
+        monkeypatch.delenv("KBA_NO_WG_SOLVE", raising=False)
+        assert a.kf_pose.tobytes() == b.kf_pose.tobytes()
+        for k in ("final_cost", "initial_cost", "iterations_total", "iterations_final", "num_solves", "n_trimmed_landmarks", "termination",
+                  "successful_steps", "num_linearizations"):
+            assert ra[k] == rb[k], (k, ra[k], rb[k])
+        assert ra["n_trimmed_landmarks"] > 0 and ra["num_solves"] >= 2  # the trimming branch ran
+
+
 def test_committed_golden_fixtures(ctx):
     """GPU results against tests/golden/oracle_windows.json (oracle outputs committed with their generator), so the
     GPU tier has fixed targets that do not depend on the oracle being rebuilt on the GPU box."""
