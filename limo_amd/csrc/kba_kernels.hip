@@ -685,10 +685,22 @@ __host__ __device__ inline int schur_lean_lds_bytes(int ncol) {
     return (3 * kSchurLm * schur_lean_ld(ncol) + 16 + 4 * kSpKf) * (int)sizeof(double) + 4 * 12 * (int)sizeof(int);
 }
 
-template <int TM, bool GP, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(BatchView bv, const int32_t* wl, int span, int span_gp) {
-    const int sb = wl_at(bv, wl, blockIdx.x);
-    if (sb < 0) return;
+// The group of Schur blocks that starts at block sb, by ONE wave.  COOP = false: the wave is the whole workgroup
+// (k_schur_lean).  COOP = true: the wave is one of several in a workgroup that work on different groups at the same time
+// (k_solve_coop) - it may not meet the others at a workgroup barrier, so the LDS hand-offs inside the wave are ordered by
+// fences alone (the LDS operations of one wave complete in order), and `smem` is the wave's own LDS region.
+template <bool COOP>
+__device__ __forceinline__ void schur_wave_sync() {
+    if constexpr (COOP) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+template <int TM, bool GP, bool COOP>
+__device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, int span, int span_gp, double* smem) {
     const int w = bv.sblk_win[sb];
     if (!bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
@@ -704,11 +716,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // bits (same products, same k order); the rhs entries are summed in another order.
     constexpr bool kTT = !GP && TM == 2;  // (plain blocks of fast windows have <= 4 free keyframes: nfq <= 24)
     const bool two_tile = kTT && Tt == 2;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Z = smem;                                   // [48][ld] + 16 zeros (the last row's panel overrun)
     double* kc = Z + 3 * kSchurLm * ld + 16;            // [4][kSpKf]
     int* zcs = reinterpret_cast<int*>(kc + 4 * kSpKf);  // [4][12] tile column of the keyframe's slots (or -1)
-    const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4;
+    const int lane = COOP ? (int)(threadIdx.x & 63) : (int)threadIdx.x, li = lane & 15, kq = lane >> 4;
     const int n_fk = wd.n_fk;
     int my_view = -1, my_kl = -1;
     if (kq < n_fk) {
@@ -734,7 +745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
     }
     if (lane < 16) Z[3 * kSchurLm * ld + lane] = 0.0;
-    __syncthreads();
+    schur_wave_sync<COOP>();
     const bool have = kq < n_fk && zcs[kq * 12] >= 0;  // the keyframe's pose block is free (its six slots together)
     const double* mine = kc + (kq < n_fk ? kq : 0) * kSpKf;
     const int32_t* my_slots = bv.lm_slot + (int64_t)(my_view >= 0 ? my_view - wd.view0 : 0) * bv.SL;
@@ -861,7 +872,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             fetch_index(l0 + 2 * kSchurLm, n_st, n_slot, n_gg);
             fetch_data(l0 + kSchurLm, st, slot, gg);
         }
-        __syncthreads();
+        schur_wave_sync<COOP>();
         // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps, upper tiles
         const double* zp = Z + kq * ld + li;
         if (TM == 1 || Tt == 1) {  // wave-uniform
@@ -933,7 +944,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
             }
         }
-        __syncthreads();
+        schur_wave_sync<COOP>();
     }
     // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix.  Entries outside the tile's columns are zero
     //      for these landmarks and must be written: the slab may have belonged to a group of the other class at
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // the slab is written in the layout of the three-tile path (upper tiles, zeros outside the Gram)
         double* St = Z;  // 1024 doubles <= 48 * ld
         for (int i = lane; i < 1024; i += 64) St[i] = 0.0;
-        __syncthreads();
+        schur_wave_sync<COOP>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = kq + 4 * r;
@@ -969,7 +980,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 if (li == 0) St[(zcs[kq * 12] + a) * 32 + nfq] = v;
             }
         }
-        __syncthreads();
+        schur_wave_sync<COOP>();
         for (int tc = 0; tc < T; ++tc)
             for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
@@ -1011,6 +1022,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
             }
     }
+}
+template <int TM, bool GP, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(BatchView bv, const int32_t* wl, int span, int span_gp) {
+    const int sb = wl_at(bv, wl, blockIdx.x);
+    if (sb < 0) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    schur_lean_group<TM, GP, false>(bv, sb, span, span_gp, smem);
 }
 
 // ------------------------------------------------------------------------------------------ camera system
@@ -1435,6 +1453,248 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
             trim_select_win(bv, c, w);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ one window, one launch, G workgroups
+// k_solve_coop: the complete solveTrimmed schedule of a window WITH free landmarks in one cooperative launch - G workgroups
+// of 256 lanes per window that meet at device-wide barriers (coop_sync: 2.7 us at 9 workgroups, scripts/micro/
+// grid_barrier.hip) where the lock-step solve has launch boundaries.  The single-window mode is what the reference runs
+// (mono_lidar.cpp:203,255: one solve() per keyframe); its LM iteration was ten dependent launches, 165 us of kernels that
+// each end on the critical path of one workgroup + 40 us between them.  Here an iteration is five barriers:
+//     [re-linearise: k_lin_lm bodies, or re-damp]  |  [workgroup 0: camera system (k_cam_assemble body) WHILE the waves
+//     of the other workgroups form the Schur complement (k_schur_lean bodies, one group of blocks per wave)]  |
+//     [workgroup 0: k_cam_solve body]  |  [k_backsub bodies]  |  [workgroup 0: step decision, accepted poses, view
+//     constants]
+// (the first linearisation of a solve computes the Jacobi scaling of the camera columns the Schur blocks are scaled with:
+// there the camera system comes first, one more barrier).  Same device functions, same partitions, same summation orders
+// as the launches: bit-identical results (tests/test_gpu_ba.py).  Fast-class windows only (WinDesc::schur_fast, camera
+// system in LDS); a barrier that is not met within half a second aborts the launch (pinned flag), it cannot hang the GPU.
+struct CoopParams {
+    int32_t G;                 // workgroups per window
+    int32_t vp, vg;            // k_schur_lean variant (TM) of the plain / ground-plane groups
+    int32_t schur_lds;         // doubles of LDS per wave in the Schur phase
+    long long cap_ticks;       // wall-clock cap of a solve (100 MHz ticks), 0: none
+    int32_t* bar;              // [n_win][4] {arrived, generation, abort, -}, zeroed before the launch
+    int32_t* abort_host;       // pinned: set when a barrier timed out
+    double *plane_rep, *plane_dep;
+};
+
+__device__ __forceinline__ bool coop_sync(int32_t* bar, int G, int& gen, int32_t* abort_host) {
+    if (G == 1) {
+        __syncthreads();
+        return true;
+    }
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __threadfence();  // the workgroup's writes (ordered before lane 0 by the barrier above) leave this XCD's L2
+        const int arrived = __hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == G - 1) {
+            __hip_atomic_store(&bar[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t0 = wall_clock64();
+            // (relaxed polls: an acquire load invalidates this XCD's L2 on EVERY poll - under the workgroup that is working;
+            // the fence behind the loop does it once)
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > 50000000ll) {
+                    __hip_atomic_store(&bar[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(volatile int32_t*)abort_host = 1;
+                    __threadfence_system();
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __threadfence();  // ... and what the others wrote is fetched again
+    }
+    ++gen;
+    return __syncthreads_and(ok) != 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts c, CoopParams a) {
+    const int G = a.G, w = blockIdx.x / G, g = blockIdx.x % G;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const WinDesc& wd = bv.win[w];
+    WinState& st = bv.st[w];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int flag;
+    __shared__ double red[6 * (kBlock / 64)];
+    int32_t* bar = a.bar + 4 * w;
+    int gen = 0;
+#ifdef KBA_COOP_TICKS  // debug build: where the time of workgroups 0, 1 and G - 1 of window 0 goes (100 MHz ticks)
+    long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = wall_clock64();
+#define KBA_CTICK(i)                         \
+    do {                                    \
+        const long long n_ = wall_clock64(); \
+        tk[i] += n_ - tl;                   \
+        tl = n_;                            \
+    } while (0)
+#else
+#define KBA_CTICK(i)
+#endif
+#define KBA_GSYNC()                                        \
+    do {                                                   \
+        if (!coop_sync(bar, G, gen, a.abort_host)) return; \
+    } while (0)
+    const int lb0 = wd.lblk0, lb1 = wd.lblk0 + wd.n_lblk;
+    const int n_pg = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
+    const int n_gg = (wd.n_sblk - wd.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+    // Schur phase: the groups of blocks of the window dealt over the waves of the workgroups from `first_worker` on
+    auto schur_phase = [&](int first_worker) __attribute__((always_inline)) {
+        if (g < first_worker) return;
+        const int n_workers = (G - first_worker) * (kBlock / 64);
+        double* mine = smem + (size_t)wave * a.schur_lds;
+        for (int t = (g - first_worker) * (kBlock / 64) + wave; t < n_pg + n_gg; t += n_workers) {
+            if (t < n_pg) {
+                const int sb = wd.sblk0 + t * c.schur_span;
+                if (a.vp == 1)
+                    schur_lean_group<1, false, true>(bv, sb, c.schur_span, c.schur_span_gp, mine);
+                else
+                    schur_lean_group<2, false, true>(bv, sb, c.schur_span, c.schur_span_gp, mine);
+            } else {
+                const int sb = wd.sblk0 + wd.n_sblk_plain + (t - n_pg) * c.schur_span_gp;
+                if (a.vg == 1)
+                    schur_lean_group<1, true, true>(bv, sb, c.schur_span, c.schur_span_gp, mine);
+                else if (a.vg == 2)
+                    schur_lean_group<2, true, true>(bv, sb, c.schur_span, c.schur_span_gp, mine);
+                else
+                    schur_lean_group<3, true, true>(bv, sb, c.schur_span, c.schur_span_gp, mine);
+            }
+            schur_wave_sync<true>();  // the wave's LDS region is reused by its next group
+        }
+    };
+    // The window's LM state is written by lane 0 of workgroup 0 only, and only between two barriers of which the first
+    // comes after every other reader's last use of the old value: all workgroups take the same branches.
+    const int n_solves = 2 * c.num_trim_rounds + 1;
+    for (int si = 0; si < n_solves; ++si) {
+        const bool final_solve = si == n_solves - 1, retry = !final_solve && (si & 1);
+        const int max_iter = final_solve ? c.max_iters : (retry ? 3 * c.trim_iters : c.trim_iters);
+        KBA_GSYNC();
+        if (g == 0) {
+            if (tid == 0) {  // k_solve_init
+                bool sel = true;
+                if (!final_solve) sel = wd.do_trim != 0;
+                if (retry) sel = sel && (st.solve_initial_cost - st.solve_final_cost <= 0.0);
+                lm_solve_init(st, sel, max_iter, c);
+            }
+            __syncthreads();
+            if (st.active && st.need_lin && tid < wd.n_view) view_consts_item(bv, wd.view0 + tid);  // k_view_consts
+        }
+        KBA_GSYNC();
+        const long long t0 = a.cap_ticks > 0 ? (long long)wall_clock64() : 0ll;
+        for (;;) {
+            if (st.active && st.need_lin) {
+                const bool scale_first = st.compute_scale != 0 || G == 1;
+                // ---- k_lin_lm
+                for (int b = lb0 + g; b < lb1; b += G) {
+                    lin_lm_block<false>(bv, c, b);
+                    __syncthreads();
+                }
+                KBA_CTICK(0);
+                KBA_GSYNC();
+                KBA_CTICK(1);
+                // ---- k_cam_assemble (workgroup 0) and the Schur complement (everybody else, or everybody afterwards)
+                if (g == 0) {
+                    cam_assemble(bv, c, w, tid, kBlock, smem);
+                    __syncthreads();
+                    if (tid == 0) lm_decide_lin(st, bv.red[w], bv.reg_cost[2 * w + 1], c);
+                }
+                KBA_CTICK(2);
+                if (scale_first) {
+                    KBA_GSYNC();
+                    KBA_CTICK(3);
+                    schur_phase(0);
+                } else {
+                    schur_phase(1);
+                }
+                KBA_CTICK(4);
+            } else {
+                // ---- k_lm_damp (after a rejected step), then the Schur complement
+                for (int b = lb0 + g; b < lb1; b += G) lm_damp_block(bv, c, b);
+                KBA_CTICK(13);
+                KBA_GSYNC();
+                KBA_CTICK(1);
+                schur_phase(0);
+                KBA_CTICK(4);
+            }
+            KBA_GSYNC();
+            KBA_CTICK(5);
+            if (a.cap_ticks > 0) {
+                if (g == 0 && tid == 0 && st.active && (long long)wall_clock64() - t0 >= a.cap_ticks) lm_terminate(st, LIMO_NO_CONVERGENCE);  // k_expire
+                KBA_GSYNC();
+            }
+            if (!st.active) break;
+            // ---- k_cam_solve
+            if (g == 0) cam_solve(bv, c, w, tid, kBlock, smem, &flag);
+            KBA_CTICK(6);
+            KBA_GSYNC();
+            KBA_CTICK(7);
+            // ---- k_backsub
+            for (int b = lb0 + g; b < lb1; b += G) {
+                backsub_block(bv, c, b);
+                __syncthreads();
+            }
+            KBA_CTICK(8);
+            KBA_GSYNC();
+            KBA_CTICK(9);
+            // ---- k_step_decide, the keyframe part of k_accept, k_view_consts of the next linearisation
+            if (g == 0) {
+                reduce_step(bv, w, tid, kBlock, red, 64);
+                __syncthreads();
+                if (tid == 0) lm_decide_step(st, bv.red[w], c);
+                __syncthreads();
+                if (st.accept && tid < wd.n_kf) {
+                    const int64_t i = wd.kf0 + tid;
+                    for (int q = 0; q < 7; ++q) bv.pose[7 * i + q] = bv.pose_c[7 * i + q];
+                    for (int q = 0; q < 3; ++q) bv.pdir[3 * i + q] = bv.pdir_c[3 * i + q];
+                    bv.pdist[i] = bv.pdist_c[i];
+                }
+                __syncthreads();
+                if (st.active && st.need_lin && tid < wd.n_view) view_consts_item(bv, wd.view0 + tid);
+            }
+            KBA_CTICK(10);
+            KBA_GSYNC();
+            KBA_CTICK(11);
+            // ---- the landmark part of k_accept: every workgroup moves the landmarks it linearises next
+            if (st.accept) {
+                for (int b = lb0 + g; b < lb1; b += G)
+                    if (tid < bv.lblk_n[b]) {
+                        const int64_t l = bv.lblk_lm0[b] + tid;
+                        for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
+                    }
+            }
+        }
+        if (retry && wd.do_trim) {  // trim(): k_trim_residual, k_trim_max, k_trim_select
+            KBA_GSYNC();
+            for (int b = wd.blk0 + g; b < wd.blk0 + wd.n_blk; b += G)
+                for (int q = 0; q < kObsPerLane; ++q) trim_residual_lane(bv, b, tid + q * kBlock, a.plane_rep, a.plane_dep);
+            KBA_GSYNC();
+            for (int l = wd.lm0 + g * kBlock + tid; l < wd.lm0 + wd.n_lm; l += G * kBlock) trim_max_lane(bv, l, a.plane_rep, a.plane_dep);
+            KBA_GSYNC();
+            if (g == 0) trim_select_win(bv, c, w);
+        }
+    }
+#ifdef KBA_COOP_TICKS
+    if (w == 0 && tid == 0 && (g == 0 || g == 1 || g == G - 1))
+        printf("[coop ticks g=%d of %d] lin %lld | gb1 %lld | assemble %lld | gb-scale %lld | schur %lld | gb2 %lld | solve %lld | gb3 %lld | backsub %lld | gb4 %lld | decide %lld | gb5 %lld | damp %lld (x10 ns)\n",
+               g, G, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[8], tk[9], tk[10], tk[11], tk[13]);
+#endif
+#ifdef KBA_PROFILE_TICKS  // (debug build: the phase stamps cam_assemble / cam_solve took in their LAST call, shader clocks)
+    if (w == 0 && g == 0 && tid == 0)
+        for (int l = 0; l < 2; ++l) {
+            printf("[coop ticks cam_assemble %s lane] observation blocks %lld, ground-plane rows %lld, regulariser rows %lld, their sums %lld, mask + store %lld, reductions %lld\n",
+                   l ? "last" : "first", kba_ticks[l][1] - kba_ticks[l][0], kba_ticks[l][2] - kba_ticks[l][1], kba_ticks[l][3] - kba_ticks[l][2],
+                   kba_ticks[l][4] - kba_ticks[l][3], kba_ticks[l][5] - kba_ticks[l][4], kba_ticks[l][6] - kba_ticks[l][5]);
+            printf("[coop ticks cam_solve %s lane] slab sum %lld, cholesky %lld, back-substitution %lld, step %lld, reduction %lld\n", l ? "last" : "first",
+                   kba_ticks[l][9] - kba_ticks[l][8], kba_ticks[l][10] - kba_ticks[l][9], kba_ticks[l][11] - kba_ticks[l][10],
+                   kba_ticks[l][12] - kba_ticks[l][11], kba_ticks[l][13] - kba_ticks[l][12]);
+        }
+#endif
+#undef KBA_CTICK
+#undef KBA_GSYNC
 }
 
 // ------------------------------------------------------------------------------------------ landmark sharding

@@ -74,6 +74,7 @@ struct limo_ba_batch : Executor {
     int plain_lds_bytes = 0;
     const void* schur_fn_leangp = nullptr;
     int leangp_lds_bytes = 0;
+    int schur_vp = 1, schur_vg = 1;  // the same choice as template arguments of the one-launch solve (k_solve_coop)
     std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
     int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
@@ -309,6 +310,8 @@ struct limo_ba_batch : Executor {
                 }
             }
             if (any_fast) {
+                schur_vp = (max_nfq + 16) / 16 <= 1 ? 1 : 2;
+                schur_vg = std::min(3, (max_nf + 16) / 16);
                 schur_fn_plain = (max_nfq + 16) / 16 <= 1 ? (const void*)k_schur_lean<1, false, 4> : (const void*)k_schur_lean<2, false, 3>;
                 plain_lds_bytes = schur_lean_lds_bytes(max_nfq + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_plain, hipFuncAttributeMaxDynamicSharedMemorySize, plain_lds_bytes));
@@ -844,6 +847,66 @@ struct limo_ba_batch : Executor {
         LAUNCH_CHECK("k_solve_wg");
     }
 
+    // ---- one window (a few windows), ONE cooperative launch (kba_kernels.hip:k_solve_coop): G workgroups per window that
+    // meet at device-wide barriers where the lock-step solve has launch boundaries.  KBA_NO_COOP_SOLVE=1 (read per call)
+    // keeps the lock-step launches (the tests compare the two paths bit by bit).
+    int32_t* d_coop_bar = nullptr;
+    bool coop_launched = false;
+    int coop_G = 0;
+    int coop_lds_bytes() const {
+        const int wave = (std::max(plain_lds_bytes, leangp_lds_bytes) + 15) / 16 * 16;
+        return std::max(std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax))), (kBlock / 64) * wave);
+    }
+    bool coop_solve_applies() {
+        if (shard_P != 1 || P.evaluate_only || P.n_win < 1) return false;
+        if (const char* e = std::getenv("KBA_NO_COOP_SOLVE"))
+            if (std::atoi(e) != 0) return false;
+        set_span(P.n_win);
+        int G = 1;
+        for (const WinDesc& d : P.win) {
+            if (!d.schur_fast || d.cam_scr_off >= 0) return false;
+            const int tasks = (d.n_sblk_plain + c.schur_span - 1) / c.schur_span + (d.n_sblk - d.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
+            // enough workgroups for one landmark workgroup each, and for one Schur group per wave next to workgroup 0
+            G = std::max(G, std::max((int)d.n_lblk, tasks ? 1 + (tasks + kBlock / 64 - 1) / (kBlock / 64) : 1));
+        }
+        G = std::min(G, 32);
+        if (const char* e = std::getenv("KBA_COOP_G")) G = std::max(1, std::min(64, std::atoi(e)));  // (timing aid)
+        if ((int64_t)P.n_win * G > 256 || coop_lds_bytes() > kCamLdsCapBytes) return false;  // one workgroup per CU, all resident
+        coop_G = G;
+        return true;
+    }
+    // false: the launch was refused (nothing ran) - the caller takes the lock-step path
+    bool solve_coop() {
+        const int lds = coop_lds_bytes();
+        if (!d_coop_bar && dmalloc((void**)&d_coop_bar, sizeof(int32_t) * 4 * P.n_win)) return false;
+        if (hipFuncSetAttribute((const void*)k_solve_coop, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        note(hipMemsetAsync(d_coop_bar, 0, sizeof(int32_t) * 4 * P.n_win, ctx->stream), "memset barrier words");
+        h_active[8] = 0;
+        CoopParams cp;
+        cp.G = coop_G;
+        cp.vp = schur_vp;
+        cp.vg = schur_vg;
+        cp.schur_lds = (std::max(plain_lds_bytes, leangp_lds_bytes) + 15) / 16 * 16 / (int)sizeof(double);
+        cp.cap_ticks = opts.max_solver_time_sec > 0.0 ? std::max(1ll, (long long)(opts.max_solver_time_sec * 1e8)) : 0ll;
+        cp.bar = d_coop_bar;
+        cp.abort_host = d_h_active + 8;
+        cp.plane_rep = d_plane_rep;
+        cp.plane_dep = d_plane_dep;
+        void* args[] = {(void*)&bv, (void*)&c, (void*)&cp};
+        static const bool plain_launch = std::getenv("KBA_COOP_PLAIN_LAUNCH") != nullptr;  // (timing aid: no co-residency guarantee)
+        const hipError_t e = plain_launch ? hipLaunchKernel((const void*)k_solve_coop, dim3(P.n_win * coop_G), dim3(kBlock), args, lds, ctx->stream)
+                                          : hipLaunchCooperativeKernel((const void*)k_solve_coop, dim3(P.n_win * coop_G), dim3(kBlock), args, lds, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        coop_launched = true;
+        return true;
+    }
+
     // The host only enqueues; it learns that all windows are done from a pinned word the scheduler writes, two rounds
     // late (so the streams never drain inside a solve).
     int solve_streaming() {
@@ -1055,7 +1118,7 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
         b->solve_streaming();
     else if (b->wg_solve_applies())
         b->solve_wg();
-    else
+    else if (!(b->coop_solve_applies() && b->solve_coop()))
         run_schedule(*b, b->opts);
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
         hipLaunchKernelGGL(k_lm_owned, dim3(cdiv(b->P.TL, 256)), dim3(256), 0, ctx->stream, b->bv, b->d_lm_tmp, b->shard_rank, b->shard_P,
@@ -1070,6 +1133,13 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     }
     HIP_TRY(ctx, hipEventRecord(b->ev_total_b, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->coop_launched) {
+        b->coop_launched = false;
+        if (b->h_active[8] != 0) {
+            ctx->err = "k_solve_coop: a device-wide barrier was not met (launch aborted)";
+            return LIMO_ERR_RUNTIME;
+        }
+    }
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, b->ev_total_a, b->ev_total_b));
     b->total_ms_acc += ms;

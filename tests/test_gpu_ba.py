@@ -188,6 +188,45 @@ def test_pose_only_one_launch_equals_lock_step(ctx, seed, cap, monkeypatch):
         assert ra["n_trimmed_landmarks"] > 0 and ra["num_solves"] >= 2  # the trimming branch ran
 
 
+def _solve_both_paths(ctx, w, o, monkeypatch):
+    a, b = w.copy(), w.copy()
+    for k in ("KBA_NO_COOP_SOLVE", "KBA_NO_WG_SOLVE"):
+        monkeypatch.delenv(k, raising=False)
+    ra = ctx.solve(a, o)
+    for k in ("KBA_NO_COOP_SOLVE", "KBA_NO_WG_SOLVE"):
+        monkeypatch.setenv(k, "1")
+    rb = ctx.solve(b, o)
+    for k in ("KBA_NO_COOP_SOLVE", "KBA_NO_WG_SOLVE"):
+        monkeypatch.delenv(k, raising=False)
+    return a, ra, b, rb
+
+
+@pytest.mark.parametrize("cap", [-1.0, 30.0])
+def test_single_window_one_launch_equals_lock_step(ctx, cap, monkeypatch):
+    """limo_ba_solve of one window is ONE cooperative launch (kba_kernels.hip:k_solve_coop: G workgroups that meet at
+    device-wide barriers where the lock-step solve has launch boundaries; camera system and Schur complement side by side).
+    Same device functions, partitions and summation orders: bit-identical to the launch-per-phase path
+    (KBA_NO_COOP_SOLVE=1) - C2 windows, the reference-test shapes, ground plane on / off, stereo, trimming on / off,
+    1 .. 4 free keyframes, a window without any landmark left."""
+    from fuzz_common import random_windows
+
+    o = default_options(max_solver_time_sec=cap)
+    ws = [synth.make_window(3000 + i) for i in range(3)]
+    ws += [synth.make_window(c["seed"], **{k: v for k, v in c.items() if k != "seed"}) for c in CASES]
+    ws += [w for kw, w in random_windows(40, 2024) if kw["n_kf"] <= 5][:12]
+    n_coop = 0
+    for w in ws:
+        a, ra, b, rb = _solve_both_paths(ctx, w, o, monkeypatch)
+        assert a.kf_pose.tobytes() == b.kf_pose.tobytes()
+        assert a.lm_pos.tobytes() == b.lm_pos.tobytes()
+        assert a.kf_plane_dir.tobytes() == b.kf_plane_dir.tobytes() and a.kf_plane_dist.tobytes() == b.kf_plane_dist.tobytes()
+        for k in ("final_cost", "initial_cost", "iterations_total", "iterations_final", "num_solves", "n_trimmed_landmarks", "termination",
+                  "successful_steps", "num_linearizations"):
+            assert ra[k] == rb[k], (k, ra[k], rb[k])
+        n_coop += 1
+    assert n_coop >= 10
+
+
 def test_committed_golden_fixtures(ctx):
     """GPU results against tests/golden/oracle_windows.json (oracle outputs committed with their generator), so the
     GPU tier has fixed targets that do not depend on the oracle being rebuilt on the GPU box."""
