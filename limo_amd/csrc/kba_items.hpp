@@ -954,7 +954,17 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
         double acc = 0.0;
         for (int j = 0; j < wd.n_view; ++j) {
             if (bv.view_kf[wd.view0 + j] - wd.kf0 != kl) continue;
-            for (int b = 0; b < wd.n_lblk; ++b) acc += bv.lv_part[wd.lvpart_off + (int64_t)(b * wd.n_view + j) * kLinPartial + 1 + q];
+            const double* lp = bv.lv_part + wd.lvpart_off + (int64_t)j * kLinPartial + 1 + q;
+            const int64_t stride = (int64_t)wd.n_view * kLinPartial;
+            int b = 0;
+            for (; b + 4 <= wd.n_lblk; b += 4) {  // four loads in flight, added in workgroup order
+                const double v0 = lp[b * stride], v1 = lp[(b + 1) * stride], v2 = lp[(b + 2) * stride], v3 = lp[(b + 3) * stride];
+                acc += v0;
+                acc += v1;
+                acc += v2;
+                acc += v3;
+            }
+            for (; b < wd.n_lblk; ++b) acc += lp[b * stride];
         }
         if (q < 21) {
             int a = 0, rem = q;
@@ -1316,9 +1326,19 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     for (int a = tid; a < nc; a += nt) {
         if (cs[a] < 0) continue;
         double hd = 0.0;
-        for (int b = 0; b < nc; ++b) hd += Hg[b * nc + a] * dl[b];  // H is symmetric to the bit: column a = row a, read coalesced
+        // H is symmetric to the bit: column a = row a, read coalesced.  Five loads in flight (nc is a multiple of kCamSlots),
+        // added in column order: one window alone pays a memory round trip per load otherwise.
+        for (int b = 0; b < nc; b += 5) {
+            const double h0 = Hg[b * nc + a], h1 = Hg[(b + 1) * nc + a], h2 = Hg[(b + 2) * nc + a], h3 = Hg[(b + 3) * nc + a], h4 = Hg[(b + 4) * nc + a];
+            hd += h0 * dl[b];
+            hd += h1 * dl[b + 1];
+            hd += h2 * dl[b + 2];
+            hd += h3 * dl[b + 3];
+            hd += h4 * dl[b + 4];
+        }
         part += -bv.gc[wd.cam0 + a] * dl[a] - 0.5 * dl[a] * hd;
     }
+    KBA_TICK(14);
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;
     double step2 = 0.0, cand2 = 0.0;
     for (int k = tid; k < wd.n_kf; k += nt) {
@@ -1338,24 +1358,9 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         }
         for (int i = 0; i < 7; ++i) xc[i] = pc[i];
         {   // what the landmark-side kernels need of the proposed camera step: dR of this keyframe (back-substitution:
-            // F_pose delta = Ft (dR p + delta_t), kba_math.hpp:quat_dR) and the per-view constants of its candidate
-            // pose (candidate cost, cf. view_consts_item)
+            // F_pose delta = Ft (dR p + delta_t), kba_math.hpp:quat_dR)
             const double zero3[3] = {0.0, 0.0, 0.0};
             quat_dR(x, cm[k * kCamSlots] ? d : zero3, bv.kf_dR + 9 * (int64_t)gk);
-            double Rk[9];
-            quat_R(pc, Rk);
-            for (int j = 0; j < wd.n_view; ++j) {
-                const int view = wd.view0 + j;
-                if (bv.view_kf[view] != gk) continue;
-                const double* cam = bv.view_cam + 16 * (int64_t)view;
-                double* vl = bv.view_lin_c + (int64_t)kViewLin * view;
-                mat3_mul(cam + 4, Rk, vl);
-                for (int i = 0; i < 3; ++i)
-                    vl[9 + i] = cam[4 + 3 * i] * pc[4] + cam[4 + 3 * i + 1] * pc[5] + cam[4 + 3 * i + 2] * pc[6] + cam[13 + i];
-                vl[25] = cam[0];
-                vl[26] = cam[1];
-                vl[27] = cam[2];
-            }
         }
         const double* n = bv.pdir + 3 * (int64_t)gk;
         double* ncand = bv.pdir_c + 3 * (int64_t)gk;
@@ -1375,6 +1380,31 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         } else {
             bv.pdist_c[gk] = bv.pdist[gk];
         }
+    }
+    // ... and the per-view constants of the candidate poses (candidate cost, cf. view_consts_item): one lane per VIEW,
+    // taken from the far end of the workgroup - other waves than the keyframe lanes above, so the two chains of dependent
+    // memory round trips (pose -> candidate -> stores; view -> its keyframe's pose -> candidate -> constants) run side by
+    // side instead of one keyframe lane walking over the window's views.  The candidate pose is formed again from the
+    // same operands (same bits).
+    for (int j = nt - 1 - tid; j < wd.n_view; j += nt) {
+        const int view = wd.view0 + j, gk = bv.view_kf[view], k = gk - wd.kf0;
+        const double* cam = bv.view_cam + 16 * (int64_t)view;
+        const double* x = bv.pose + 7 * (int64_t)gk;
+        double pc[7];
+        if (cm[k * kCamSlots + 0]) {
+            pose_plus(x, dl + k * kCamSlots, pc);
+        } else {
+            for (int i = 0; i < 7; ++i) pc[i] = x[i];
+        }
+        double Rk[9];
+        quat_R(pc, Rk);
+        double* vl = bv.view_lin_c + (int64_t)kViewLin * view;
+        mat3_mul(cam + 4, Rk, vl);
+        for (int i = 0; i < 3; ++i)
+            vl[9 + i] = cam[4 + 3 * i] * pc[4] + cam[4 + 3 * i + 1] * pc[5] + cam[4 + 3 * i + 2] * pc[6] + cam[13 + i];
+        vl[25] = cam[0];
+        vl[26] = cam[1];
+        vl[27] = cam[2];
     }
     KBA_TICK(12);
     // three sums at once (red holds 3*nt doubles)
@@ -1409,7 +1439,18 @@ KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red
         cost += bv.lblk_part[(int64_t)b * 8 + 6];
         if (bv.lblk_part[(int64_t)b * 8 + 7] != 0.0) cfail = 1.0;
     }
-    for (int g = wd.gp0 + t0; g < wd.gp0 + wd.n_gp; g += n_work) cost += bv.gp_cost_c[g];
+    {   // (four loads in flight, added in row order: one workgroup alone waits a memory round trip per load otherwise)
+        int g = wd.gp0 + t0;
+        const int g_end = wd.gp0 + wd.n_gp;
+        for (; g + 3 * n_work < g_end; g += 4 * n_work) {
+            const double v0 = bv.gp_cost_c[g], v1 = bv.gp_cost_c[g + n_work], v2 = bv.gp_cost_c[g + 2 * n_work], v3 = bv.gp_cost_c[g + 3 * n_work];
+            cost += v0;
+            cost += v1;
+            cost += v2;
+            cost += v3;
+        }
+        for (; g < g_end; g += n_work) cost += bv.gp_cost_c[g];
+    }
     const int nrows = reg_row_count(wd);
     for (int i = t0; i < nrows; i += n_work) {
         RegRow row;

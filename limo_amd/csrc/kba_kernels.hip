@@ -1477,7 +1477,9 @@ struct CoopParams {
     int32_t* bar;              // [n_win][4] {arrived, generation, abort, -}, zeroed before the launch
     int32_t* abort_host;       // pinned: set when a barrier timed out
     double *plane_rep, *plane_dep;
+    double* red;               // [n_win][kCoopRedStride] the window's Schur slabs summed (see k_cam_solve below)
 };
+constexpr int kCoopRedStride = 64 * 64;  // nf_pad <= 64 for fast-class windows (<= 4 free keyframes: 40 slots + rhs)
 
 __device__ __forceinline__ bool coop_sync(int32_t* bar, int G, int& gen, int32_t* abort_host) {
     if (G == 1) {
@@ -1627,8 +1629,40 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 KBA_GSYNC();
             }
             if (!st.active) break;
-            // ---- k_cam_solve
-            if (g == 0) cam_solve(bv, c, w, tid, kBlock, smem, &flag);
+            // ---- k_cam_solve.  Its first phase - S minus the sum of the Schur slabs, entry by entry - is a chain of
+            //      dependent memory round trips for ONE workgroup (a third of the kernel); here every workgroup sums a share
+            //      of the entries over all slabs first, in the order cam_solve adds them ((q mod 4) partial sums, then
+            //      (a0 + a1) + (a2 + a3)), and workgroup 0 reads ONE slab: s - ((R + 0) + (0 + 0)) has the bits of s - R.
+            if (G > 1) {
+                const int nfp = wd.nf_pad, slab = nfp * nfp, n_slab = n_pg + n_gg;
+                const double* sp = bv.S_part + wd.spart_off;
+                double* outr = a.red + (int64_t)w * kCoopRedStride;
+                for (int e = g * kBlock + tid; e < slab; e += G * kBlock) {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int n4 = n_slab & ~3;
+                    for (int q0 = 0; q0 < n_slab; q0 += 16) {  // 16 loads in flight, then added in slab order
+                        double v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) v[j] = q0 + j < n_slab ? sp[(int64_t)(q0 + j) * slab + e] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            if (q0 + j < n_slab) acc[q0 + j < n4 ? (j & 3) : 0] += v[j];
+                    }
+                    outr[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                }
+                KBA_CTICK(14);
+                KBA_GSYNC();
+                KBA_CTICK(15);
+                if (g == 0) {
+                    BatchView bvr = bv;
+                    bvr.S_red = outr - wd.sred_off;
+                    SolveConsts cr = c;
+                    cr.schur_nslab = 1;
+                    cam_solve(bvr, cr, w, tid, kBlock, smem, &flag);
+                }
+            } else {
+                cam_solve(bv, c, w, tid, kBlock, smem, &flag);
+            }
             KBA_CTICK(6);
             KBA_GSYNC();
             KBA_CTICK(7);
@@ -1679,8 +1713,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
     }
 #ifdef KBA_COOP_TICKS
     if (w == 0 && tid == 0 && (g == 0 || g == 1 || g == G - 1))
-        printf("[coop ticks g=%d of %d] lin %lld | gb1 %lld | assemble %lld | gb-scale %lld | schur %lld | gb2 %lld | solve %lld | gb3 %lld | backsub %lld | gb4 %lld | decide %lld | gb5 %lld | damp %lld (x10 ns)\n",
-               g, G, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[8], tk[9], tk[10], tk[11], tk[13]);
+        printf("[coop ticks g=%d of %d] lin %lld | gb1 %lld | assemble %lld | gb-scale %lld | schur %lld | gb2 %lld | solve %lld | gb3 %lld | backsub %lld | gb4 %lld | decide %lld | gb5 %lld | damp %lld | slab sum %lld | gb-slab %lld (x10 ns)\n",
+               g, G, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[8], tk[9], tk[10], tk[11], tk[13], tk[14], tk[15]);
 #endif
 #ifdef KBA_PROFILE_TICKS  // (debug build: the phase stamps cam_assemble / cam_solve took in their LAST call, shader clocks)
     if (w == 0 && g == 0 && tid == 0)
@@ -1688,9 +1722,9 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
             printf("[coop ticks cam_assemble %s lane] observation blocks %lld, ground-plane rows %lld, regulariser rows %lld, their sums %lld, mask + store %lld, reductions %lld\n",
                    l ? "last" : "first", kba_ticks[l][1] - kba_ticks[l][0], kba_ticks[l][2] - kba_ticks[l][1], kba_ticks[l][3] - kba_ticks[l][2],
                    kba_ticks[l][4] - kba_ticks[l][3], kba_ticks[l][5] - kba_ticks[l][4], kba_ticks[l][6] - kba_ticks[l][5]);
-            printf("[coop ticks cam_solve %s lane] slab sum %lld, cholesky %lld, back-substitution %lld, step %lld, reduction %lld\n", l ? "last" : "first",
+            printf("[coop ticks cam_solve %s lane] slab sum %lld, cholesky %lld, back-substitution %lld, step %lld (of it: model cost change %lld), reduction %lld\n", l ? "last" : "first",
                    kba_ticks[l][9] - kba_ticks[l][8], kba_ticks[l][10] - kba_ticks[l][9], kba_ticks[l][11] - kba_ticks[l][10],
-                   kba_ticks[l][12] - kba_ticks[l][11], kba_ticks[l][13] - kba_ticks[l][12]);
+                   kba_ticks[l][12] - kba_ticks[l][11], kba_ticks[l][14] - kba_ticks[l][11], kba_ticks[l][13] - kba_ticks[l][12]);
         }
 #endif
 #undef KBA_CTICK

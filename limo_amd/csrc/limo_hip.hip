@@ -851,6 +851,7 @@ struct limo_ba_batch : Executor {
     // meet at device-wide barriers where the lock-step solve has launch boundaries.  KBA_NO_COOP_SOLVE=1 (read per call)
     // keeps the lock-step launches (the tests compare the two paths bit by bit).
     int32_t* d_coop_bar = nullptr;
+    double* d_coop_red = nullptr;
     bool coop_launched = false;
     int coop_G = 0;
     int coop_lds_bytes() const {
@@ -864,7 +865,7 @@ struct limo_ba_batch : Executor {
         set_span(P.n_win);
         int G = 1;
         for (const WinDesc& d : P.win) {
-            if (!d.schur_fast || d.cam_scr_off >= 0) return false;
+            if (!d.schur_fast || d.cam_scr_off >= 0 || d.nf_pad * d.nf_pad > kCoopRedStride) return false;
             const int tasks = (d.n_sblk_plain + c.schur_span - 1) / c.schur_span + (d.n_sblk - d.n_sblk_plain + c.schur_span_gp - 1) / c.schur_span_gp;
             // enough workgroups for one landmark workgroup each, and for one Schur group per wave next to workgroup 0
             G = std::max(G, std::max((int)d.n_lblk, tasks ? 1 + (tasks + kBlock / 64 - 1) / (kBlock / 64) : 1));
@@ -879,6 +880,7 @@ struct limo_ba_batch : Executor {
     bool solve_coop() {
         const int lds = coop_lds_bytes();
         if (!d_coop_bar && dmalloc((void**)&d_coop_bar, sizeof(int32_t) * 4 * P.n_win)) return false;
+        if (!d_coop_red && dmalloc((void**)&d_coop_red, sizeof(double) * kCoopRedStride * P.n_win)) return false;
         if (hipFuncSetAttribute((const void*)k_solve_coop, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -895,6 +897,7 @@ struct limo_ba_batch : Executor {
         cp.abort_host = d_h_active + 8;
         cp.plane_rep = d_plane_rep;
         cp.plane_dep = d_plane_dep;
+        cp.red = d_coop_red;
         void* args[] = {(void*)&bv, (void*)&c, (void*)&cp};
         static const bool plain_launch = std::getenv("KBA_COOP_PLAIN_LAUNCH") != nullptr;  // (timing aid: no co-residency guarantee)
         const hipError_t e = plain_launch ? hipLaunchKernel((const void*)k_solve_coop, dim3(P.n_win * coop_G), dim3(kBlock), args, lds, ctx->stream)
