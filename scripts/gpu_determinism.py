@@ -5,7 +5,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 from limo_amd import ba, default_options, synth, synth_lidar
 from test_gpu_landmark_init import _rays
-from test_emu_vs_oracle import make_pose_only_case
 
 ctx = ba.Context(0)
 o = default_options()
@@ -34,7 +33,7 @@ for name, mk in (("solve C2", lambda: synth.make_window(7001)), ("solve 5x500", 
         if i % 2: ctx.landmark_init(off, rays, use_depth)
     print("%s: %d of %d calls differ" % (name, bad, REP), flush=True)
 
-pw, prior, gt = make_pose_only_case(71)
+pw, prior, gt = synth.make_pose_only_case(71)
 ref, bad = None, 0
 for i in range(REP * 3):
     w = pw.copy(); r = ctx.adjust_pose_only(w, prior, default_options(min_landmarks_for_trimming=30))

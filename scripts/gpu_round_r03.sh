@@ -4,7 +4,10 @@
 TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $OUT/pytest_gpu.log; fi
+if [ -z "$SKIP_TESTS" ]; then
+  python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_full.log 2>&1
+  grep -E "passed|failed|error" $OUT/pytest_gpu_full.log | tail -4 | tee $OUT/pytest_gpu.log
+fi
 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err; head -c 400 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ -z "$SKIP_PROF" ]; then

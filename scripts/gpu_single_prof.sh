@@ -17,6 +17,7 @@ dt = (time.perf_counter() - t0) / 10
 print("single: %.2f ms per window, %.1f LM iterations per window -> %.0f us per iteration" % (dt * 1e3, its / 10, 1e6 * dt * 10 / its))
 PY
 python /tmp/single.py
+KBA_NO_COOP_SOLVE=1 python /tmp/single.py | sed 's/^single:/single [lock-step launches, KBA_NO_COOP_SOLVE=1]:/'
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_single -o s -- python /tmp/single.py > gpurun_out/prof_single.log 2>&1
 grep "^single" gpurun_out/prof_single.log
 python scripts/prof_summary.py gpurun_out/prof_single/s_results.db | head -24

@@ -8,11 +8,10 @@ timeout 600 python -m pytest tests/test_gpu_ba.py -x -q -m gpu -k "pose_only" 2>
 cat > /tmp/po.py <<'PY'
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-from limo_amd import ba, default_options
-from test_emu_vs_oracle import make_pose_only_case
+from limo_amd import ba, default_options, synth
 ctx = ba.Context(0)
 o = default_options(min_landmarks_for_trimming=30)
-pw, prior, gt = make_pose_only_case(71)
+pw, prior, gt = synth.make_pose_only_case(71)
 for _ in range(5): ctx.adjust_pose_only(pw.copy(), prior, o)
 N = int(os.environ.get("N_CALLS", "200"))
 ts = []

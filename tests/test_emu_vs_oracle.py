@@ -90,43 +90,8 @@ def test_batch_is_independent_of_batch_composition(emu):
 
 
 def make_pose_only_case(seed):
-    """New frame against fixed landmarks (adjustPoseOnly): take a solved-ish window, use the newest keyframe as the
-    frame to adjust with a perturbed prior, all landmarks at their ground-truth positions."""
-    w = synth.make_window(seed, n_kf=4, n_lm=300, outlier_frac=0.02)
-    k = w.n_kf - 1
-    sel = w.obs_kf == k
-    from limo_amd.window import Window
-
-    pw = Window(
-        kf_pose=w.kf_pose[k : k + 1].copy(),
-        kf_plane_dir=w.kf_plane_dir[k : k + 1],
-        kf_plane_dist=w.kf_plane_dist[k : k + 1],
-        kf_fixation=np.array([_ffi.LIMO_FIX_NONE], np.int32),
-        cam=w.cam,
-        lm_pos=w.meta["gt_lm"].copy(),
-        lm_weight=w.lm_weight,
-        lm_is_ground=w.lm_is_ground,
-        obs_kf=np.zeros(sel.sum(), np.int32),
-        obs_lm=w.obs_lm[sel],
-        obs_cam=w.obs_cam[sel],
-        obs_u=w.obs_u[sel],
-        obs_v=w.obs_v[sel],
-        obs_d=w.obs_d[sel],
-    )
-    gt = w.meta["gt_pose"][k]
-    prior = _ffi.SpeedPrior()
-    prior.speed_weight = 0.7
-    prior.dt_cur = 0.4
-    pb = w.meta["gt_pose"][k - 1]
-    prior.pose_before[:] = pb.tolist()
-    # velocity of the previous step expressed as the reference does: translation(pose_before * pose_before2^-1)/dt
-    from limo_amd.synth import pose_to_Rt
-
-    Rb, tb = pose_to_Rt(pb)
-    Rbb, tbb = pose_to_Rt(w.meta["gt_pose"][k - 2])
-    v = (tb - Rb @ Rbb.T @ tbb) / 0.4
-    prior.vel_prev[:] = v.tolist()
-    return pw, prior, gt
+    """New frame against fixed landmarks (adjustPoseOnly): limo_amd/synth.py:make_pose_only_case."""
+    return synth.make_pose_only_case(seed)
 
 
 @pytest.mark.parametrize("with_prior", [False, True])
