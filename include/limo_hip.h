@@ -174,7 +174,11 @@ void limo_host_free(void* p);
 void limo_ba_default_options(limo_ba_options* out);
 
 /* --- bundle adjustment --------------------------------------------------------------------------- */
-/* One window, host buffers in, optimised in place.  = batch_create(1) + solve + download + destroy. */
+/* One window, host buffers in, optimised in place.  = batch_create(1) + solve + download + destroy.
+ * The call the reference's node makes per keyframe (mono_lidar.cpp:255).  A window of the common shape (<= 4 free
+ * keyframes, one camera each) is solved in ONE cooperative kernel launch (k_solve_coop: several workgroups that meet at
+ * device-wide barriers), any other window as a launch sequence - same results bit for bit (KBA_NO_COOP_SOLVE=1 forces
+ * the launch sequence).  A wall-clock cap (opts->max_solver_time_sec > 0) is honoured on both paths. */
 int limo_ba_solve(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, limo_ba_report* report);
 
 /*
@@ -251,6 +255,9 @@ int limo_ba_evaluate_batch_time(limo_ctx* ctx, int32_t n_windows, const limo_ba_
  * window: n_kf == 1 (the new keyframe; its pose is optimised in place), landmarks constant.
  * Optional speed prior (SpeedRegularizationVector2, cost_functors_ceres.hpp:300-353): enabled when
  * speed_weight > 0: residual (t_new - R_new R_b^T t_b)/dt_cur - vel_prev with pose_before = (q_b,t_b).
+ * The call the reference's node makes for every frame (mono_lidar.cpp:203): the whole solveTrimmed schedule of the
+ * window runs in ONE kernel launch of one workgroup (k_solve_wg; KBA_NO_WG_SOLVE=1 KBA_NO_COOP_SOLVE=1 force the
+ * launch sequence - same bits).
  */
 typedef struct limo_speed_prior {
     double speed_weight;     /* 1 - rot_diff/0.03, <= 0 disables (bundle_adjuster_keyframes.cpp:842-843) */

@@ -20,7 +20,7 @@ dt = (time.perf_counter() - t0) / N
 print("adjustPoseOnly: %d landmarks, %d obs: %.2f ms per call, %d LM iterations, %d solves" % (pw.n_lm, pw.n_obs, dt * 1e3, r["iterations_total"], r["num_solves"]))
 PY
 python /tmp/po.py 2>&1 | grep "^adjustPoseOnly"   # no profiler attached: the latency that counts
-KBA_NO_WG_SOLVE=1 python /tmp/po.py 2>&1 | grep "^adjustPoseOnly" | sed 's/^adjustPoseOnly/adjustPoseOnly [lock-step launches, KBA_NO_WG_SOLVE=1]/'
+KBA_NO_WG_SOLVE=1 KBA_NO_COOP_SOLVE=1 python /tmp/po.py 2>&1 | grep "^adjustPoseOnly" | sed 's/^adjustPoseOnly/adjustPoseOnly [lock-step launches, KBA_NO_WG_SOLVE=1 KBA_NO_COOP_SOLVE=1]/'
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_po -o po -- python /tmp/po.py > gpurun_out/prof_po.log 2>&1
 grep "^adjustPoseOnly" gpurun_out/prof_po.log | sed 's/^adjustPoseOnly/adjustPoseOnly [under rocprofv3]/' 
 python scripts/prof_summary.py gpurun_out/prof_po/po_results.db | head -16

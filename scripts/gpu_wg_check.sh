@@ -22,9 +22,9 @@ print("adjustPoseOnly [%s]: %d landmarks, %d obs: median %.3f ms, mean %.3f ms p
     "lock-step launches" if os.environ.get("KBA_NO_WG_SOLVE") else "one launch", pw.n_lm, pw.n_obs, ts[N // 2] * 1e3, sum(ts) / N * 1e3, r["iterations_total"], r["num_solves"]))
 PY
 timeout 300 python /tmp/po.py
-KBA_NO_WG_SOLVE=1 timeout 300 python /tmp/po.py
+KBA_NO_WG_SOLVE=1 KBA_NO_COOP_SOLVE=1 timeout 300 python /tmp/po.py
 N_CALLS=3 KBA_HOST_TRACE=1 timeout 300 python /tmp/po.py 2>&1 | tail -5
-N_CALLS=3 KBA_HOST_TRACE=1 KBA_NO_WG_SOLVE=1 timeout 300 python /tmp/po.py 2>&1 | tail -5
+N_CALLS=3 KBA_HOST_TRACE=1 KBA_NO_WG_SOLVE=1 KBA_NO_COOP_SOLVE=1 KBA_NO_COOP_SOLVE=1 timeout 300 python /tmp/po.py 2>&1 | tail -5
 N_CALLS=50 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_po -o po -- python /tmp/po.py > $OUT/prof_po.log 2>&1
 grep "^adjustPoseOnly" $OUT/prof_po.log
 python scripts/prof_summary.py $OUT/prof_po/po_results.db | head -12

@@ -175,16 +175,23 @@ def test_pose_only_one_launch_equals_lock_step(ctx, seed, cap, monkeypatch):
     pw, prior, _ = make_pose_only_case(seed)
     o = default_options(min_landmarks_for_trimming=30, max_solver_time_sec=cap)
     for pr in (None, prior):
-        a, b = pw.copy(), pw.copy()
-        monkeypatch.delenv("KBA_NO_WG_SOLVE", raising=False)
-        ra = ctx.adjust_pose_only(a, pr, o)
-        monkeypatch.setenv("KBA_NO_WG_SOLVE", "1")
-        rb = ctx.adjust_pose_only(b, pr, o)
-        monkeypatch.delenv("KBA_NO_WG_SOLVE", raising=False)
-        assert a.kf_pose.tobytes() == b.kf_pose.tobytes()
-        for k in ("final_cost", "initial_cost", "iterations_total", "iterations_final", "num_solves", "n_trimmed_landmarks", "termination",
-                  "successful_steps", "num_linearizations"):
-            assert ra[k] == rb[k], (k, ra[k], rb[k])
+        # three paths: one workgroup (k_solve_wg), the cooperative kernel with G = 1 (KBA_NO_WG_SOLVE=1), the lock-step launches
+        runs = []
+        for env in ({}, {"KBA_NO_WG_SOLVE": "1"}, {"KBA_NO_WG_SOLVE": "1", "KBA_NO_COOP_SOLVE": "1"}):
+            for k in ("KBA_NO_WG_SOLVE", "KBA_NO_COOP_SOLVE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            x = pw.copy()
+            runs.append((x, ctx.adjust_pose_only(x, pr, o)))
+        for k in ("KBA_NO_WG_SOLVE", "KBA_NO_COOP_SOLVE"):
+            monkeypatch.delenv(k, raising=False)
+        (a, ra) = runs[0]
+        for b, rb in runs[1:]:
+            assert a.kf_pose.tobytes() == b.kf_pose.tobytes()
+            for k in ("final_cost", "initial_cost", "iterations_total", "iterations_final", "num_solves", "n_trimmed_landmarks", "termination",
+                      "successful_steps", "num_linearizations"):
+                assert ra[k] == rb[k], (k, ra[k], rb[k])
         assert ra["n_trimmed_landmarks"] > 0 and ra["num_solves"] >= 2  # the trimming branch ran
 
 
