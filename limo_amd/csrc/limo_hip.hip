@@ -850,6 +850,10 @@ struct limo_ba_batch : Executor {
     // ---- one window (a few windows), ONE cooperative launch (kba_kernels.hip:k_solve_coop): G workgroups per window that
     // meet at device-wide barriers where the lock-step solve has launch boundaries.  KBA_NO_COOP_SOLVE=1 (read per call)
     // keeps the lock-step launches (the tests compare the two paths bit by bit).
+    // At most 64 windows per launch (>= 4 workgroups per window): measured on C2 windows (scripts/gpu_small_batch.py), one launch
+    // vs streaming solve: 16 windows 10.8 / 19.1 ms, 64: 17.4 / 22.4 ms, 128: 25.0 / 24.0 ms, 256: 34.0 / 27.7 ms
+    // (KBA_COOP_MAX_WIN: timing aid, up to 256).
+    static constexpr int kCoopMaxWg = 256, kCoopMaxWin = 64;
     int32_t* d_coop_bar = nullptr;
     double* d_coop_red = nullptr;
     bool coop_launched = false;
@@ -872,7 +876,10 @@ struct limo_ba_batch : Executor {
         }
         G = std::min(G, 32);
         if (const char* e = std::getenv("KBA_COOP_G")) G = std::max(1, std::min(64, std::atoi(e)));  // (timing aid)
-        if ((int64_t)P.n_win * G > 256 || coop_lds_bytes() > kCamLdsCapBytes) return false;  // one workgroup per CU, all resident
+        // one workgroup per CU, all resident: a batch of up to kCoopMaxWin windows shares the chip with fewer workgroups per
+        // window (64 windows: 4 each) - still far ahead of ten launches per iteration over 64 slots
+        if (P.n_win > kCoopMaxWg || coop_lds_bytes() > kCamLdsCapBytes) return false;
+        G = std::max(1, std::min(G, kCoopMaxWg / (int)P.n_win));
         coop_G = G;
         return true;
     }
@@ -1116,12 +1123,20 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     // Windows of a batch converge after very different numbers of iterations: from a few windows on they stream through
     // slots (k_sched) instead of advancing in lock-step.  Not for sharded solves (exchange steps between the kernels)
     // and not with a wall-clock cap (a per-solve clock, run_schedule keeps it).
-    const int stream_min = std::getenv("KBA_STREAM_MIN") ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;  // (read per call: the tests switch paths)
-    if (b->shard_P == 1 && b->opts.max_solver_time_sec <= 0.0 && b->P.n_win >= stream_min && !b->P.evaluate_only)
-        b->solve_streaming();
-    else if (b->wg_solve_applies())
+    // ... and small batches (<= 256 windows of the common shape) run as ONE launch: a workgroup per window (no free
+    // landmark) or G workgroups per window that meet at device-wide barriers (k_solve_coop).  All paths give the same bits.
+    const bool env_stream = std::getenv("KBA_STREAM_MIN") != nullptr;  // (read per call: the tests switch paths)
+    const int stream_min = env_stream ? std::atoi(std::getenv("KBA_STREAM_MIN")) : 16;
+    const int coop_max = std::getenv("KBA_COOP_MAX_WIN") ? std::min(std::atoi(std::getenv("KBA_COOP_MAX_WIN")), (int)limo_ba_batch::kCoopMaxWg) : limo_ba_batch::kCoopMaxWin;
+    const bool can_stream = b->shard_P == 1 && b->opts.max_solver_time_sec <= 0.0 && b->P.n_win >= stream_min && !b->P.evaluate_only;
+    const bool one_launch = !(env_stream && can_stream) && b->P.n_win <= coop_max;  // (KBA_STREAM_MIN set: the caller asks for the streaming solve)
+    if (one_launch && b->wg_solve_applies())
         b->solve_wg();
-    else if (!(b->coop_solve_applies() && b->solve_coop()))
+    else if (one_launch && b->coop_solve_applies() && b->solve_coop())
+        ;
+    else if (can_stream)
+        b->solve_streaming();
+    else
         run_schedule(*b, b->opts);
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
         hipLaunchKernelGGL(k_lm_owned, dim3(cdiv(b->P.TL, 256)), dim3(256), 0, ctx->stream, b->bv, b->d_lm_tmp, b->shard_rank, b->shard_P,

@@ -93,6 +93,8 @@ def test_streaming_and_lock_step_schedules_give_the_same_bits(ctx, monkeypatch):
     ws.insert(7, Window(**d))
     o = default_options()
     results = []
+    for k in ("KBA_NO_COOP_SOLVE", "KBA_NO_WG_SOLVE"):  # (the one-launch paths have their own tests below)
+        monkeypatch.setenv(k, "1")
     for stream_min in ("1", "1000"):
         monkeypatch.setenv("KBA_STREAM_MIN", stream_min)
         b = ba.Batch(ctx, [w.copy() for w in ws])
@@ -232,6 +234,33 @@ def test_single_window_one_launch_equals_lock_step(ctx, cap, monkeypatch):
             assert ra[k] == rb[k], (k, ra[k], rb[k])
         n_coop += 1
     assert n_coop >= 10
+
+
+@pytest.mark.parametrize("n", [24, 64, 200])
+def test_small_batch_one_launch_equals_streaming(ctx, n, monkeypatch):
+    """Batches of up to 64 fast-class windows run as one cooperative launch with fewer workgroups per window (64 windows:
+    4 each; with KBA_COOP_MAX_WIN=256 also 200 windows, 1 each): same bits as the streaming solve of the same batch
+    (KBA_STREAM_MIN=1 asks for it)."""
+    monkeypatch.setenv("KBA_COOP_MAX_WIN", "256")
+    ws = [synth.make_window(5200 + i, n_kf=3 + (i % 3), n_lm=(150, 400, 900, 2000)[i % 4], ground_frac=(0.0, 0.2)[i % 2]) for i in range(n)]
+    o = default_options()
+    results = []
+    for streaming in (False, True):
+        monkeypatch.delenv("KBA_STREAM_MIN", raising=False)
+        if streaming:
+            monkeypatch.setenv("KBA_STREAM_MIN", "1")
+        b = ba.Batch(ctx, [w.copy() for w in ws])
+        b.solve(o)
+        reps = b.download()
+        results.append((reps, [(w.kf_pose.copy(), w.kf_plane_dir.copy(), w.kf_plane_dist.copy(), w.lm_pos.copy()) for w in b.windows], [b.trimmed(i) for i in range(len(ws))]))
+        b.close()
+    monkeypatch.delenv("KBA_STREAM_MIN", raising=False)
+    (ra, pa, ta), (rb, pb, tb) = results
+    for i in range(len(ws)):
+        for key in ("termination", "iterations_total", "successful_steps", "n_trimmed_landmarks", "final_cost", "initial_cost", "num_solves"):
+            assert ra[i][key] == rb[i][key], (i, key)
+        assert all(np.array_equal(x, y) for x, y in zip(pa[i], pb[i])), i
+        assert np.array_equal(ta[i], tb[i])
 
 
 def test_committed_golden_fixtures(ctx):
