@@ -140,11 +140,13 @@ def functor_jacobian(kind, consts, *params):
 
 def first_step(window, opts):
     """The linear least-squares problem of the first LM step of solve() and the Schur-based solution: dict with J
-    (column-scaled, landmarks first), r, D, y, num_e."""
+    (column-scaled, landmarks first), r, D, y, num_e; None when the solve takes no step."""
     lib = load()
     s = window.as_struct()
     sizes = np.zeros(3, np.int32)
     rc = lib.oracle_ba_first_step(C.byref(s), C.byref(opts), sizes.ctypes.data_as(_ffi.c_int32_p), None, None, None, None)
+    if rc == 1:
+        return None  # the solve took no step (evaluation failed at x0, or it stopped at iteration zero)
     if rc != 0:
         raise RuntimeError("oracle_ba_first_step rc=%d" % rc)
     m, n = int(sizes[0]), int(sizes[1])

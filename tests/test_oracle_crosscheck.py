@@ -14,7 +14,7 @@
 import numpy as np
 import pytest
 import scipy.optimize
-from hypothesis import given, settings
+from hypothesis import assume, given, settings
 from hypothesis import strategies as st
 
 import ba_numpy
@@ -220,7 +220,7 @@ def test_sympy_local_jacobians_match_problem_evaluate(oracle):
 window_shapes = st.tuples(st.integers(0, 10_000), st.integers(2, 5), st.integers(6, 40), st.sampled_from([0.0, 0.3, 1.0]), st.sampled_from([0.0, 0.3]))
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(window_shapes, st.integers(0, 2 ** 31 - 1))
 def test_residuals_do_not_depend_on_the_origin_frame(oracle, shape, gseed):
     """Gauge: with X_k -> X_k G^-1 and p -> G p every keyframe-frame point X_k p is unchanged, so reprojection, depth and
@@ -243,7 +243,7 @@ def test_residuals_do_not_depend_on_the_origin_frame(oracle, shape, gseed):
     assert abs(c1 - c2) <= 1e-9 * c1  # ground rows (nearest keyframe by |X_k p|) and regularisers (relative poses) included
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(window_shapes)
 def test_schur_step_equals_the_dense_least_squares_step(oracle, shape):
     """SchurEliminator + dense Cholesky + back-substitution of the oracle against numpy's SVD-based lstsq on the stacked
@@ -251,6 +251,7 @@ def test_schur_step_equals_the_dense_least_squares_step(oracle, shape):
     seed, n_kf, n_lm, depth_prob, ground_frac = shape
     w = synth.make_window(seed, n_kf=n_kf, n_lm=n_lm, depth_prob=depth_prob, ground_frac=ground_frac)
     s = oracle.first_step(w, default_options())
+    assume(s is not None)  # (a window whose solve takes no step: functor failure at x0 or convergence at iteration zero)
     J, r, D, y = s["J"], s["r"], s["D"], s["y"]
     A = np.vstack([J, np.diag(D)])
     y_dense = np.linalg.lstsq(A, np.r_[r, np.zeros(len(D))], rcond=None)[0]
