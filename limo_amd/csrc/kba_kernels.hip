@@ -1474,7 +1474,7 @@ struct CoopParams {
     int32_t vp, vg;            // k_schur_lean variant (TM) of the plain / ground-plane groups
     int32_t schur_lds;         // doubles of LDS per wave in the Schur phase
     long long cap_ticks;       // wall-clock cap of a solve (100 MHz ticks), 0: none
-    int32_t* bar;              // [n_win][4] {arrived, generation, abort, -}, zeroed before the launch
+    int32_t* bar;              // [n_win][2][4] {arrived, generation, abort, -} x {all workgroups, all but the first}, zeroed before the launch
     int32_t* abort_host;       // pinned: set when a barrier timed out
     double *plane_rep, *plane_dep;
     double* red;               // [n_win][kCoopRedStride] the window's Schur slabs summed (see k_cam_solve below)
@@ -1523,8 +1523,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag;
     __shared__ double red[6 * (kBlock / 64)];
-    int32_t* bar = a.bar + 4 * w;
-    int gen = 0;
+    int32_t* bar = a.bar + 8 * w;  // [0..3]: all G workgroups, [4..7]: the workgroups 1 .. G - 1 among themselves
+    int gen = 0, gen_sub = 0;
 #ifdef KBA_COOP_TICKS  // debug build: where the time of workgroups 0, 1 and G - 1 of window 0 goes (100 MHz ticks)
     long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tl = wall_clock64();
@@ -1588,6 +1588,31 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
         KBA_GSYNC();
         const long long t0 = a.cap_ticks > 0 ? (long long)wall_clock64() : 0ll;
         for (;;) {
+            // Sum of the window's Schur slabs, entry by entry, by the workgroups first .. G - 1 (n_sum of them): cam_solve's
+            // first phase - S minus the sum of the slabs - is a chain of dependent memory round trips for ONE workgroup (a
+            // third of the kernel); here every workgroup sums a share of the entries over all slabs, in the order cam_solve
+            // adds them ((q mod 4) partial sums, then (a0 + a1) + (a2 + a3)), and workgroup 0 reads ONE slab:
+            // s - ((R + 0) + (0 + 0)) has the bits of s - R.
+            double* outr = a.red + (int64_t)w * kCoopRedStride;
+            auto slab_sum = [&](int first) __attribute__((always_inline)) {
+                if (g < first) return;
+                const int nfp = wd.nf_pad, slab = nfp * nfp, n_slab = n_pg + n_gg, n_sum = G - first;
+                const double* sp = bv.S_part + wd.spart_off;
+                for (int e = (g - first) * kBlock + tid; e < slab; e += n_sum * kBlock) {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int n4 = n_slab & ~3;
+                    for (int q0 = 0; q0 < n_slab; q0 += 16) {  // 16 loads in flight, then added in slab order
+                        double v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) v[j] = q0 + j < n_slab ? sp[(int64_t)(q0 + j) * slab + e] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            if (q0 + j < n_slab) acc[q0 + j < n4 ? (j & 3) : 0] += v[j];
+                    }
+                    outr[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                }
+            };
+            bool slabs_summed = false;
             if (st.active && st.need_lin) {
                 const bool scale_first = st.compute_scale != 0 || G == 1;
                 // ---- k_lin_lm
@@ -1610,7 +1635,16 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                     KBA_CTICK(3);
                     schur_phase(0);
                 } else {
+                    // ... and they also sum the slabs while workgroup 0 is still assembling (the camera system takes longer
+                    // than the Schur complement): a barrier among the workgroups 1 .. G - 1 only
                     schur_phase(1);
+                    KBA_CTICK(4);
+                    if (g >= 1) {
+                        if (!coop_sync(bar + 4, G - 1, gen_sub, a.abort_host)) return;
+                        slab_sum(1);
+                    }
+                    slabs_summed = true;
+                    KBA_CTICK(14);
                 }
                 KBA_CTICK(4);
             } else {
@@ -1629,30 +1663,14 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 KBA_GSYNC();
             }
             if (!st.active) break;
-            // ---- k_cam_solve.  Its first phase - S minus the sum of the Schur slabs, entry by entry - is a chain of
-            //      dependent memory round trips for ONE workgroup (a third of the kernel); here every workgroup sums a share
-            //      of the entries over all slabs first, in the order cam_solve adds them ((q mod 4) partial sums, then
-            //      (a0 + a1) + (a2 + a3)), and workgroup 0 reads ONE slab: s - ((R + 0) + (0 + 0)) has the bits of s - R.
+            // ---- k_cam_solve
             if (G > 1) {
-                const int nfp = wd.nf_pad, slab = nfp * nfp, n_slab = n_pg + n_gg;
-                const double* sp = bv.S_part + wd.spart_off;
-                double* outr = a.red + (int64_t)w * kCoopRedStride;
-                for (int e = g * kBlock + tid; e < slab; e += G * kBlock) {
-                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                    const int n4 = n_slab & ~3;
-                    for (int q0 = 0; q0 < n_slab; q0 += 16) {  // 16 loads in flight, then added in slab order
-                        double v[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) v[j] = q0 + j < n_slab ? sp[(int64_t)(q0 + j) * slab + e] : 0.0;
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            if (q0 + j < n_slab) acc[q0 + j < n4 ? (j & 3) : 0] += v[j];
-                    }
-                    outr[e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                if (!slabs_summed) {
+                    slab_sum(0);
+                    KBA_CTICK(14);
+                    KBA_GSYNC();
+                    KBA_CTICK(15);
                 }
-                KBA_CTICK(14);
-                KBA_GSYNC();
-                KBA_CTICK(15);
                 if (g == 0) {
                     BatchView bvr = bv;
                     bvr.S_red = outr - wd.sred_off;

@@ -886,13 +886,13 @@ struct limo_ba_batch : Executor {
     // false: the launch was refused (nothing ran) - the caller takes the lock-step path
     bool solve_coop() {
         const int lds = coop_lds_bytes();
-        if (!d_coop_bar && dmalloc((void**)&d_coop_bar, sizeof(int32_t) * 4 * P.n_win)) return false;
+        if (!d_coop_bar && dmalloc((void**)&d_coop_bar, sizeof(int32_t) * 8 * P.n_win)) return false;
         if (!d_coop_red && dmalloc((void**)&d_coop_red, sizeof(double) * kCoopRedStride * P.n_win)) return false;
         if (hipFuncSetAttribute((const void*)k_solve_coop, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        note(hipMemsetAsync(d_coop_bar, 0, sizeof(int32_t) * 4 * P.n_win, ctx->stream), "memset barrier words");
+        note(hipMemsetAsync(d_coop_bar, 0, sizeof(int32_t) * 8 * P.n_win, ctx->stream), "memset barrier words");
         h_active[8] = 0;
         CoopParams cp;
         cp.G = coop_G;
