@@ -946,6 +946,23 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     KBA_TICK(0);
     for (int i = tid; i < nc * nc; i += nt) H[i] = 0.0;
     for (int i = tid; i < nc; i += nt) gc[i] = 0.0;
+    // Ground-plane rows are staged through LDS in chunks (coalesced plane reads).  The first chunk is fetched here, ahead of
+    // the observation sums: its memory round trip runs under theirs instead of after them.
+    auto gp_stage = [&](int g0) {
+        const int ng = (wd.gp0 + wd.n_gp - g0) < kGpChunk ? (wd.gp0 + wd.n_gp - g0) : kGpChunk;
+        for (int i = tid; i < ng * 12; i += nt) {
+            const int q = i / ng, g = g0 + i % ng;  // q-major: consecutive lanes read consecutive rows of a plane
+            double v;
+            if (q < 10)
+                v = bv.gp_F[q * bv.SG + g];
+            else if (q == 10)
+                v = bv.gp_r[g];
+            else
+                v = (double)(bv.gp_kf[g] - wd.kf0);
+            gps[(i % ng) * 12 + q] = v;
+        }
+    };
+    if (wd.n_gp > 0) gp_stage(wd.gp0);
     KBA_SYNC();
     // (1) observations: U_k (6x6) and g_k per keyframe = sum of the camera-side partial sums of its views over the
     //     window's landmark workgroups and their waves (k_lin_lm); one lane per (keyframe, entry): single writer, fixed order.
@@ -982,22 +999,14 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     KBA_SYNC();
     KBA_TICK(1);
     if (c.pad == 41) return;  // (41-44: profiling aids, early exits after the phases)
-    // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe.  Rows are staged through LDS in chunks
-    //     (coalesced plane reads), then one lane per (keyframe, entry) adds the rows of ITS keyframe in row order.
+    // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe: one lane per (keyframe, entry) adds the staged
+    //     rows of ITS keyframe in row order.
     for (int g0 = wd.gp0; g0 < wd.gp0 + wd.n_gp; g0 += kGpChunk) {
         const int ng = (wd.gp0 + wd.n_gp - g0) < kGpChunk ? (wd.gp0 + wd.n_gp - g0) : kGpChunk;
-        for (int i = tid; i < ng * 12; i += nt) {
-            const int q = i / ng, g = g0 + i % ng;  // q-major: consecutive lanes read consecutive rows of a plane
-            double v;
-            if (q < 10)
-                v = bv.gp_F[q * bv.SG + g];
-            else if (q == 10)
-                v = bv.gp_r[g];
-            else
-                v = (double)(bv.gp_kf[g] - wd.kf0);
-            gps[(i % ng) * 12 + q] = v;
+        if (g0 != wd.gp0) {  // (the first chunk is in LDS already)
+            gp_stage(g0);
+            KBA_SYNC();
         }
-        KBA_SYNC();
         for (int e = tid; e < wd.n_kf * 110; e += nt) {
             const int kl = e / 110, q = e % 110;
             const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : 10;
