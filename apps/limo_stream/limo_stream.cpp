@@ -172,6 +172,9 @@ int main(int argc, char** argv) {
     std::printf("limo_stream: pipeline %.2f ms per frame -> %.1f frames/s (depth %.2f, pose-only %.2f, push %.2f, solve %.2f ms per frame; %.2f ms per solve()); input synthesis %.1f ms per frame\n",
                 1e3 * sec_pipeline / n_frames, n_frames / sec_pipeline, 1e3 * st.sec_depth / n_frames, 1e3 * st.sec_pose_only / n_frames,
                 1e3 * st.sec_push / n_frames, 1e3 * st.sec_solve / n_frames, st.solves ? 1e3 * st.sec_solve / st.solves : 0., 1e3 * sec_synth / n_frames);
+    std::printf("limo_stream: host side per frame: Keyframe object %.2f, keyframe selection %.2f, window cut + labels %.2f ms; inside the C-ABI: adjustPoseOnly %.2f of %.2f, solve %.2f of %.2f ms per frame\n",
+                1e3 * st.sec_keyframe / n_frames, 1e3 * st.sec_select / n_frames, 1e3 * st.sec_window / n_frames, 1e3 * st.sec_abi_pose_only / n_frames,
+                1e3 * st.sec_pose_only / n_frames, 1e3 * st.sec_abi_solve / n_frames, 1e3 * st.sec_solve / n_frames);
     std::printf("limo_stream: ATE rmse %.4f m (max %.4f m) over %.1f m\n", ate, worst, 0.55 * (n_frames - 1));
     if (te.rel_samples)
         std::printf("limo_stream: relative errors over 100..800 m sub-paths (KITTI devkit measure, %d samples): translation %.3f %%, rotation %.5f deg/m\n",

@@ -5,6 +5,9 @@
 // getKeyframe :989-1021) and src/definitions.cpp (conversions :14-28,63-69, calcQuaternionDiff :104-111).
 #include "bundle_adjuster_keyframes.hpp"
 
+#include <algorithm>
+#include <chrono>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -262,11 +265,13 @@ bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d&
 
 // ------------------------------------------------------------------------------------------ labels
 void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_weight) {
+    // (the three label sets are looked up once, not per track: a std::string key per lookup was a third of this function)
+    const std::set<int>&outlier_labels = labels_["outliers"], &shrubbery_labels = labels_["shrubbery"], &ground_labels = labels_["ground"];
     std::set<LandmarkId> outlier_ids;
     for (const auto& id : landmark_selector_->getOutliers())
         if (active_landmark_ids_.count(id)) outlier_ids.insert(id);
     for (const auto& track : t.tracks)
-        if (track.is_outlier || labels_["outliers"].count(track.label)) outlier_ids.insert(track.id);
+        if (track.is_outlier || outlier_labels.count(track.label)) outlier_ids.insert(track.id);
     landmark_selector_->clearOutliers();
     landmark_selector_->setOutlier(outlier_ids);
     for (const auto& track : t.tracks) {
@@ -274,8 +279,8 @@ void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_
         // (the reference uses landmarks_.at(), which throws for an active id that could not be reconstructed)
         auto it = landmarks_.find(track.id);
         if (it == landmarks_.end()) continue;
-        if (labels_["shrubbery"].count(track.label)) it->second->weight = shrubbery_weight;
-        it->second->is_ground_plane = labels_["ground"].count(track.label) > 0;
+        if (shrubbery_labels.count(track.label)) it->second->weight = shrubbery_weight;
+        it->second->is_ground_plane = ground_labels.count(track.label) > 0;
     }
 }
 
@@ -349,18 +354,47 @@ void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmar
         } else if (n < min_size_optimization_window - 1) {
             cur.is_active_ = true;
         } else {
-            int common = 0;  // landmark ids measured in both keyframes (std::set_intersection of the map keys, :88-111)
-            for (const auto& m : cur.measurements_)
-                if (newest.measurements_.count(m.first)) ++common;
+            int common = 0;  // landmark ids measured in both keyframes (std::set_intersection of the map keys, :88-111):
+                             // one merge pass over the two sorted key ranges
+            auto ia = cur.measurements_.cbegin();
+            auto ib = newest.measurements_.cbegin();
+            while (ia != cur.measurements_.cend() && ib != newest.measurements_.cend()) {
+                if (ia->first < ib->first)
+                    ++ia;
+                else if (ib->first < ia->first)
+                    ++ib;
+                else {
+                    ++common;
+                    ++ia;
+                    ++ib;
+                }
+            }
             cur.is_active_ = common > min_num_connecting_landmarks;
         }
         if (!cur.is_active_) active_keyframe_ids_.erase(it->first);
     }
-    std::set<LandmarkId> still_active;
-    for (const auto& kf_id : active_keyframe_ids_)
-        for (const auto& m : keyframes_.at(kf_id)->measurements_)
-            if (active_landmark_ids_.count(m.first)) still_active.insert(m.first);
-    active_landmark_ids_ = still_active;
+    // active landmarks that some active keyframe still measures: merge passes over sorted ranges, then ONE sorted insertion
+    // (a set lookup + a set insertion per measurement of every active keyframe was most of this function)
+    std::vector<LandmarkId> seen;
+    for (const auto& kf_id : active_keyframe_ids_) {
+        const auto& ms = keyframes_.at(kf_id)->measurements_;
+        auto ia = ms.begin();
+        auto ib = active_landmark_ids_.begin();
+        while (ia != ms.end() && ib != active_landmark_ids_.end()) {
+            if (ia->first < *ib)
+                ++ia;
+            else if (*ib < ia->first)
+                ++ib;
+            else {
+                seen.push_back(*ib);
+                ++ia;
+                ++ib;
+            }
+        }
+    }
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    active_landmark_ids_ = std::set<LandmarkId>(seen.begin(), seen.end());
     // oldest active keyframe fixes the gauge, second oldest carries the scale prior (:962-986)
     auto rest = getSortedIdsWithActiveKeyframePtrs();
     if (rest.size() > 0) rest[0].second->fixation_status_ = Keyframe::FixationStatus::Pose;
@@ -401,9 +435,11 @@ struct Flat {
                              : kf.fixation_status_ == Keyframe::FixationStatus::Scale ? LIMO_FIX_SCALE : LIMO_FIX_NONE);
     }
     void add_observations(int k, const Keyframe& kf, const std::map<LandmarkId, int>& lm_index) {
+        auto it = lm_index.cbegin();              // (measurements and index are both sorted by landmark id: one merge pass)
         for (const auto& m : kf.measurements_) {  // addKeyframeToProblem, :569-576
-            auto it = lm_index.find(m.first);
-            if (it == lm_index.end()) continue;
+            while (it != lm_index.cend() && it->first < m.first) ++it;
+            if (it == lm_index.cend()) break;
+            if (it->first != m.first) continue;
             for (const auto& cam_meas : m.second) {
                 obs_kf.push_back(k);
                 obs_lm.push_back(it->second);
@@ -463,7 +499,14 @@ std::string report_string(const limo_ba_report& r, const char* what) {
 
 std::string BundleAdjusterKeyframes::solve() {
     if (keyframes_.size() < 3) throw NotEnoughKeyframesException(keyframes_.size(), 3);
-    selected_landmark_ids_ = landmark_selector_->select(getActiveLandmarkConstPtrs(), getActiveKeyframeConstPtrs());
+    using clk = std::chrono::steady_clock;
+    static const bool shim_trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;  // where the host time of solve() goes
+    const auto t_s0 = clk::now();
+    const auto active_lms = getActiveLandmarkConstPtrs();
+    const auto active_kfs = getActiveKeyframeConstPtrs();
+    const auto t_s0b = clk::now();
+    selected_landmark_ids_ = landmark_selector_->select(active_lms, active_kfs);
+    const auto t_s1 = clk::now();
 
     Flat F;
     for (const auto& id : active_keyframe_ids_) F.add_keyframe(*keyframes_.at(id));
@@ -471,7 +514,7 @@ std::string BundleAdjusterKeyframes::solve() {
     for (const auto& id : selected_landmark_ids_) {
         auto it = landmarks_.find(id);
         if (it == landmarks_.end()) continue;
-        lm_index[id] = (int)F.lms.size();
+        lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
         F.lm_w.push_back(it->second->weight);
@@ -492,12 +535,19 @@ std::string BundleAdjusterKeyframes::solve() {
     limo_ba_report rep;
     limo_ctx* ctx = context();
     dump_window_if_asked(F.w);
+    const auto t_s2 = clk::now();
     const int rc = limo_ba_solve(ctx, &F.w, &o, &rep);
+    const auto t_s3 = clk::now();
     if (rc == LIMO_ERR_NOT_ENOUGH_KF) throw NotEnoughKeyframesException(F.kfs.size(), 3);
     if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_ba_solve: ") + limo_last_error(ctx));
     F.write_back(true);
     last_report_ = {rep.termination, rep.num_solves, rep.iterations_total, rep.n_trimmed_landmarks, rep.n_depth_blocks,
                     rep.n_repr_blocks, rep.n_gp_blocks, rep.initial_cost, rep.final_cost, rep.time_sec};
+    if (shim_trace) {
+        auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[shim] solve: %zu active landmarks, %zu selected: active maps %.0f us, selection %.0f us, flatten %.0f us, limo_ba_solve %.0f us, write-back %.0f us\n",
+                     active_landmark_ids_.size(), selected_landmark_ids_.size(), us(t_s0, t_s0b), us(t_s0b, t_s1), us(t_s1, t_s2), us(t_s2, t_s3), us(t_s3, clk::now()));
+    }
     return report_string(rep, "solve");
 }
 
@@ -509,7 +559,7 @@ std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
     for (const auto& id : selected_landmark_ids_) {
         auto it = landmarks_.find(id);
         if (it == landmarks_.end()) continue;
-        lm_index[id] = (int)F.lms.size();
+        lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
         F.lm_w.push_back(it->second->weight);

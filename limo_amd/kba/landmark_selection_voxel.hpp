@@ -44,24 +44,41 @@ namespace landmark_helpers {
 inline std::map<LandmarkId, double> calcFlow(const std::vector<LandmarkId>& ids,
                                              const std::vector<Keyframe::ConstPtr>& kfs_in_time_order, bool use_mean) {
     std::map<LandmarkId, double> out;
+    struct PerCam {  // (a landmark is seen by one or two cameras: a flat list instead of three std::maps per landmark)
+        CameraId cam;
+        Measurement last;
+        double sum;
+        int cnt;
+    };
+    std::vector<PerCam> cams;
     for (const auto& id : ids) {
-        std::map<CameraId, Measurement> last;
-        std::map<CameraId, double> sum;
-        std::map<CameraId, int> cnt;
-        for (const auto& kf : kfs_in_time_order)
-            for (const auto& cm : kf->getMeasurements(id)) {
-                auto it = last.find(cm.first);
-                if (it != last.end()) {
-                    const double du = double(it->second.u) - double(cm.second.u), dv = double(it->second.v) - double(cm.second.v);
-                    sum[cm.first] += std::sqrt(du * du + dv * dv);
-                    cnt[cm.first] += 1;
+        cams.clear();
+        for (const auto& kf : kfs_in_time_order) {
+            const auto im = kf->measurements_.find(id);  // (= getMeasurements(id) without the copy: the cameras that measured it)
+            if (im == kf->measurements_.cend()) continue;
+            for (const auto& cm : im->second) {
+                if (!kf->cameras_.count(cm.first)) continue;
+                PerCam* pc = nullptr;
+                for (auto& c : cams)
+                    if (c.cam == cm.first) pc = &c;
+                if (pc) {
+                    const double du = double(pc->last.u) - double(cm.second.u), dv = double(pc->last.v) - double(cm.second.v);
+                    pc->sum += std::sqrt(du * du + dv * dv);
+                    pc->cnt += 1;
+                    pc->last = cm.second;
+                } else {
+                    cams.push_back({cm.first, cm.second, 0., 0});
                 }
-                last[cm.first] = cm.second;
             }
-        if (sum.empty()) continue;
+        }
         double best = -1.;
-        for (const auto& s : sum) best = std::max(best, use_mean ? s.second / cnt.at(s.first) : s.second);
-        out[id] = best;
+        bool any = false;
+        for (const auto& c : cams) {
+            if (c.cnt == 0) continue;
+            any = true;
+            best = std::max(best, use_mean ? c.sum / c.cnt : c.sum);
+        }
+        if (any) out.insert(out.end(), {id, best});
     }
     return out;
 }
@@ -75,14 +92,15 @@ inline std::map<LandmarkId, double> calcFlow(const std::vector<LandmarkId>& ids,
 
 inline std::vector<LandmarkId> chooseNearLmIds(size_t max_num, const std::vector<LandmarkId>& near_ids,
                                                const std::map<LandmarkId, double>& flow) {
+    std::vector<std::pair<double, LandmarkId>> keyed;  // (the flow of an id is looked up once, not in every comparison)
+    for (const auto& id : near_ids) {
+        const auto it = flow.find(id);
+        if (it != flow.end()) keyed.push_back({it->second, id});
+    }
+    std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    keyed.resize(std::min(max_num, keyed.size()));
     std::vector<LandmarkId> ids;
-    for (const auto& id : near_ids)
-        if (flow.count(id)) ids.push_back(id);
-    std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) {
-        const double fa = flow.at(a), fb = flow.at(b);
-        return fa > fb || (fa == fb && a < b);
-    });
-    ids.resize(std::min(max_num, ids.size()));
+    for (const auto& k : keyed) ids.push_back(k.second);
     return ids;
 }
 // A uniformly random subset of max_num ids, deterministic in (ids, seed) and STABLE: every id gets the rank
@@ -107,17 +125,17 @@ inline std::vector<LandmarkId> chooseMiddleLmIds(size_t max_num, const std::vect
 }
 inline std::vector<LandmarkId> chooseFarLmIds(size_t max_num, const std::vector<LandmarkId>& far_ids,
                                               const std::map<KeyframeId, Keyframe::ConstPtr>& keyframes) {
-    std::map<LandmarkId, unsigned> count;
+    std::vector<std::pair<unsigned, LandmarkId>> keyed;
     for (const auto& id : far_ids) {
-        count[id] = 0;
+        unsigned n = 0;
         for (const auto& kf : keyframes)
-            if (kf.second->hasMeasurement(id)) count[id] += 1;
+            if (kf.second->hasMeasurement(id)) n += 1;
+        keyed.push_back({n, id});
     }
-    std::vector<LandmarkId> ids(far_ids);
-    std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) {
-        return count.at(a) > count.at(b) || (count.at(a) == count.at(b) && a < b);
-    });
-    ids.resize(std::min(max_num, ids.size()));
+    std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    keyed.resize(std::min(max_num, keyed.size()));
+    std::vector<LandmarkId> ids;
+    for (const auto& k : keyed) ids.push_back(k.second);
     return ids;
 }
 
@@ -182,33 +200,34 @@ public:
             else
                 ids_far.push_back(id_lm.first);
         }
-        // voxel grid over the pipe: one representative per occupied voxel
-        struct Cell {
-            double sx = 0, sy = 0, sz = 0;
-            std::vector<size_t> members;
-        };
-        std::map<std::array<long, 3>, Cell> grid;
-        for (size_t i = 0; i < pipe.size(); ++i) {
-            const std::array<long, 3> key{{(long)std::floor(pipe[i].p[0] / params_.voxel_size_xyz[0]),
-                                           (long)std::floor(pipe[i].p[1] / params_.voxel_size_xyz[1]),
-                                           (long)std::floor(pipe[i].p[2] / params_.voxel_size_xyz[2])}};
-            Cell& c = grid[key];
-            c.sx += pipe[i].p[0];
-            c.sy += pipe[i].p[1];
-            c.sz += pipe[i].p[2];
-            c.members.push_back(i);
-        }
+        // voxel grid over the pipe: one representative per occupied voxel.  (voxel key, pipe index) pairs sorted by key, the
+        // members of a voxel in pipe order (= landmark id order, the order their coordinates are summed in) - instead of a
+        // std::map of cells with a member vector each.
+        std::vector<std::pair<std::array<long, 3>, size_t>> cells(pipe.size());
+        for (size_t i = 0; i < pipe.size(); ++i)
+            cells[i] = {{{(long)std::floor(pipe[i].p[0] / params_.voxel_size_xyz[0]), (long)std::floor(pipe[i].p[1] / params_.voxel_size_xyz[1]),
+                          (long)std::floor(pipe[i].p[2] / params_.voxel_size_xyz[2])}},
+                        i};
+        std::sort(cells.begin(), cells.end());
         std::vector<LandmarkId> ids_near, ids_middle;
-        for (const auto& kc : grid) {
-            const Cell& c = kc.second;
-            const double n = (double)c.members.size();
-            const Vector3d centroid(c.sx / n, c.sy / n, c.sz / n);
-            size_t best = c.members[0];
+        for (size_t c0 = 0; c0 < cells.size();) {
+            size_t c1 = c0;
+            double sx = 0, sy = 0, sz = 0;
+            while (c1 < cells.size() && cells[c1].first == cells[c0].first) {
+                sx += pipe[cells[c1].second].p[0];
+                sy += pipe[cells[c1].second].p[1];
+                sz += pipe[cells[c1].second].p[2];
+                ++c1;
+            }
+            const double n = (double)(c1 - c0);
+            const Vector3d centroid(sx / n, sy / n, sz / n);
+            size_t best = cells[c0].second;
             double bd = std::numeric_limits<double>::max();
             // nearest member to the centroid; members whose distances agree to 1e-9 relative count as equidistant and the
             // smaller id wins - the two members of a 2-member voxel are ALWAYS equidistant from their midpoint, and which
             // of the two computed distances comes out smaller is rounding noise
-            for (size_t i : c.members) {
+            for (size_t q = c0; q < c1; ++q) {
+                const size_t i = cells[q].second;
                 const double d = (pipe[i].p - centroid).norm();
                 const bool tie = std::fabs(d - bd) <= 1e-9 * (d + bd);
                 if ((!tie && d < bd) || (tie && pipe[i].id < pipe[best].id)) {
@@ -217,6 +236,7 @@ public:
                 }
             }
             (pipe[best].dist < params_.roi_middle_xyz[0] ? ids_near : ids_middle).push_back(pipe[best].id);
+            c0 = c1;
         }
         const auto flow = landmark_helpers::calcFlow(ids_near, keyframes, false);
         for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, ids_near, flow)) out[id] = Category::NearField;
@@ -255,10 +275,13 @@ public:
             if (ind < 0 || ind > (int)kfs.size() - 1) continue;
             const Keyframe& kf = *kfs[ind];
             std::vector<std::pair<LandmarkId, double>> keyed;
+            const EigenPose T = kf.getEigenPose();
+            auto it = landmarks.cbegin();  // (measurements and landmarks are both sorted by id: one merge pass)
             for (const auto& m : kf.measurements_) {
-                auto it = landmarks.find(m.first);
-                if (it == landmarks.cend() || !std::get<2>(el)(it->second)) continue;
-                const Vector3d local = kf.getEigenPose() * Vector3d(it->second->pos.data());
+                while (it != landmarks.cend() && it->first < m.first) ++it;
+                if (it == landmarks.cend()) break;
+                if (it->first != m.first || !std::get<2>(el)(it->second)) continue;
+                const Vector3d local = T * Vector3d(it->second->pos.data());
                 double worst = -std::numeric_limits<double>::max();  // largest key over the cameras that see it
                 for (const auto& cam_meas : m.second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
                 keyed.push_back({m.first, worst});

@@ -4,6 +4,10 @@
 // (it defines the INPUT of the hot path).
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
 #include <random>
 #include <string>
 
@@ -46,15 +50,41 @@ public:
 class LandmarkRejectionSchemeCheirality : public LandmarkRejectionSchemeBase {
 public:
     std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
-        std::set<LandmarkId> out;
-        for (const auto& lm : landmarks) {
-            bool ok = true;
-            for (const auto& id_kf : keyframes) {
-                if (!id_kf.second->is_active_) continue;
-                for (const auto& cam_lm : id_kf.second->getProjectedLandmarkPosition(lm))
-                    if (cam_lm.second.z() < 0.) ok = false;
+        // Same test as Keyframe::getProjectedLandmarkPosition per (landmark, keyframe) - camera <- vehicle <- origin applied
+        // to the landmark, z < 0 rejects - as ONE merge pass per keyframe over its measurements and the landmarks (both
+        // sorted by id), the keyframe's and the cameras' transforms formed once: the per-pair std::map the accessor
+        // returns, a lookup per pair and a quaternion conversion per pair were 1.3 ms of every solve() at 1500 landmarks.
+        std::vector<char> bad(landmarks.size(), 0);
+        for (const auto& id_kf : keyframes) {
+            const Keyframe& kf = *id_kf.second;
+            if (!kf.is_active_) continue;
+            const EigenPose T = kf.getEigenPose();
+            std::map<CameraId, EigenPose> cam_T;
+            for (const auto& c : kf.cameras_) cam_T[c.first] = c.second->getEigenPose();
+            auto il = landmarks.cbegin();
+            auto im = kf.measurements_.cbegin();
+            size_t i = 0;
+            while (il != landmarks.cend() && im != kf.measurements_.cend()) {
+                if (il->first < im->first) {
+                    ++il;
+                    ++i;
+                } else if (im->first < il->first) {
+                    ++im;
+                } else {
+                    const Vector3d p_vehicle = T * Vector3d(il->second->pos.data());
+                    for (const auto& cam_meas : im->second)
+                        if ((cam_T.at(cam_meas.first) * p_vehicle).z() < 0.) bad[i] = 1;
+                    ++il;
+                    ++i;
+                    ++im;
+                }
             }
-            if (ok) out.insert(lm.first);
+        }
+        std::set<LandmarkId> out;
+        size_t i = 0;
+        for (const auto& lm : landmarks) {
+            if (!bad[i]) out.insert(out.end(), lm.first);
+            ++i;
         }
         return out;
     }
@@ -93,48 +123,84 @@ public:
     // landmark_selector.hpp:118-253: drop flagged outliers, apply every rejection scheme (set shrinks), collect the
     // must-have selections, sparsify the rest, union, remember what was not selected.
     std::set<LandmarkId> select(const LandmarkMap& landmarks, const KeyframeMap& kfs) {
-        LandmarkMap pool = landmarks;
-        for (const auto& id : outlier_ids_) pool.erase(id);
+        using clk = std::chrono::steady_clock;
+        static const bool trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;
+        const auto t0 = clk::now();
+        LandmarkMap pool;
+        for (const auto& el : landmarks)
+            if (!outlier_ids_.count(el.first)) pool.insert(pool.end(), el);
         for (const auto& scheme : rejection_schemes_) pool = restrict(landmarks, run(scheme, pool, kfs));
+        const auto t1 = clk::now();
         LandmarkMap must;
         for (const auto& scheme : selection_schemes_)
             for (const auto& el : restrict(pool, run(scheme, pool, kfs))) must[el.first] = el.second;
+        const auto t2 = clk::now();
         LandmarkMap thin = pool;
         for (const auto& scheme : sparsification_schemes_) thin = restrict(pool, run(scheme, thin, kfs));
+        const auto t3 = clk::now();
         for (const auto& el : must) thin[el.first] = el.second;
         std::set<LandmarkId> selection;
-        for (const auto& el : thin) selection.insert(el.first);
+        for (const auto& el : thin) selection.insert(selection.end(), el.first);
+        const auto t4 = clk::now();
         if (!kfs.empty()) {
             TimestampNSec newest = 0;
             for (const auto& kf : kfs) newest = std::max(newest, kf.second->timestamp_);
-            for (const auto& lm : landmarks)
-                if (!selection.count(lm.first)) markUnselected(lm.first, newest);
+            auto is = selection.cbegin();  // (landmarks and selection are both sorted by id: one merge pass)
+            for (const auto& lm : landmarks) {
+                while (is != selection.cend() && *is < lm.first) ++is;
+                if (is == selection.cend() || *is != lm.first) markUnselected(lm.first, newest);
+            }
             const TimestampNSec ten_s = convert(TimestampSec(10.));
             clean(newest > ten_s ? newest - ten_s : 0);
         }
         last_selected_lms_ = selection;
+        if (trace) {
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[shim] select: rejection %.0f us, must-have %.0f us, sparsification %.0f us, union %.0f us, unselected bookkeeping %.0f us (%zu tracked)\n",
+                         us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, clk::now()), last_time_seen_.size());
+        }
         return selection;
     }
 
     void markUnselected(LandmarkId lm_id, TimestampNSec last_time_seen) {
         unselected_lms_[lm_id] += 1;
         last_time_seen_[lm_id] = last_time_seen;
+        if (!marks_.empty() && last_time_seen < marks_.back().first) marks_in_time_order_ = false;
+        marks_.push_back({last_time_seen, lm_id});
     }
+    // Forget the landmarks last marked before `oldest` (landmark_selector.hpp:240-252).  The marks are also kept as a queue
+    // in the order they were made - time order, the callers' stamps only grow -, so the expired ones are at its front:
+    // a scan of the whole map per call (15 k landmarks after ten seconds of driving) was 1 ms of every solve().
     void clean(TimestampNSec oldest) {
-        for (auto it = last_time_seen_.begin(); it != last_time_seen_.end();) {
-            if (it->second < oldest) {
-                unselected_lms_.erase(it->first);
-                it = last_time_seen_.erase(it);
-            } else {
-                ++it;
+        if (!marks_in_time_order_) {  // (marks with a decreasing stamp: fall back to the full scan, then start over)
+            for (auto it = last_time_seen_.begin(); it != last_time_seen_.end();) {
+                if (it->second < oldest) {
+                    unselected_lms_.erase(it->first);
+                    it = last_time_seen_.erase(it);
+                } else {
+                    ++it;
+                }
             }
+            marks_.clear();
+            for (const auto& el : last_time_seen_) marks_.push_back({el.second, el.first});
+            std::sort(marks_.begin(), marks_.end());
+            marks_in_time_order_ = true;
+            return;
+        }
+        while (!marks_.empty() && marks_.front().first < oldest) {
+            const auto it = last_time_seen_.find(marks_.front().second);
+            if (it != last_time_seen_.end() && it->second < oldest) {  // (not marked again since)
+                unselected_lms_.erase(it->first);
+                last_time_seen_.erase(it);
+            }
+            marks_.pop_front();
         }
     }
     const std::map<LandmarkId, unsigned int>& getUnselectedLandmarks() const { return unselected_lms_; }
     const std::map<LandmarkId, LandmarkCategorizatonInterface::Category>& getLandmarkCategories() const {
         return landmark_categories_;
     }
-    std::set<LandmarkId> getLastSelection() const { return last_selected_lms_; }
+    const std::set<LandmarkId>& getLastSelection() const { return last_selected_lms_; }
     void clearOutliers() { outlier_ids_.clear(); }
     const std::set<LandmarkId>& getOutliers() const { return outlier_ids_; }
     void setOutlier(LandmarkId id) { outlier_ids_.insert(id); }
@@ -155,19 +221,31 @@ private:
         if (!cat) return scheme->getSelection(lms, kfs);
         landmark_categories_ = cat->getCategorizedSelection(lms, kfs);
         std::set<LandmarkId> out;
-        for (const auto& el : landmark_categories_) out.insert(el.first);
+        for (const auto& el : landmark_categories_) out.insert(out.end(), el.first);
         return out;
     }
+    // the entries of `all` whose id is in `ids` (both sorted: one merge pass, appended in order)
     static LandmarkMap restrict(const LandmarkMap& all, const std::set<LandmarkId>& ids) {
         LandmarkMap out;
-        for (const auto& id : ids) {
-            auto it = all.find(id);
-            if (it != all.end()) out[id] = it->second;
+        auto ia = all.cbegin();
+        auto ii = ids.cbegin();
+        while (ia != all.cend() && ii != ids.cend()) {
+            if (ia->first < *ii)
+                ++ia;
+            else if (*ii < ia->first)
+                ++ii;
+            else {
+                out.insert(out.end(), *ia);
+                ++ia;
+                ++ii;
+            }
         }
         return out;
     }
     std::map<LandmarkId, unsigned int> unselected_lms_;
     std::map<LandmarkId, TimestampNSec> last_time_seen_;
+    std::deque<std::pair<TimestampNSec, LandmarkId>> marks_;  // every markUnselected call, oldest first
+    bool marks_in_time_order_ = true;
     std::set<LandmarkId> last_selected_lms_;
     std::map<LandmarkId, LandmarkCategorizatonInterface::Category> landmark_categories_;
 };

@@ -61,6 +61,9 @@ public:
     struct Stats {
         int frames = 0, keyframes = 0, solves = 0, solves_on_non_keyframes = 0, features = 0, features_with_depth = 0;
         double sec_depth = 0., sec_pose_only = 0., sec_push = 0., sec_solve = 0., sec_total = 0.;
+        // host-side bookkeeping of a frame: the Keyframe object of the frame (measurement maps of its tracks), keyframe
+        // selection, window cut + labels; and of sec_pose_only / sec_solve the share spent inside the C-ABI calls
+        double sec_keyframe = 0., sec_select = 0., sec_window = 0., sec_abi_pose_only = 0., sec_abi_solve = 0.;
     };
 
     StreamDriver(const StreamParams& p, Camera::Ptr camera, const EigenPose& T_camera_lidar) : p_(p), camera_(camera), T_cam_lidar_(T_camera_lidar) {
@@ -123,28 +126,36 @@ public:
                 for (int i = 0; i < 4; ++i) q[i] /= n;
                 prior = convert(q);
             }
+            const auto t_kf = clk::now();
             auto cur = std::make_shared<Keyframe>(stamp, tracklets, camera_, prior, Keyframe::FixationStatus::None, ground_plane);
+            stats_.sec_keyframe += std::chrono::duration<double>(clk::now() - t_kf).count();
             if (!external_prior) {  // a prior without scale is always refined against the fixed landmarks of the last
                                     // selection (:200-211; before the first solve() that selection is empty)
                 const auto t0 = clk::now();
                 ba_.adjustPoseOnly(*cur);
                 stats_.sec_pose_only += std::chrono::duration<double>(clk::now() - t0).count();
+                stats_.sec_abi_pose_only += ba_.last_report_.time_sec;
                 trace("pose-only", stamp, cur->pose_, ba_.last_report_.final_cost);
             }
             pose = cur->getEigenPose();
+            const auto t_sel = clk::now();
             const auto selected = selector_.select({cur}, ba_.getActiveKeyframePtrs());
             const auto t1 = clk::now();
+            stats_.sec_select += std::chrono::duration<double>(t1 - t_sel).count();
             for (const auto& kf : selected) ba_.push(*kf);
             stats_.sec_push += std::chrono::duration<double>(clk::now() - t1).count();
             is_keyframe = !selected.empty();
             const double now_sec = convert(stamp);
             // bundle adjustment every time_between_keyframes, whether or not THIS frame became a keyframe (:245-246)
             if (ba_.keyframes_.size() > 2 && now_sec - last_solved_sec_ > 0.98 * p_.time_between_keyframes_sec) {
+                const auto t_w = clk::now();
                 ba_.deactivateKeyframes(p_.min_number_connecting_landmarks, 3, p_.max_size_optimization_window);
                 ba_.updateLabels(tracklets, p_.shrubbery_weight);
                 const auto t2 = clk::now();
+                stats_.sec_window += std::chrono::duration<double>(t2 - t_w).count();
                 last_summary_ = ba_.solve();
                 stats_.sec_solve += std::chrono::duration<double>(clk::now() - t2).count();
+                stats_.sec_abi_solve += ba_.last_report_.time_sec;
                 ++stats_.solves;
                 trace("solve", stamp, ba_.getKeyframe().pose_, ba_.last_report_.final_cost);
                 stats_.solves_on_non_keyframes += !is_keyframe;
