@@ -20,6 +20,47 @@
 
 namespace keyframe_bundle_adjustment {
 
+namespace {
+// Successive lookups of (mostly) increasing keys in a std::map: continues from the last position with a short walk instead
+// of a descent from the root per key.  landmarks_ holds every landmark of the drive (hundreds of thousands after a few
+// minutes) while the ids asked for - the active ones - sit next to each other at its end.
+template <class T>
+const T& key_of(const T& v) {
+    return v;
+}
+template <class K, class V>
+const K& key_of(const std::pair<const K, V>& v) {
+    return v.first;
+}
+template <class Map>
+class SortedFinder {
+public:
+    explicit SortedFinder(const Map& m) : m_(m), it_(m.cend()) {}
+    typename Map::const_iterator find(const typename Map::key_type& k) {
+        if (!started_ || it_ == m_.cend() || k < key_of(*it_)) {
+            it_ = m_.lower_bound(k);
+            started_ = true;
+        } else {
+            int steps = 0;
+            while (it_ != m_.cend() && key_of(*it_) < k) {
+                ++it_;
+                if (++steps > 32) {
+                    it_ = m_.lower_bound(k);
+                    break;
+                }
+            }
+        }
+        return (it_ != m_.cend() && key_of(*it_) == k) ? it_ : m_.cend();
+    }
+
+private:
+    const Map& m_;
+    typename Map::const_iterator it_;
+    bool started_ = false;
+};
+}  // namespace
+
+
 // Debugging aid: LIMO_KBA_DUMP=<dir>[:<first>[:<last>]] writes the flattened window of the solve() calls number first..last
 // (default: all) as <dir>/solve_NNNNNN.bin = int32 n_kf, n_cam, n_lm, n_obs, then the arrays of limo_ba_window in declaration
 // order (tests/window_io.py reads them back into a Window): how a window of a long drive becomes a test fixture.
@@ -187,8 +228,10 @@ void BundleAdjusterKeyframes::push(const std::vector<Keyframe>& kfs) {
     for (const auto& kf : kfs) push(kf);
 }
 
-void BundleAdjusterKeyframes::push(const Keyframe& kf) {
-    keyframes_[kf.timestamp_] = std::make_shared<Keyframe>(kf);
+void BundleAdjusterKeyframes::push(const Keyframe& kf) { push(Keyframe(kf)); }
+
+void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
+    const Keyframe& kf = *(keyframes_[kf_in.timestamp_] = std::make_shared<Keyframe>(std::move(kf_in)));
     active_keyframe_ids_.insert(kf.timestamp_);
     // Every landmark this keyframe introduces is initialised in ONE device call (the reference does it one by one,
     // :289-330): depth back-projection where the keyframe measures a depth, N-view triangulation otherwise.
@@ -196,8 +239,9 @@ void BundleAdjusterKeyframes::push(const Keyframe& kf) {
     std::vector<int32_t> off{0};
     std::vector<limo_ray> rays;
     std::vector<uint8_t> use_depth;
+    SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& m : kf.measurements_) {
-        if (landmarks_.find(m.first) != landmarks_.cend()) continue;
+        if (known.find(m.first) != landmarks_.cend()) continue;
         const bool has_depth = containsDepth(kf, m.first);
         const size_t before = rays.size();
         if (has_depth) {
@@ -221,8 +265,9 @@ void BundleAdjusterKeyframes::push(const Keyframe& kf) {
         for (size_t i = 0; i < ids.size(); ++i)
             if (ok[i]) landmarks_[ids[i]] = std::make_shared<Landmark>(Vector3d(pos.data() + 3 * i), use_depth[i] != 0);
     }
+    SortedFinder<decltype(landmarks_)> now_known(landmarks_);
     for (const auto& m : kf.measurements_)
-        if (landmarks_.find(m.first) != landmarks_.cend()) active_landmark_ids_.insert(m.first);
+        if (now_known.find(m.first) != landmarks_.cend()) active_landmark_ids_.insert(m.first);
 }
 
 void BundleAdjusterKeyframes::collectRays(const Keyframe& kf, const LandmarkId& lId, std::vector<limo_ray>& rays) const {
@@ -274,11 +319,13 @@ void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_
         if (track.is_outlier || outlier_labels.count(track.label)) outlier_ids.insert(track.id);
     landmark_selector_->clearOutliers();
     landmark_selector_->setOutlier(outlier_ids);
+    SortedFinder<decltype(active_landmark_ids_)> active(active_landmark_ids_);
+    SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& track : t.tracks) {
-        if (!active_landmark_ids_.count(track.id)) continue;
+        if (active.find(track.id) == active_landmark_ids_.cend()) continue;
         // (the reference uses landmarks_.at(), which throws for an active id that could not be reconstructed)
-        auto it = landmarks_.find(track.id);
-        if (it == landmarks_.end()) continue;
+        auto it = known.find(track.id);
+        if (it == landmarks_.cend()) continue;
         if (shrubbery_labels.count(track.label)) it->second->weight = shrubbery_weight;
         it->second->is_ground_plane = ground_labels.count(track.label) > 0;
     }
@@ -287,9 +334,10 @@ void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_
 // ------------------------------------------------------------------------------------------ getters
 std::map<LandmarkId, Landmark::ConstPtr> BundleAdjusterKeyframes::filterLandmarksById(const std::set<LandmarkId>& ids) const {
     std::map<LandmarkId, Landmark::ConstPtr> out;
+    SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : ids) {
-        auto it = landmarks_.find(id);
-        if (it != landmarks_.cend()) out[id] = it->second;
+        auto it = known.find(id);
+        if (it != landmarks_.cend()) out.insert(out.end(), {id, it->second});
     }
     return out;
 }
@@ -373,28 +421,38 @@ void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmar
         }
         if (!cur.is_active_) active_keyframe_ids_.erase(it->first);
     }
-    // active landmarks that some active keyframe still measures: merge passes over sorted ranges, then ONE sorted insertion
-    // (a set lookup + a set insertion per measurement of every active keyframe was most of this function)
-    std::vector<LandmarkId> seen;
+    // active landmarks that some active keyframe still measures: one merge pass per keyframe over its measurements and the
+    // active ids (both sorted) that flags the ids it meets; the flagged ids, in order, are the new set (a set lookup and
+    // a set insertion per measurement of every active keyframe was most of this function)
+    std::vector<char> keep(active_landmark_ids_.size(), 0);
     for (const auto& kf_id : active_keyframe_ids_) {
         const auto& ms = keyframes_.at(kf_id)->measurements_;
-        auto ia = ms.begin();
-        auto ib = active_landmark_ids_.begin();
-        while (ia != ms.end() && ib != active_landmark_ids_.end()) {
+        auto ia = ms.cbegin();
+        auto ib = active_landmark_ids_.cbegin();
+        size_t i = 0;
+        while (ia != ms.cend() && ib != active_landmark_ids_.cend()) {
             if (ia->first < *ib)
                 ++ia;
-            else if (*ib < ia->first)
+            else if (*ib < ia->first) {
                 ++ib;
-            else {
-                seen.push_back(*ib);
+                ++i;
+            } else {
+                keep[i] = 1;
                 ++ia;
                 ++ib;
+                ++i;
             }
         }
     }
-    std::sort(seen.begin(), seen.end());
-    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
-    active_landmark_ids_ = std::set<LandmarkId>(seen.begin(), seen.end());
+    {
+        std::set<LandmarkId> still_active;
+        size_t i = 0;
+        for (const auto& id : active_landmark_ids_) {
+            if (keep[i]) still_active.insert(still_active.end(), id);
+            ++i;
+        }
+        active_landmark_ids_.swap(still_active);
+    }
     // oldest active keyframe fixes the gauge, second oldest carries the scale prior (:962-986)
     auto rest = getSortedIdsWithActiveKeyframePtrs();
     if (rest.size() > 0) rest[0].second->fixation_status_ = Keyframe::FixationStatus::Pose;
@@ -511,9 +569,10 @@ std::string BundleAdjusterKeyframes::solve() {
     Flat F;
     for (const auto& id : active_keyframe_ids_) F.add_keyframe(*keyframes_.at(id));
     std::map<LandmarkId, int> lm_index;
+    SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
-        auto it = landmarks_.find(id);
-        if (it == landmarks_.end()) continue;
+        auto it = known.find(id);
+        if (it == landmarks_.cend()) continue;
         lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
@@ -556,9 +615,10 @@ std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
     Flat F;
     F.add_keyframe(kf);
     std::map<LandmarkId, int> lm_index;
+    SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
-        auto it = landmarks_.find(id);
-        if (it == landmarks_.end()) continue;
+        auto it = known.find(id);
+        if (it == landmarks_.cend()) continue;
         lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);

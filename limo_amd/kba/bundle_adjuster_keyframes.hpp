@@ -49,6 +49,7 @@ public:
     BundleAdjusterKeyframes& operator=(const BundleAdjusterKeyframes&) = delete;
 
     void push(const Keyframe& kf);
+    void push(Keyframe&& kf);  // (same, without copying the keyframe's measurement maps: for callers that hand the keyframe over)
     void push(const std::vector<Keyframe>& kfs);
     std::string solve();
     void deactivateKeyframes(int min_num_connecting_landmarks = 3, int min_size_optimization_window = 4,

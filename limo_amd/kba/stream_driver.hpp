@@ -142,7 +142,12 @@ public:
             const auto selected = selector_.select({cur}, ba_.getActiveKeyframePtrs());
             const auto t1 = clk::now();
             stats_.sec_select += std::chrono::duration<double>(t1 - t_sel).count();
-            for (const auto& kf : selected) ba_.push(*kf);
+            for (const auto& kf : selected) {
+                if (kf == cur)  // (this frame's keyframe object is not looked at again below: hand it over instead of copying its maps)
+                    ba_.push(std::move(*cur));
+                else
+                    ba_.push(*kf);
+            }
             stats_.sec_push += std::chrono::duration<double>(clk::now() - t1).count();
             is_keyframe = !selected.empty();
             const double now_sec = convert(stamp);
@@ -150,8 +155,12 @@ public:
             if (ba_.keyframes_.size() > 2 && now_sec - last_solved_sec_ > 0.98 * p_.time_between_keyframes_sec) {
                 const auto t_w = clk::now();
                 ba_.deactivateKeyframes(p_.min_number_connecting_landmarks, 3, p_.max_size_optimization_window);
+                const auto t_w1 = clk::now();
                 ba_.updateLabels(tracklets, p_.shrubbery_weight);
                 const auto t2 = clk::now();
+                if (std::getenv("LIMO_SHIM_TRACE"))
+                    std::fprintf(stderr, "[shim] window cut %.0f us, labels %.0f us\n", std::chrono::duration<double, std::micro>(t_w1 - t_w).count(),
+                                 std::chrono::duration<double, std::micro>(t2 - t_w1).count());
                 stats_.sec_window += std::chrono::duration<double>(t2 - t_w).count();
                 last_summary_ = ba_.solve();
                 stats_.sec_solve += std::chrono::duration<double>(clk::now() - t2).count();
