@@ -493,6 +493,13 @@ struct Flat {
                              : kf.fixation_status_ == Keyframe::FixationStatus::Scale ? LIMO_FIX_SCALE : LIMO_FIX_NONE);
     }
     void add_observations(int k, const Keyframe& kf, const std::map<LandmarkId, int>& lm_index) {
+        const size_t room = obs_kf.size() + lm_index.size();
+        obs_kf.reserve(room);
+        obs_lm.reserve(room);
+        obs_cam.reserve(room);
+        u.reserve(room);
+        v.reserve(room);
+        d.reserve(room);
         auto it = lm_index.cbegin();              // (measurements and index are both sorted by landmark id: one merge pass)
         for (const auto& m : kf.measurements_) {  // addKeyframeToProblem, :569-576
             while (it != lm_index.cend() && it->first < m.first) ++it;

@@ -270,21 +270,47 @@ public:
         for (const auto& kf : keyframes)
             if (kf.second->is_active_) kfs.push_back(kf.second);
         std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
-        for (const auto& el : params_.params_per_keyframe) {
+        // the landmarks every configuration's predicate lets through, collected in ONE pass over the landmark map
+        const size_t n_cfg = params_.params_per_keyframe.size();
+        std::vector<std::vector<LandmarkMap::const_iterator>> qualifies(n_cfg);
+        for (auto it = landmarks.cbegin(); it != landmarks.cend(); ++it)
+            for (size_t c = 0; c < n_cfg; ++c) {
+                const FrameIndex ind = std::get<0>(params_.params_per_keyframe[c]);
+                if (ind < 0 || ind > (int)kfs.size() - 1) continue;
+                if (std::get<2>(params_.params_per_keyframe[c])(it->second)) qualifies[c].push_back(it);
+            }
+        for (size_t cfg = 0; cfg < n_cfg; ++cfg) {
+            const auto& el = params_.params_per_keyframe[cfg];
             const FrameIndex ind = std::get<0>(el);
             if (ind < 0 || ind > (int)kfs.size() - 1) continue;
             const Keyframe& kf = *kfs[ind];
             std::vector<std::pair<LandmarkId, double>> keyed;
             const EigenPose T = kf.getEigenPose();
-            auto it = landmarks.cbegin();  // (measurements and landmarks are both sorted by id: one merge pass)
-            for (const auto& m : kf.measurements_) {
-                while (it != landmarks.cend() && it->first < m.first) ++it;
-                if (it == landmarks.cend()) break;
-                if (it->first != m.first || !std::get<2>(el)(it->second)) continue;
-                const Vector3d local = T * Vector3d(it->second->pos.data());
+            // the landmarks that qualify (a fifth of them with the ground-plane predicate), then their measurements in this
+            // keyframe - both in id order: the position in measurements_ moves forward with a short walk or a fresh search
+            auto im = kf.measurements_.cbegin();
+            bool first = true;
+            for (const auto& lm_it : qualifies[cfg]) {
+                const auto& lm = *lm_it;
+                if (first) {
+                    im = kf.measurements_.lower_bound(lm.first);
+                    first = false;
+                } else {
+                    int steps = 0;
+                    while (im != kf.measurements_.cend() && im->first < lm.first) {
+                        ++im;
+                        if (++steps > 16) {
+                            im = kf.measurements_.lower_bound(lm.first);
+                            break;
+                        }
+                    }
+                }
+                if (im == kf.measurements_.cend()) break;
+                if (im->first != lm.first) continue;
+                const Vector3d local = T * Vector3d(lm.second->pos.data());
                 double worst = -std::numeric_limits<double>::max();  // largest key over the cameras that see it
-                for (const auto& cam_meas : m.second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
-                keyed.push_back({m.first, worst});
+                for (const auto& cam_meas : im->second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
+                keyed.push_back({lm.first, worst});
             }
             std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) {
                 return a.second < b.second || (a.second == b.second && a.first < b.first);

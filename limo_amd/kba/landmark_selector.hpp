@@ -135,20 +135,62 @@ public:
         for (const auto& scheme : selection_schemes_)
             for (const auto& el : restrict(pool, run(scheme, pool, kfs))) must[el.first] = el.second;
         const auto t2 = clk::now();
-        LandmarkMap thin = pool;
-        for (const auto& scheme : sparsification_schemes_) thin = restrict(pool, run(scheme, thin, kfs));
+        // thin = pool passed through every sparsification scheme in turn (the first one reads pool itself: no copy of the map)
+        LandmarkMap thin_store;
+        const LandmarkMap* thin = &pool;
+        for (const auto& scheme : sparsification_schemes_) {
+            LandmarkMap next = restrict(pool, run(scheme, *thin, kfs));
+            thin_store.swap(next);
+            thin = &thin_store;
+        }
         const auto t3 = clk::now();
-        for (const auto& el : must) thin[el.first] = el.second;
+        // selection = ids of thin and of the must-have landmarks (both sorted by id: merged)
         std::set<LandmarkId> selection;
-        for (const auto& el : thin) selection.insert(selection.end(), el.first);
+        {
+            auto ia = thin->cbegin();
+            auto ib = must.cbegin();
+            while (ia != thin->cend() || ib != must.cend()) {
+                if (ib == must.cend() || (ia != thin->cend() && ia->first < ib->first)) {
+                    selection.insert(selection.end(), ia->first);
+                    ++ia;
+                } else if (ia == thin->cend() || ib->first < ia->first) {
+                    selection.insert(selection.end(), ib->first);
+                    ++ib;
+                } else {
+                    selection.insert(selection.end(), ia->first);
+                    ++ia;
+                    ++ib;
+                }
+            }
+        }
         const auto t4 = clk::now();
         if (!kfs.empty()) {
             TimestampNSec newest = 0;
             for (const auto& kf : kfs) newest = std::max(newest, kf.second->timestamp_);
-            auto is = selection.cbegin();  // (landmarks and selection are both sorted by id: one merge pass)
+            auto is = selection.cbegin();  // (landmarks and selection are both sorted by id: one merge pass ...
+            auto iu = unselected_lms_.begin();
+            auto it = last_time_seen_.begin();
+            bool first = true;
             for (const auto& lm : landmarks) {
                 while (is != selection.cend() && *is < lm.first) ++is;
-                if (is == selection.cend() || *is != lm.first) markUnselected(lm.first, newest);
+                if (is != selection.cend() && *is == lm.first) continue;
+                // ... and the two bookkeeping maps are entered at / next to the previous position: markUnselected(lm.first,
+                // newest) without a descent from the root per landmark)
+                const LandmarkId id = lm.first;
+                if (first) {
+                    iu = unselected_lms_.lower_bound(id);
+                    it = last_time_seen_.lower_bound(id);
+                    first = false;
+                } else {
+                    iu = advance_to(unselected_lms_, iu, id);
+                    it = advance_to(last_time_seen_, it, id);
+                }
+                if (iu == unselected_lms_.end() || iu->first != id) iu = unselected_lms_.emplace_hint(iu, id, 0u);
+                iu->second += 1;
+                if (it == last_time_seen_.end() || it->first != id) it = last_time_seen_.emplace_hint(it, id, newest);
+                it->second = newest;
+                if (!marks_.empty() && newest < marks_.back().first) marks_in_time_order_ = false;
+                marks_.push_back({newest, id});
             }
             const TimestampNSec ten_s = convert(TimestampSec(10.));
             clean(newest > ten_s ? newest - ten_s : 0);
@@ -215,6 +257,16 @@ public:
     std::set<LandmarkId> outlier_ids_;
 
 private:
+    // first entry of m with key >= id, reached from `from` (an entry with a smaller or equal key) by a short walk if it is near
+    template <class M>
+    static typename M::iterator advance_to(M& m, typename M::iterator from, LandmarkId id) {
+        int steps = 0;
+        while (from != m.end() && from->first < id) {
+            ++from;
+            if (++steps > 32) return m.lower_bound(id);
+        }
+        return from;
+    }
     template <typename S>
     std::set<LandmarkId> run(const std::shared_ptr<const S>& scheme, const LandmarkMap& lms, const KeyframeMap& kfs) {
         auto cat = std::dynamic_pointer_cast<const LandmarkCategorizatonInterface>(scheme);
