@@ -128,13 +128,14 @@ int main(int argc, char** argv) {
         }
         live = now;
         const auto t1 = clk::now();
-        driver.process(ts, cloud.data(), cloud.size() / 4);
+        const size_t n_tracks = ts.tracks.size();
+        driver.process(std::move(ts), cloud.data(), cloud.size() / 4);  // (the tracker's message is handed over: the driver fills in depths)
         const auto t2 = clk::now();
         sec_synth += std::chrono::duration<double>(t1 - t0).count();
         sec_pipeline += std::chrono::duration<double>(t2 - t1).count();
         if (!quiet && (t % 100 == 0 || t == n_frames - 1)) {
             const Vector3d e = driver.poses().back().inverse().translation() - world.origin_veh[t].translation();
-            std::printf("frame %d: %zu tracks, %zu points, position error %.3f m, %d keyframes, %d solves\n", t, ts.tracks.size(), cloud.size() / 4, e.norm(),
+            std::printf("frame %d: %zu tracks, %zu points, position error %.3f m, %d keyframes, %d solves\n", t, n_tracks, cloud.size() / 4, e.norm(),
                         driver.stats().keyframes, driver.stats().solves);
             std::fflush(stdout);
         }
