@@ -354,6 +354,300 @@ static void test_landmark_selector_voxel() {  // LandmarkSelector.voxel, :1278-1
     CHECK(selector.getLandmarkCategories().size() == 5);
 }
 
+// ---- the schemes as merge passes over sorted ranges (limo_amd/kba/landmark_selector.hpp, landmark_selection_voxel.hpp) against
+// their PLAIN statements - one lookup per landmark, the accessors of Keyframe, a map of voxel cells - on random scenes: the
+// same sets, categories and bookkeeping, id for id.  (The plain statements are what the files held before their inner
+// loops were rewritten for speed; they are the specification of the rewrite.)
+namespace plain {
+using LandmarkMap = LandmarkSchemeBase::LandmarkMap;
+using KeyframeMap = LandmarkSchemeBase::KeyframeMap;
+
+static std::set<LandmarkId> cheirality(const LandmarkMap& landmarks, const KeyframeMap& keyframes) {
+    std::set<LandmarkId> out;
+    for (const auto& lm : landmarks) {
+        bool ok = true;
+        for (const auto& id_kf : keyframes) {
+            if (!id_kf.second->is_active_) continue;
+            for (const auto& cam_lm : id_kf.second->getProjectedLandmarkPosition(lm))
+                if (cam_lm.second.z() < 0.) ok = false;
+        }
+        if (ok) out.insert(lm.first);
+    }
+    return out;
+}
+
+static std::set<LandmarkId> add_depth(const LandmarkSelectionSchemeAddDepth::Parameters& params, const LandmarkMap& landmarks, const KeyframeMap& keyframes) {
+    std::set<LandmarkId> out;
+    std::vector<Keyframe::ConstPtr> kfs;
+    for (const auto& kf : keyframes)
+        if (kf.second->is_active_) kfs.push_back(kf.second);
+    std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
+    for (const auto& el : params.params_per_keyframe) {
+        const int ind = std::get<0>(el);
+        if (ind < 0 || ind > (int)kfs.size() - 1) continue;
+        const Keyframe& kf = *kfs[ind];
+        std::vector<std::pair<LandmarkId, double>> keyed;
+        for (const auto& m : kf.measurements_) {
+            auto it = landmarks.find(m.first);
+            if (it == landmarks.cend() || !std::get<2>(el)(it->second)) continue;
+            const Vector3d local = kf.getEigenPose() * Vector3d(it->second->pos.data());
+            double worst = -std::numeric_limits<double>::max();
+            for (const auto& cam_meas : m.second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
+            keyed.push_back({m.first, worst});
+        }
+        std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.second < b.second || (a.second == b.second && a.first < b.first); });
+        const int n = std::min(std::get<1>(el), (int)keyed.size());
+        for (int i = 0; i < n; ++i) out.insert(keyed[i].first);
+    }
+    return out;
+}
+
+static std::map<LandmarkId, double> flow(const std::vector<LandmarkId>& ids, const KeyframeMap& keyframes, bool use_mean) {
+    std::vector<Keyframe::ConstPtr> kfs;
+    for (const auto& k : keyframes) kfs.push_back(k.second);
+    std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
+    std::map<LandmarkId, double> out;
+    for (const auto& id : ids) {
+        std::map<CameraId, Measurement> last;
+        std::map<CameraId, double> sum;
+        std::map<CameraId, int> cnt;
+        for (const auto& kf : kfs)
+            for (const auto& cm : kf->getMeasurements(id)) {
+                auto it = last.find(cm.first);
+                if (it != last.end()) {
+                    const double du = double(it->second.u) - double(cm.second.u), dv = double(it->second.v) - double(cm.second.v);
+                    sum[cm.first] += std::sqrt(du * du + dv * dv);
+                    cnt[cm.first] += 1;
+                }
+                last[cm.first] = cm.second;
+            }
+        if (sum.empty()) continue;
+        double best = -1.;
+        for (const auto& s : sum) best = std::max(best, use_mean ? s.second / cnt.at(s.first) : s.second);
+        out[id] = best;
+    }
+    return out;
+}
+
+using Category = LandmarkCategorizatonInterface::Category;
+static std::map<LandmarkId, Category> voxel(const LandmarkSparsificationSchemeVoxel::Parameters& params, const LandmarkMap& lms, const KeyframeMap& keyframes) {
+    std::map<LandmarkId, Category> out;
+    if (keyframes.empty()) return out;
+    const auto newest = std::max_element(keyframes.cbegin(), keyframes.cend(), [](const auto& a, const auto& b) { return a.second->timestamp_ < b.second->timestamp_; });
+    const EigenPose cur = newest->second->getEigenPose();
+    std::vector<Vector3d> path;
+    for (const auto& kf : keyframes) path.push_back(cur * kf.second->getEigenPose().inverse().translation());
+    struct P {
+        LandmarkId id;
+        Vector3d p;
+        double dist;
+    };
+    std::vector<P> pipe;
+    std::vector<LandmarkId> ids_far;
+    for (const auto& id_lm : lms) {
+        const Vector3d p = cur * Vector3d(id_lm.second->pos.data());
+        if (!(p[2] >= -20. && p[2] <= 100.)) continue;
+        const double d = landmark_helpers::distanceToPath(p, path);
+        if (d < params.roi_far_xyz[0])
+            pipe.push_back({id_lm.first, p, d});
+        else
+            ids_far.push_back(id_lm.first);
+    }
+    struct Cell {
+        double sx = 0, sy = 0, sz = 0;
+        std::vector<size_t> members;
+    };
+    std::map<std::array<long, 3>, Cell> grid;
+    for (size_t i = 0; i < pipe.size(); ++i) {
+        const std::array<long, 3> key{{(long)std::floor(pipe[i].p[0] / params.voxel_size_xyz[0]), (long)std::floor(pipe[i].p[1] / params.voxel_size_xyz[1]),
+                                       (long)std::floor(pipe[i].p[2] / params.voxel_size_xyz[2])}};
+        Cell& c = grid[key];
+        c.sx += pipe[i].p[0];
+        c.sy += pipe[i].p[1];
+        c.sz += pipe[i].p[2];
+        c.members.push_back(i);
+    }
+    std::vector<LandmarkId> ids_near, ids_middle;
+    for (const auto& kc : grid) {
+        const Cell& c = kc.second;
+        const double n = (double)c.members.size();
+        const Vector3d centroid(c.sx / n, c.sy / n, c.sz / n);
+        size_t best = c.members[0];
+        double bd = std::numeric_limits<double>::max();
+        for (size_t i : c.members) {
+            const double d = (pipe[i].p - centroid).norm();
+            const bool tie = std::fabs(d - bd) <= 1e-9 * (d + bd);
+            if ((!tie && d < bd) || (tie && pipe[i].id < pipe[best].id)) {
+                bd = d;
+                best = i;
+            }
+        }
+        (pipe[best].dist < params.roi_middle_xyz[0] ? ids_near : ids_middle).push_back(pipe[best].id);
+    }
+    const auto fl = flow(ids_near, keyframes, false);
+    {   // near: largest flow first, ties by id
+        std::vector<LandmarkId> ids;
+        for (const auto& id : ids_near)
+            if (fl.count(id)) ids.push_back(id);
+        std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) { return fl.at(a) > fl.at(b) || (fl.at(a) == fl.at(b) && a < b); });
+        ids.resize(std::min<size_t>(params.max_num_landmarks_near, ids.size()));
+        for (const auto& id : ids) out[id] = Category::NearField;
+    }
+    for (const auto& id : landmark_helpers::chooseMiddleLmIds(params.max_num_landmarks_middle, ids_middle, newest->second->timestamp_)) out[id] = Category::MiddleField;
+    {   // far: longest tracks first, ties by id
+        std::map<LandmarkId, unsigned> count;
+        for (const auto& id : ids_far) {
+            count[id] = 0;
+            for (const auto& kf : keyframes)
+                if (kf.second->hasMeasurement(id)) count[id] += 1;
+        }
+        std::vector<LandmarkId> ids(ids_far);
+        std::sort(ids.begin(), ids.end(), [&](LandmarkId a, LandmarkId b) { return count.at(a) > count.at(b) || (count.at(a) == count.at(b) && a < b); });
+        ids.resize(std::min<size_t>(params.max_num_landmarks_far, ids.size()));
+        for (const auto& id : ids) out[id] = Category::FarField;
+    }
+    return out;
+}
+}  // namespace plain
+
+static void test_selector_schemes_equal_their_plain_statements() {
+    std::mt19937_64 rng(20260924);
+    std::uniform_real_distribution<double> U(0., 1.);
+    auto cam = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
+    for (int scene = 0; scene < 6; ++scene) {
+        const int n_kf = 3 + scene % 4, n_lm = 200 + 150 * scene;
+        // keyframes along a gently turning path, 1.1 m apart; landmarks in a corridor around it, some behind the first cameras
+        std::map<KeyframeId, Keyframe::ConstPtr> kfs;
+        std::vector<EigenPose> poses;
+        for (int k = 0; k < n_kf; ++k) {
+            EigenPose p = EigenPose::Identity();
+            p.translate(Vector3d(0.05 * k * k, 0.02 * k, 1.1 * k));
+            p.rotate(0.03 * k, Vector3d(0., 1., 0.));
+            poses.push_back(p.inverse());  // keyframe <- origin
+        }
+        std::map<LandmarkId, Landmark::ConstPtr> lm_map;
+        std::vector<Vector3d> pts;
+        for (int i = 0; i < n_lm; ++i) {
+            const Vector3d x(40. * (U(rng) - 0.5), 6. * (U(rng) - 0.5), -3. + 70. * U(rng) * U(rng));
+            auto lm = std::make_shared<Landmark>(x, U(rng) < 0.5);
+            lm->is_ground_plane = U(rng) < 0.25;
+            lm_map[(LandmarkId)(1000 + 3 * i)] = lm;
+            pts.push_back(x);
+        }
+        for (int k = 0; k < n_kf; ++k) {
+            Tracklets ts;
+            ts.stamps.push_back((TimestampNSec)(k + 1) * 100000000ull);
+            int i = 0;
+            for (const auto& el : lm_map) {
+                const Vector3d pc = poses[k] * pts[i++];
+                if (U(rng) < 0.3) continue;  // not tracked in this keyframe
+                matches_msg_types::Tracklet tr;
+                tr.id = el.first;
+                const double z = std::fabs(pc[2]) < 0.05 ? 0.05 : pc[2];
+                tr.feature_points.push_back(FeaturePoint((float)(300 + 600 * pc[0] / z), (float)(200 + 600 * pc[1] / z), U(rng) < 0.5 ? (float)z : -1.f));
+                ts.tracks.push_back(tr);
+            }
+            auto kf = std::make_shared<Keyframe>(ts.stamps[0], ts, cam, poses[k]);
+            kf->is_active_ = !(scene == 5 && k == 0);  // one scene with an inactive keyframe
+            kfs[(KeyframeId)ts.stamps[0]] = kf;
+        }
+        // 1. cheirality
+        CHECK(LandmarkRejectionSchemeCheirality().getSelection(lm_map, kfs) == plain::cheirality(lm_map, kfs));
+        CHECK(plain::cheirality(lm_map, kfs).size() < lm_map.size());  // (the scene has landmarks behind cameras)
+        // 2. add-depth: 20 nearest landmarks with depth in the oldest keyframe, 15 ground landmarks per keyframe
+        LandmarkSelectionSchemeAddDepth::Parameters ap;
+        ap.params_per_keyframe.push_back(std::make_tuple(0, 20, [](const Landmark::ConstPtr& lm) { return lm->has_measured_depth; },
+                                                         [](const Measurement& m, const Vector3d&) { return m.d; }));
+        for (int i = 0; i < 6; ++i)
+            ap.params_per_keyframe.push_back(std::make_tuple(i, 15, [](const Landmark::ConstPtr& lm) { return lm->is_ground_plane; },
+                                                             [](const Measurement&, const Vector3d& local) { return (float)local.norm(); }));
+        CHECK(LandmarkSelectionSchemeAddDepth(ap).getSelection(lm_map, kfs) == plain::add_depth(ap, lm_map, kfs));
+        CHECK(!plain::add_depth(ap, lm_map, kfs).empty());
+        // 3. flow and voxel categories
+        std::vector<LandmarkId> all_ids;
+        for (const auto& el : lm_map) all_ids.push_back(el.first);
+        std::shuffle(all_ids.begin(), all_ids.end(), rng);
+        for (bool mean : {false, true}) CHECK(landmark_helpers::calcFlow(all_ids, kfs, mean) == plain::flow(all_ids, kfs, mean));
+        LandmarkSparsificationSchemeVoxel::Parameters vp;
+        vp.voxel_size_xyz = {{1.5, 1.5, 1.0}};
+        vp.roi_far_xyz = {{12., 12., 12.}};
+        vp.roi_middle_xyz = {{5., 5., 5.}};
+        vp.max_num_landmarks_near = 40;
+        vp.max_num_landmarks_middle = 30;
+        vp.max_num_landmarks_far = 25;
+        const auto cat = LandmarkSparsificationSchemeVoxel(vp).getCategorizedSelection(lm_map, kfs);
+        CHECK(cat == plain::voxel(vp, lm_map, kfs));
+        int n_cat[3] = {0, 0, 0};
+        for (const auto& el : cat) n_cat[(int)el.second] += 1;
+        CHECK(n_cat[0] > 0 && n_cat[1] > 0 && n_cat[2] > 0);
+        // 4. the selector as a whole, called repeatedly with growing stamps and changing outliers: selection and the
+        //    bookkeeping of unselected landmarks against the plain pipeline (lookup per landmark, full scan in clean())
+        LandmarkSelector selector;
+        selector.addScheme(LandmarkRejectionSchemeCheirality::createConst());
+        selector.addScheme(LandmarkSparsificationSchemeVoxel::createConst(vp));
+        selector.addScheme(LandmarkSelectionSchemeAddDepth::createConst(ap));
+        std::map<LandmarkId, unsigned int> un_plain;
+        std::map<LandmarkId, TimestampNSec> seen_plain;
+        for (int call = 0; call < 8; ++call) {
+            std::set<LandmarkId> outliers;
+            for (const auto& el : lm_map)
+                if (U(rng) < 0.05) outliers.insert(el.first);
+            selector.clearOutliers();
+            selector.setOutlier(outliers);
+            // a moving subset of the landmarks is "active" in this call; the newest keyframe's stamp grows by 3 s per call
+            std::map<LandmarkId, Landmark::ConstPtr> act;
+            for (const auto& el : lm_map)
+                if (U(rng) < 0.8) act.insert(act.end(), el);
+            std::map<KeyframeId, Keyframe::ConstPtr> kfs_now;
+            for (const auto& el : kfs) {
+                auto k2 = std::make_shared<Keyframe>(*el.second);
+                k2->timestamp_ = el.second->timestamp_ + (TimestampNSec)call * 3000000000ull;
+                kfs_now[(KeyframeId)k2->timestamp_] = k2;
+            }
+            const auto sel = selector.select(act, kfs_now);
+            // plain pipeline
+            std::map<LandmarkId, Landmark::ConstPtr> pool = act;
+            for (const auto& id : outliers) pool.erase(id);
+            auto restrict_to = [](const plain::LandmarkMap& all, const std::set<LandmarkId>& ids) {
+                plain::LandmarkMap out;
+                for (const auto& id : ids) {
+                    auto it = all.find(id);
+                    if (it != all.end()) out[id] = it->second;
+                }
+                return out;
+            };
+            pool = restrict_to(act, plain::cheirality(pool, kfs_now));
+            const auto must = restrict_to(pool, plain::add_depth(ap, pool, kfs_now));
+            std::set<LandmarkId> thin_ids;
+            for (const auto& el : plain::voxel(vp, pool, kfs_now)) thin_ids.insert(el.first);
+            std::set<LandmarkId> expect;
+            for (const auto& el : restrict_to(pool, thin_ids)) expect.insert(el.first);
+            for (const auto& el : must) expect.insert(el.first);
+            CHECK(sel == expect);
+            CHECK(selector.getLastSelection() == expect);
+            TimestampNSec newest = 0;
+            for (const auto& kf : kfs_now) newest = std::max(newest, kf.second->timestamp_);
+            for (const auto& lm : act)
+                if (!expect.count(lm.first)) {
+                    un_plain[lm.first] += 1;
+                    seen_plain[lm.first] = newest;
+                }
+            const TimestampNSec ten_s = convert(TimestampSec(10.));
+            const TimestampNSec oldest = newest > ten_s ? newest - ten_s : 0;
+            for (auto it = seen_plain.begin(); it != seen_plain.end();) {
+                if (it->second < oldest) {
+                    un_plain.erase(it->first);
+                    it = seen_plain.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            CHECK(selector.getUnselectedLandmarks() == un_plain);
+        }
+        CHECK(!un_plain.empty());
+    }
+}
+
 static void test_exceptions() {
     BundleAdjusterKeyframes b;
     bool thrown = false;
@@ -434,6 +728,7 @@ int main(int argc, char** argv) {
                  {"KeyframeSelector.process", test_keyframe_selector_process},
                  {"LandmarkSelector.base", test_landmark_selector_base},
                  {"LandmarkSelector.voxel", test_landmark_selector_voxel},
+                 {"LandmarkSelector.schemes_equal_plain_statements", test_selector_schemes_equal_their_plain_statements},
                  {"KeyFrameBundleAdjustment.solve", test_solve},
                  {"KeyFrameBundleAdjustment.solve_depth", test_solve_depth},
                  {"BundleAdjusterKeyframes.adjustMotionOnly", test_adjust_motion_only}};
