@@ -231,8 +231,11 @@ void BundleAdjusterKeyframes::push(const std::vector<Keyframe>& kfs) {
 void BundleAdjusterKeyframes::push(const Keyframe& kf) { push(Keyframe(kf)); }
 
 void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
-    const Keyframe& kf = *(keyframes_[kf_in.timestamp_] = std::make_shared<Keyframe>(std::move(kf_in)));
-    active_keyframe_ids_.insert(kf.timestamp_);
+    const TimestampNSec stamp = kf_in.timestamp_;
+    const auto stored = std::make_shared<Keyframe>(std::move(kf_in));
+    keyframes_[stamp] = stored;
+    const Keyframe& kf = *stored;
+    active_keyframe_ids_.insert(stamp);
     // Every landmark this keyframe introduces is initialised in ONE device call (the reference does it one by one,
     // :289-330): depth back-projection where the keyframe measures a depth, N-view triangulation otherwise.
     std::vector<LandmarkId> ids;
