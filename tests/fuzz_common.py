@@ -54,10 +54,19 @@ def rel_cost_err(ra, rb):
 def ulp_spread(w, solve_o, n=4):
     """Largest relative change of the oracle's own final cost (and pose translation) when one coordinate of the input
     is moved by 1 ulp: n re-runs, a different coordinate each."""
+    s = input_sensitivity(w, solve_o, n)
+    return s["cost"], s["pose"]
+
+
+def input_sensitivity(w, solve_o, n=4):
+    """The same re-runs, with everything they tell: {"cost", "pose"}: largest relative change of the oracle's own final
+    cost / keyframe translations; "terminations": the set of termination types seen; "iterations": (min, max) LM
+    iterations."""
     o = default_options()
     base = w.copy()
     r0 = solve_o(base, o)
     spread_c = spread_p = 0.0
+    terms, iters = {r0["termination"]}, [r0["iterations_total"]]
     for k in range(n):
         p = w.copy()
         if k % 2 == 0 and p.n_lm:
@@ -69,7 +78,9 @@ def ulp_spread(w, solve_o, n=4):
         r = solve_o(p, o)
         spread_c = max(spread_c, rel_cost_err(r, r0))
         spread_p = max(spread_p, rel_pose_err(p.kf_pose, base.kf_pose))
-    return spread_c, spread_p
+        terms.add(r["termination"])
+        iters.append(r["iterations_total"])
+    return {"cost": spread_c, "pose": spread_p, "terminations": terms, "iterations": (min(iters), max(iters))}
 
 
 def well_posed(w, min_obs=8):
@@ -95,7 +106,7 @@ def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, s
         if not np.array_equal(end_x.kf_pose[0], w.kf_pose[0]):
             return False, "Pose-fixed keyframe moved", False
         return True, "ill-posed window (weak checks)", False
-    for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks", "termination"):
+    for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks"):
         if rep_x[k] != rep_o[k]:
             return False, "%s: %r != %r" % (k, rep_x[k], rep_o[k]), False
     if not np.array_equal(np.sort(trimmed_x), np.sort(trimmed_o)):
@@ -103,11 +114,23 @@ def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, s
     if not np.array_equal(end_x.kf_pose[0], w.kf_pose[0]):
         return False, "Pose-fixed keyframe moved", False
     ep, ec = rel_pose_err(end_x.kf_pose, end_o.kf_pose), rel_cost_err(rep_x, rep_o)
-    if ep > TOL:
-        return False, "pose translation differs by %.2e" % ep, False
-    if ec <= TOL:
+    same_term = rep_x["termination"] == rep_o["termination"]
+    if same_term and ep <= TOL and ec <= TOL:
         return True, "cost %.2e pose %.2e" % (ec, ep), False
-    sc, sp = ulp_spread(w, solve_o)
-    if sc > TOL and ec <= 3.0 * sc and sp <= TOL:
-        return True, "cost %.2e inside the oracle's own 1-ulp spread %.2e (poses %.2e, spread %.2e)" % (ec, sc, ep, sp), True
-    return False, "final cost differs by %.2e; the oracle's own 1-ulp spread is %.2e" % (ec, sc), False
+    # Not within 1e-4: is the RESULT determined to 1e-4 by the input at all?  The oracle itself is re-run with one input
+    # coordinate moved by 1 ulp; where its own cost / poses / termination move by more than the bar, the implementation under
+    # test has to stay within 3x the oracle's own spread (and may end with another termination type only if the oracle's own
+    # varies).  Two kinds of window do this: gross outliers kept by the quantile (flat valleys of the robust
+    # cost: the cost moves, the poses do not) and weakly constrained geometry - 11-12 keyframes on 60 landmarks, no depth,
+    # no stereo, no ground plane - where the poses themselves move by 1e-2 (seed 2026: windows 11, 225).
+    s = input_sensitivity(w, solve_o)
+    ill = s["cost"] > TOL or s["pose"] > TOL or len(s["terminations"]) > 1
+    if (ill and ep <= max(TOL, 3.0 * s["pose"]) and ec <= max(TOL, 3.0 * s["cost"])
+            and (same_term or len(s["terminations"]) > 1 or rep_x["termination"] in s["terminations"])):
+        return True, ("cost %.2e / pose %.2e inside 3x the oracle's own 1-ulp spread (cost %.2e, pose %.2e, terminations %s, iterations %d..%d)"
+                      % (ec, ep, s["cost"], s["pose"], sorted(s["terminations"]), s["iterations"][0], s["iterations"][1])), True
+    if not same_term:
+        return False, "termination: %r != %r (the oracle's own under 1-ulp changes: %s)" % (rep_x["termination"], rep_o["termination"], sorted(s["terminations"])), False
+    if ep > TOL:
+        return False, "pose translation differs by %.2e; the oracle's own 1-ulp spread is %.2e" % (ep, s["pose"]), False
+    return False, "final cost differs by %.2e; the oracle's own 1-ulp spread is %.2e" % (ec, s["cost"]), False

@@ -2,7 +2,7 @@
 
 CPU tier: the emulated pipeline (same statements as the gfx950 kernels) on a slice of the sweep that contains the known
 plateau window (seed 77, window 21).  GPU tier: liblimo_hip.so through the C-ABI on the full sweeps - seed 123 x 290
-windows and seed 77 x 60 windows (LIMO_FUZZ_SCALE=0.1 runs a tenth of them for a quick check) - single solves against
+windows, seed 77 x 60 and seed 2026 x 240 windows (LIMO_FUZZ_SCALE=0.1 runs a tenth of them for a quick check) - single solves against
 the oracle, then one mixed batch that must reproduce the single solves bit for bit.
 The parity rule is fuzz_common.check_parity.
 """
@@ -57,8 +57,39 @@ def test_final_cost_of_outlier_windows_is_not_determined_to_1e4(oracle):
         assert sc > fc.TOL and sp <= fc.TOL, (seed, idx, sc, sp)
 
 
+# Windows of a third sweep (scripts/gpu_fuzz.py 400 2026) whose RESULT is not determined to 1e-4 by their input: the oracle's own
+# poses move by 1e-2 (11, 225: twelve keyframes on 60 landmarks, mono, no depth, no ground plane) or its cost by 1e-2 (89, 96:
+# 15 % gross outliers) when one input coordinate moves by 1 ulp.
+WEAK_2026 = {
+    11: dict(n_kf=12, n_lm=60, depth_prob=0.02, ground_frac=0.05, outlier_frac=0.15, stereo_baseline=0.0, with_ground_plane=False),
+    89: dict(n_kf=11, n_lm=3000, depth_prob=0.2, ground_frac=0.05, outlier_frac=0.15, stereo_baseline=0.0, with_ground_plane=True),
+    96: dict(n_kf=11, n_lm=1500, depth_prob=0.9, ground_frac=0.05, outlier_frac=0.15, stereo_baseline=0.54, with_ground_plane=True),
+    225: dict(n_kf=12, n_lm=60, depth_prob=0.0, ground_frac=0.05, outlier_frac=0.05, stereo_baseline=0.0, with_ground_plane=False),
+}
+
+
+@pytest.mark.parametrize("idx", sorted(WEAK_2026))
+def test_weakly_determined_windows_stay_inside_the_oracles_own_spread(oracle, emu, idx):
+    """The parity rule on the windows a 400-window sweep with a fresh seed flagged: the strict bar cannot hold (the oracle
+    does not reproduce ITSELF to 1e-4 on them), the emulated pipeline has to stay within 3x the oracle's own 1-ulp spread."""
+    from limo_amd import synth
+
+    w = synth.make_window(10000 + idx, **WEAK_2026[idx])
+    o = default_options()
+    so, se = _oracle_solver(oracle, 8), _emu_solver(emu)
+    we, wo = w.copy(), w.copy()
+    re_ = se(we, o)
+    te = emu.last_trimmed(0)
+    ro = so(wo, o)
+    to = oracle.last_trimmed()
+    s = fc.input_sensitivity(w, so)
+    assert s["cost"] > fc.TOL or s["pose"] > fc.TOL or len(s["terminations"]) > 1, s  # (not determined by its input)
+    ok, detail, by_spread = fc.check_parity(w, re_, we, te, se, ro, wo, to, so)
+    assert ok, "window %d: %s" % (idx, detail)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n", [(123, 290), (77, 60)])
+@pytest.mark.parametrize("seed,n", [(123, 290), (77, 60), (2026, 240)])
 def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
     from limo_amd import ba
 
@@ -89,7 +120,8 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
             worst_c = max(worst_c, fc.rel_cost_err(rg, ro))
         worst_p = max(worst_p, fc.rel_pose_err(wg.kf_pose, wo.kf_pose))
         singles.append(wg)
-    assert n_plateau <= max(1, n // 50)  # the plateau case is rare (1 in 290 / 1 in 60 at full size)
+    # windows whose result is not determined to 1e-4 by their input are rare: 1 in 290 / 1 in 60 / 4 in 240 at full size
+    assert n_plateau <= max(1, n // 40)
     # windows that only get the weak checks (a keyframe with < 8 observations: 9 of 290 / 1 of 60 at full size) stay few:
     # the strict rule (sets, termination, pose and cost to 1e-4) covers >= 95 % of the sweep
     assert n_ill <= max(1, n // 20), n_ill
