@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
     uint64_t seed = 7;
     std::string poses_path, gt_path, dump_dir, replay_dir;
-    bool use_depth = true, quiet = false;
+    bool use_depth = true, quiet = false, five_point_prior = false;
     double min_flow = -1., time_between_keyframes = -1.;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
@@ -47,8 +47,9 @@ int main(int argc, char** argv) {
         else if (arg("--velodyne")) replay_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!std::strcmp(argv[i], "--five-point-prior")) five_point_prior = true;  // the node's prior without tf (mono_lidar.cpp:157-186)
         else {
-            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--quiet]\n");
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--five-point-prior] [--quiet]\n");
             return 2;
         }
     }
@@ -61,6 +62,7 @@ int main(int argc, char** argv) {
     sp.assign_depth = use_depth;
     if (min_flow >= 0.) sp.min_median_flow = min_flow;
     if (time_between_keyframes > 0.) sp.time_between_keyframes_sec = time_between_keyframes;
+    if (five_point_prior) sp.motion_prior = StreamParams::MotionPrior::FivePoint;
     sp.solver_time_sec = -1.;  // no wall-clock cap: the drive is reproducible
     sp.image_width = (int)world.W;
     sp.image_height = (int)world.H;

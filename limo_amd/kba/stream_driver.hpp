@@ -3,8 +3,9 @@
 // with the depth assignment of the (separate) tracklets_depth node in front of it, on the MI355X library:
 //   LiDAR sweep + tracked features of the frame
 //     -> limo_depth_estimate            FeaturePoint::d of every track's newest point (include/limo_hip.h)
-//     -> motion prior                   external, or constant velocity from the last two poses (the node: tf or the
-//                                       five-point algorithm scaled by the last keyframes' speed, :119-186 - not restated)
+//     -> motion prior                   external (the node: tf), else the five-point direction scaled by the last keyframes'
+//                                       speed (:157-186, five_point.hpp; StreamParams::motion_prior) or - the default here -
+//                                       constant velocity from the last two poses
 //     -> Keyframe(prior) + adjustPoseOnly            (:192-211)
 //     -> KeyframeSelector::select                    (:218-222)
 //     -> push                                        (:231-233)
@@ -26,6 +27,7 @@
 
 #include "../../include/limo_hip.h"
 #include "bundle_adjuster_keyframes.hpp"
+#include "five_point.hpp"
 #include "keyframe_selector.hpp"
 #include "landmark_selection_voxel.hpp"
 
@@ -43,6 +45,12 @@ struct StreamParams {
     double solver_time_sec = 20.;               // wall-clock cap of a solve; <= 0: none (deterministic)
     double prior_speed = 11.;                   // m/s along the vehicle's x axis while no motion has been estimated yet (the
                                                 // node scales its five-point direction by interface_.prior_speed, :160-165)
+    // Motion prior of a frame that comes without an external one (mono_lidar.cpp:157-186): the node takes the direction from
+    // the five-point algorithm on the matches between the last keyframe and the frame and the length from the speed of the last
+    // two keyframes (five_point.hpp restates it); constant velocity from the last two frame poses is this driver's default (no
+    // RANSAC in the frame loop; adjustPoseOnly refines either against the fixed landmarks).
+    enum class MotionPrior { ConstantVelocity, FivePoint };
+    MotionPrior motion_prior = MotionPrior::ConstantVelocity;
     // landmark selection (keyframe_ba_monolid.launch:36-38; wiring of MonoLidar::reconfigureRequest, mono_lidar.cpp:396-430)
     unsigned max_number_landmarks_near_bin = 200, max_number_landmarks_middle_bin = 200, max_number_landmarks_far_bin = 100;
     double roi_middle = 15., roi_far = 40.;                            // :405-408
@@ -119,7 +127,8 @@ public:
             ba_.push(Keyframe(stamp, tracklets, camera_, EigenPose::Identity(), Keyframe::FixationStatus::Pose, ground_plane));
             is_keyframe = true;
         } else {
-            EigenPose prior = external_prior ? *external_prior : constantVelocityPrior(stamp);
+            EigenPose prior = external_prior ? *external_prior
+                              : p_.motion_prior == StreamParams::MotionPrior::FivePoint ? fivePointPrior(stamp, tracklets) : constantVelocityPrior(stamp);
             {   // a product of estimated transforms: back onto SO(3) (convert() does not normalise, definitions.cpp:14-28)
                 Pose q = convert(prior);
                 const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -202,6 +211,7 @@ public:
     BundleAdjusterKeyframes& adjuster() { return ba_; }
     const std::vector<EigenPose>& poses() const { return poses_; }
     const Stats& stats() const { return stats_; }
+    const five_point::Motion& lastFivePoint() const { return last_five_point_; }
     const std::string& lastSummary() const { return last_summary_; }
     limo_depth_params& depthParams() { return depth_params_; }
 
@@ -213,6 +223,22 @@ private:
         if (on)
             std::fprintf(stderr, "trace %s %llu cost %.17g pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g selected %zu\n", what, (unsigned long long)stamp, cost, p[0],
                          p[1], p[2], p[3], p[4], p[5], p[6], ba_.selected_landmark_ids_.size());
+    }
+    // mono_lidar.cpp:157-186: direction of the motion since the last keyframe from the five-point algorithm (straight ahead
+    // when the image flow is too small for it), length = speed of the last two keyframes x time since the last one
+    // (prior_speed while there is only one keyframe), applied to the last keyframe's pose.
+    EigenPose fivePointPrior(TimestampNSec stamp, const Tracklets& tracklets) {
+        const Keyframe& last_kf = ba_.getKeyframe();
+        EigenPose motion = five_point::motionUnscaled(camera_->focal_length, camera_->principal_point, stamp, last_kf.timestamp_, tracklets,
+                                                      camera_->getEigenPose(), p_.prior_speed, (uint64_t)stamp, &last_five_point_);
+        const auto kfs = ba_.getSortedActiveKeyframePtrs();
+        if (kfs.size() > 1) {
+            const Keyframe &k1 = *kfs[kfs.size() - 1], &k0 = *kfs[kfs.size() - 2];
+            const double speed = (k1.getEigenPose() * k0.getEigenPose().inverse()).translation().norm() / (convert(k1.timestamp_) - convert(k0.timestamp_));
+            const double n = std::sqrt(motion.t[0] * motion.t[0] + motion.t[1] * motion.t[1] + motion.t[2] * motion.t[2]);
+            for (int i = 0; i < 3; ++i) motion.t[i] = motion.t[i] / std::max(0.0001, n) * speed * (convert(stamp) - convert(k1.timestamp_));
+        }
+        return motion * (kfs.empty() ? last_kf.getEigenPose() : kfs.back()->getEigenPose());
     }
     // constant velocity from the last two poses; before there are two: straight ahead at prior_speed
     EigenPose constantVelocityPrior(TimestampNSec stamp) const {
@@ -283,6 +309,7 @@ private:
     double last_solved_sec_ = -1e30;
     std::string last_summary_;
     Stats stats_;
+    five_point::Motion last_five_point_;  // the last five-point estimate (diagnostics: inliers, samples)
 };
 
 }  // namespace keyframe_bundle_adjustment

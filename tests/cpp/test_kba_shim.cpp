@@ -17,6 +17,7 @@
 #include "../../limo_amd/kba/keyframe_selector.hpp"
 #include "../../limo_amd/kba/kitti_io.hpp"
 #include "../../limo_amd/kba/landmark_selection_voxel.hpp"
+#include "../../limo_amd/kba/five_point.hpp"
 
 using namespace keyframe_bundle_adjustment;
 
@@ -648,6 +649,149 @@ static void test_selector_schemes_equal_their_plain_statements() {
     }
 }
 
+// ---- five_point.hpp: the motion prior the node computes with OpenCV (general_helpers.hpp:103-140, 209-231)
+static double angle_between(const double* a, const double* b) {
+    const double na = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    const double c = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) / (na * nb);
+    return std::acos(std::max(-1., std::min(1., c)));
+}
+static double rotation_angle(const five_point::Mat3& Ra, const EigenPose& Tb) {  // angle of Ra Rb^T
+    double tr = 0.;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) tr += Ra[3 * i + j] * Tb.R[3 * i + j];
+    return std::acos(std::max(-1., std::min(1., 0.5 * (tr - 1.))));
+}
+
+static void test_five_point_motion() {
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1., 1.);
+    auto random_motion = [&]() {  // x_b = R x_a + t, |t| = 1: a forward-ish motion with a rotation of up to 0.2 rad
+        EigenPose T = EigenPose::Identity();
+        T.rotate(0.2 * U(rng), Vector3d(U(rng), U(rng), U(rng)));
+        const double tn[3] = {0.3 * U(rng), 0.2 * U(rng), 1.0 + 0.3 * U(rng)};
+        const double nn = std::sqrt(tn[0] * tn[0] + tn[1] * tn[1] + tn[2] * tn[2]);
+        for (int i = 0; i < 3; ++i) T.t[i] = tn[i] / nn;
+        return T;
+    };
+    // 1. the minimal solver: the true essential matrix is among the (at most ten) solutions of five exact correspondences
+    int missing = 0, too_many = 0;
+    for (int trial = 0; trial < 2000; ++trial) {
+        const EigenPose T = random_motion();
+        double a[5][2], b[5][2];
+        for (int i = 0; i < 5; ++i) {
+            const Vector3d X(4 * U(rng), 3 * U(rng), 8 + 5 * U(rng));
+            const Vector3d Y = T * X;
+            a[i][0] = X[0] / X[2];
+            a[i][1] = X[1] / X[2];
+            b[i][0] = Y[0] / Y[2];
+            b[i][1] = Y[1] / Y[2];
+        }
+        const double tx[9] = {0, -T.t[2], T.t[1], T.t[2], 0, -T.t[0], -T.t[1], T.t[0], 0};
+        five_point::Mat3 Et{};
+        double n = 0.;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                Et[3 * i + j] = tx[3 * i] * T.R[j] + tx[3 * i + 1] * T.R[3 + j] + tx[3 * i + 2] * T.R[6 + j];
+                n += Et[3 * i + j] * Et[3 * i + j];
+            }
+        for (double& e : Et) e /= std::sqrt(n);
+        const auto Es = five_point::essentialFromFive(a, b);
+        too_many += Es.size() > 10;
+        double best = 1e9;
+        for (const auto& E : Es) {
+            double dp = 0., dm = 0., worst = 0.;
+            for (int i = 0; i < 9; ++i) {
+                dp += (E[i] - Et[i]) * (E[i] - Et[i]);
+                dm += (E[i] + Et[i]) * (E[i] + Et[i]);
+            }
+            best = std::min(best, std::sqrt(std::min(dp, dm)));
+            for (int i = 0; i < 5; ++i) worst = std::max(worst, five_point::sampson2(E, a[i], b[i]));
+            CHECK(worst < 1e-16);  // every solution satisfies the five constraints
+        }
+        missing += !(best < 1e-6);
+    }
+    CHECK(missing == 0);
+    CHECK(too_many == 0);
+    // 2. RANSAC + pose: 300 correspondences, 0.3 px noise, 30 % gross outliers.  The model is the best MINIMAL-sample model (as
+    //    with cv::findEssentialMat: no refit on the inliers): rotation to 0.04-0.3 deg, translation direction to 0.5-3.3 deg here
+    for (int trial = 0; trial < 20; ++trial) {
+        const EigenPose T = random_motion();
+        std::vector<Vector2d> pa, pb;
+        std::normal_distribution<double> N(0., 0.3);
+        for (int i = 0; i < 300; ++i) {
+            const Vector3d X(12 * U(rng), 4 * U(rng), 6 + 30 * std::fabs(U(rng)));
+            const Vector3d Y = T * X;
+            Vector2d ua(718.856 * X[0] / X[2] + 607.19 + N(rng), 718.856 * X[1] / X[2] + 185.2 + N(rng));
+            Vector2d ub(718.856 * Y[0] / Y[2] + 607.19 + N(rng), 718.856 * Y[1] / Y[2] + 185.2 + N(rng));
+            if (i % 10 < 3) ub = Vector2d(620. * (1. + U(rng)), 190. * (1. + U(rng)));  // a wrong match
+            pa.push_back(ua);
+            pb.push_back(ub);
+        }
+        const five_point::Motion m = five_point::estimateMotion(pa, pb, 718.856, Vector2d(607.19, 185.2), 0.999, 2.0, 100 + trial);
+        CHECK(m.ok);
+        CHECK(m.inliers >= 190 && m.inliers <= 240);
+        CHECK(m.in_front >= m.inliers - 8);
+        if (std::getenv("FIVE_POINT_VERBOSE"))
+            std::printf("    trial %d: %d inliers, %d in front, %d samples, rotation error %.3f deg, translation direction error %.2f deg\n", trial, m.inliers, m.in_front,
+                        m.samples, rotation_angle(m.R, T) * 180. / M_PI, angle_between(m.t, T.t) * 180. / M_PI);
+        CHECK(rotation_angle(m.R, T) < 0.5 * M_PI / 180.);
+        CHECK(angle_between(m.t, T.t) < 5.0 * M_PI / 180.);
+        CHECK(std::fabs(std::sqrt(m.t[0] * m.t[0] + m.t[1] * m.t[1] + m.t[2] * m.t[2]) - 1.) < 1e-12);
+        CHECK(m.samples < 200);  // adaptive stop: ~40 samples for 70 % inliers at 0.999
+        // same seed, same answer
+        const five_point::Motion m2 = five_point::estimateMotion(pa, pb, 718.856, Vector2d(607.19, 185.2), 0.999, 2.0, 100 + trial);
+        CHECK(m2.inliers == m.inliers && m2.R == m.R);
+    }
+    CHECK(!five_point::estimateMotion({Vector2d(1, 2)}, {Vector2d(1, 2)}, 700., Vector2d(600, 180)).ok);  // fewer than five correspondences
+    // 3. getMotionUnscaled: frames, scale and fall-backs.  Vehicle frame x forward / z up, camera z forward (the KITTI static TF)
+    {
+        EigenPose T_cam_veh = EigenPose::Identity();
+        T_cam_veh.R[0] = 0; T_cam_veh.R[1] = -1; T_cam_veh.R[2] = 0;
+        T_cam_veh.R[3] = 0; T_cam_veh.R[4] = 0; T_cam_veh.R[5] = -1;
+        T_cam_veh.R[6] = 1; T_cam_veh.R[7] = 0; T_cam_veh.R[8] = 0;
+        T_cam_veh.t[0] = 0.; T_cam_veh.t[1] = 1.35; T_cam_veh.t[2] = -1.08;
+        // the vehicle drives 1 m forward and yaws by 0.02 rad between the last keyframe (stamp 1) and the frame (stamp 2)
+        EigenPose veh_t1_t0 = EigenPose::Identity();  // new vehicle <- old vehicle
+        veh_t1_t0.rotate(-0.02, Vector3d(0., 0., 1.));
+        veh_t1_t0.t[0] = -1.0;
+        const EigenPose cam_t1_t0 = T_cam_veh * veh_t1_t0 * T_cam_veh.inverse();
+        Tracklets ts;
+        ts.stamps = {200000000ull, 100000000ull};  // newest first: index 0 = the frame (0.2 s), index 1 = the last keyframe (0.1 s)
+        for (int i = 0; i < 200; ++i) {
+            const Vector3d X0(15 * U(rng), 3 * U(rng) + 1., 8 + 30 * std::fabs(U(rng)));  // in the camera at t0
+            const Vector3d X1 = cam_t1_t0 * X0;
+            matches_msg_types::Tracklet tr;
+            tr.id = i;
+            tr.label = i % 50 == 0 ? 24 : 11;  // a few tracks carry an outlier label (person): not used
+            tr.feature_points.push_back(FeaturePoint((float)(700 * X1[0] / X1[2] + 600), (float)(700 * X1[1] / X1[2] + 180)));
+            tr.feature_points.push_back(FeaturePoint((float)(700 * X0[0] / X0[2] + 600), (float)(700 * X0[1] / X0[2] + 180)));
+            ts.tracks.push_back(tr);
+        }
+        five_point::Motion info;
+        const EigenPose est = five_point::motionUnscaled(700., Vector2d(600, 180), ts.stamps[0], ts.stamps[1], ts, T_cam_veh, 13., 5, &info);
+        CHECK(info.ok && info.inliers >= 180);
+        {   // speed x dt is the length of the CAMERA's translation (the scaling happens before the change of frame, :225-229)
+            const EigenPose cam = T_cam_veh * est.inverse() * T_cam_veh.inverse();  // camera t0 <- camera t1
+            CHECK(std::fabs(cam.translation().norm() - 13. * 0.1) < 1e-9);
+        }
+        const double want[3] = {veh_t1_t0.t[0], veh_t1_t0.t[1], veh_t1_t0.t[2]}, got[3] = {est.t[0], est.t[1], est.t[2]};
+        CHECK(angle_between(want, got) < 1.0 * M_PI / 180.);  // (float pixel coordinates)
+        five_point::Mat3 Rest;
+        for (int i = 0; i < 9; ++i) Rest[i] = est.R[i];
+        CHECK(rotation_angle(Rest, veh_t1_t0) < 0.05 * M_PI / 180.);
+        // no image flow (identical points): zero translation, identity rotation (calcMotion5Point zeroes it)
+        Tracklets still = ts;
+        for (auto& tr : still.tracks) tr.feature_points[0] = tr.feature_points[1];
+        const EigenPose e0 = five_point::motionUnscaled(700., Vector2d(600, 180), ts.stamps[0], ts.stamps[1], still, T_cam_veh, 13.);
+        CHECK(e0.translation().norm() < 1e-12 && e0.isApprox(EigenPose::Identity(), 1e-12));
+        // no matches at all: straight ahead along the camera's z axis = the vehicle's x axis, new <- old: -speed x dt
+        Tracklets none;
+        none.stamps = ts.stamps;
+        const EigenPose e1 = five_point::motionUnscaled(700., Vector2d(600, 180), ts.stamps[0], ts.stamps[1], none, T_cam_veh, 13.);
+        CHECK(std::fabs(e1.t[0] + 1.3) < 1e-9 && std::fabs(e1.t[1]) < 1e-9 && std::fabs(e1.t[2]) < 1e-9);
+    }
+}
+
 static void test_exceptions() {
     BundleAdjusterKeyframes b;
     bool thrown = false;
@@ -729,6 +873,7 @@ int main(int argc, char** argv) {
                  {"LandmarkSelector.base", test_landmark_selector_base},
                  {"LandmarkSelector.voxel", test_landmark_selector_voxel},
                  {"LandmarkSelector.schemes_equal_plain_statements", test_selector_schemes_equal_their_plain_statements},
+                 {"FivePoint.motion_prior", test_five_point_motion},
                  {"KeyFrameBundleAdjustment.solve", test_solve},
                  {"KeyFrameBundleAdjustment.solve_depth", test_solve_depth},
                  {"BundleAdjusterKeyframes.adjustMotionOnly", test_adjust_motion_only}};

@@ -99,6 +99,10 @@ def test_limo_stream_with_emulated_backend(tmp_path):
     assert np.allclose(first, np.eye(4)[:3], atol=1e-12)        # the first frame is the origin
     no_depth = run_limo_stream(exe, 40, 2000, extra=["--no-depth"])
     assert no_depth["depth_fraction"] == 0.0 and no_depth["ate_rmse"] > out["ate_rmse"]  # monocular: scale drifts without LiDAR
+    # the node's own prior when it has no tf: five-point direction + the last keyframes' speed (mono_lidar.cpp:157-186,
+    # limo_amd/kba/five_point.hpp) instead of constant velocity - adjustPoseOnly refines either, the drive stays on track
+    fp = run_limo_stream(exe, 40, 2000, extra=["--five-point-prior"])
+    assert fp["frames"] == 40 and fp["solves"] >= 12 and fp["ate_rmse"] < 0.1 and fp["ate_max"] < 0.6  # (worst: frames before the first solve, prior unrefined)
 
 
 def test_limo_stream_replays_velodyne_scans(tmp_path):
