@@ -95,7 +95,9 @@ void symmetric_eigen(std::array<double, N * N> a, std::array<double, N>& w, std:
         double off = 0.;
         for (int i = 0; i < N; ++i)
             for (int j = i + 1; j < N; ++j) off += a[i * N + j] * a[i * N + j];
-        if (off < 1e-300) break;
+        double diag = 0.;
+        for (int i = 0; i < N; ++i) diag += a[i * N + i] * a[i * N + i];
+        if (off <= 1e-32 * diag || off < 1e-300) break;  // (off-diagonal mass below the rounding level of the diagonal)
         for (int p = 0; p < N; ++p)
             for (int q = p + 1; q < N; ++q) {
                 if (std::fabs(a[p * N + q]) < 1e-300) continue;
@@ -426,9 +428,12 @@ inline std::vector<Mat3> essentialFromFive(const double a[5][2], const double b[
             // u ~ v / (lambda - shift): eigenvalue estimate from the growth along v
             double vv = 0.;
             for (double x : v) vv += x * x;
-            lambda = shift + vv / uv;
+            const double lambda_new = shift + vv / uv;
+            const bool settled = it >= 1 && std::fabs(lambda_new - lambda) <= 1e-13 * (1. + std::fabs(lambda_new));
+            lambda = lambda_new;
             const double n = std::sqrt(uu);
             for (int i = 0; i < 10; ++i) v[i] = u[i] / n;
+            if (settled) break;
         }
         if (!ok || !std::isfinite(lambda)) continue;
         double res = 0.;  // |A v - lambda v| with |v| = 1
@@ -568,7 +573,7 @@ inline Motion estimateMotion(const std::vector<Vector2d>& pts_a, const std::vect
         return x ^ (x >> 31);
     };
     int need = max_samples;
-    std::vector<char> inl(n), best_inl(n, 0);
+    std::vector<char> best_inl(n, 0);
     for (int s = 0; s < need && s < max_samples; ++s) {
         size_t pick[5];
         for (int q = 0; q < 5; ++q) {
@@ -588,15 +593,15 @@ inline Motion estimateMotion(const std::vector<Vector2d>& pts_a, const std::vect
         }
         ++m.samples;
         for (const Mat3& E : essentialFromFive(sa, sb)) {
+            // inlier count; abandoned as soon as even all remaining points could not beat the best model so far
             int count = 0;
             for (size_t i = 0; i < n; ++i) {
-                inl[i] = sampson2(E, a[i].data(), b[i].data()) < thr2;
-                count += inl[i];
+                count += sampson2(E, a[i].data(), b[i].data()) < thr2;
+                if (count + (int)(n - 1 - i) <= m.inliers) break;
             }
             if (count > m.inliers) {
                 m.inliers = count;
                 m.E = E;
-                best_inl = inl;
                 m.ok = true;
                 // samples needed for `probability` of one all-inlier sample at this inlier ratio (cv::RANSACUpdateNumIters)
                 const double wr = std::min(1. - 1e-12, std::pow((double)count / (double)n, 5.));
@@ -605,7 +610,10 @@ inline Motion estimateMotion(const std::vector<Vector2d>& pts_a, const std::vect
             }
         }
     }
-    if (m.ok) poseFromEssential(m.E, a, b, best_inl, m);
+    if (m.ok) {
+        for (size_t i = 0; i < n; ++i) best_inl[i] = sampson2(m.E, a[i].data(), b[i].data()) < thr2;
+        poseFromEssential(m.E, a, b, best_inl, m);
+    }
     return m;
 }
 
