@@ -15,47 +15,41 @@ public:
 
     Keyframe() {}
 
-    // multi-camera constructor (keyframe.cpp:5-17)
+    // Rig of several cameras: `landmark_to_cameras` names, per track id, the cameras that measured it.
+    // (reference interface: keyframe.hpp:44-50 / src/keyframe.cpp:5-17)
     Keyframe(TimestampNSec timestamp, const Tracklets& tracklets, std::map<CameraId, Camera::Ptr> cameras,
              std::map<LandmarkId, CameraIds> landmark_to_cameras, EigenPose p,
-             FixationStatus fix_stat = FixationStatus::None, Plane ground_plane = Plane())
-            : timestamp_(timestamp), cameras_(cameras), fixation_status_(fix_stat), local_ground_plane_(ground_plane),
-              is_active_(true) {
+             FixationStatus fix_stat = FixationStatus::None, Plane ground_plane = Plane()) {
+        setup(timestamp, std::move(cameras), p, fix_stat, ground_plane);
         assignMeasurements(tracklets, landmark_to_cameras);
-        assignPose(p);
     }
-    // mono constructor (keyframe.cpp:19-31)
+    // One camera; it gets id 0.  (reference interface: keyframe.hpp:52-57 / src/keyframe.cpp:19-31)
     Keyframe(TimestampNSec timestamp, const Tracklets& tracklets, Camera::Ptr camera, EigenPose p,
-             FixationStatus fix_stat = FixationStatus::None, Plane ground_plane = Plane())
-            : timestamp_(timestamp), fixation_status_(fix_stat), local_ground_plane_(ground_plane), is_active_(true) {
-        CameraId cam_id = 0;
-        cameras_[cam_id] = camera;
-        assignMeasurements(tracklets, cam_id);
-        assignPose(p);
+             FixationStatus fix_stat = FixationStatus::None, Plane ground_plane = Plane()) {
+        setup(timestamp, {{CameraId(0), std::move(camera)}}, p, fix_stat, ground_plane);
+        assignMeasurements(tracklets, CameraId(0));
     }
 
-    bool operator<(const Keyframe& kf) const { return this->timestamp_ < kf.timestamp_; }
+    bool operator<(const Keyframe& kf) const { return timestamp_ < kf.timestamp_; }
 
-    // keyframe.cpp:61-75: index of this keyframe's stamp in tracklets.stamps selects the feature point of every track
+    // Every track carries one feature point per stamp of `tracklets.stamps` (index 0 = newest, src/keyframe.cpp:61-75);
+    // the column of THIS keyframe's stamp is the measurement it contributes.  A track shorter than that column was not
+    // alive yet.  (A stamp that is not listed gives column == stamps.size(), like std::distance to end() in the reference.)
     void assignMeasurements(const Tracklets& tracklets, const CameraId& cam_id) {
-        auto iter = std::find(tracklets.stamps.begin(), tracklets.stamps.end(), this->timestamp_);
-        int index = static_cast<int>(std::distance(tracklets.stamps.begin(), iter));
-        for (const auto& track : tracklets.tracks) {
-            if (index < int(track.feature_points.size())) {
-                measurements_[track.id][cam_id] = track.feature_points[index];
-            }
-        }
+        const size_t col = stampColumn(tracklets.stamps);
+        for (const Tracklet& t : tracklets.tracks)
+            if (col < t.feature_points.size()) measurements_[t.id][cam_id] = t.feature_points[col];
     }
-    // keyframe.cpp:43-59
+    // The same for a rig (src/keyframe.cpp:43-59): no per-camera copies of the tracklets - one pass, the column is found
+    // once.  An id that `landmark_lookup` does not know throws std::out_of_range, as the reference's .at() does.
     void assignMeasurements(const Tracklets& tracklets, const std::map<LandmarkId, CameraIds>& landmark_lookup) {
-        std::map<CameraId, Tracklets> out;
-        for (const auto& track : tracklets.tracks) {
-            for (const auto& cam_id : landmark_lookup.at(track.id)) {
-                out[cam_id].stamps = tracklets.stamps;
-                out[cam_id].tracks.push_back(track);
-            }
+        const size_t col = stampColumn(tracklets.stamps);
+        for (const Tracklet& t : tracklets.tracks) {
+            const CameraIds& seen_by = landmark_lookup.at(t.id);
+            if (col >= t.feature_points.size()) continue;
+            auto& per_cam = measurements_[t.id];
+            for (const CameraId& c : seen_by) per_cam[c] = t.feature_points[col];
         }
-        for (const auto& el : out) assignMeasurements(el.second, el.first);
     }
     void assignPose(const EigenPose& p) { pose_ = convert(p); }
 
@@ -63,33 +57,56 @@ public:
     const Measurement& getMeasurement(LandmarkId lm_id, CameraId cam_id) const {
         return measurements_.at(lm_id).at(cam_id);
     }
+    // measurements of a landmark by the cameras of this keyframe's rig (keyframe.hpp:84-100)
     std::map<CameraId, Measurement> getMeasurements(LandmarkId lm_id) const {
         std::map<CameraId, Measurement> out;
-        for (const auto& cam : cameras_)
-            if (hasMeasurement(lm_id, cam.first)) out[cam.first] = getMeasurement(lm_id, cam.first);
+        const auto row = measurements_.find(lm_id);
+        if (row == measurements_.cend()) return out;
+        for (const auto& cm : row->second)
+            if (cameras_.count(cm.first)) out.emplace_hint(out.end(), cm.first, cm.second);
         return out;
     }
     bool hasMeasurement(const LandmarkId& lm_id, const CameraId& cam_id) const {
-        auto it_lm = measurements_.find(lm_id);
-        return it_lm != measurements_.cend() && it_lm->second.find(cam_id) != it_lm->second.cend();
+        const auto row = measurements_.find(lm_id);
+        return row != measurements_.cend() && row->second.count(cam_id) != 0;
     }
     bool hasMeasurement(LandmarkId lm_id) const {
-        for (const auto& cam : cameras_)
-            if (hasMeasurement(lm_id, cam.first)) return true;
+        const auto row = measurements_.find(lm_id);
+        if (row == measurements_.cend()) return false;
+        for (const auto& cm : row->second)
+            if (cameras_.count(cm.first)) return true;
         return false;
     }
-    // keyframe.cpp:81-104
+    // Landmark position in the frame of every camera that measured it in this keyframe (empty when none did):
+    // camera <- vehicle <- origin (src/keyframe.cpp:81-104).
     std::map<CameraId, Vector3d> getProjectedLandmarkPosition(
         const std::pair<LandmarkId, Landmark::ConstPtr>& id_lm) const {
-        auto it = measurements_.find(id_lm.first);
-        if (it == measurements_.cend()) return std::map<CameraId, Vector3d>();
-        const Vector3d p_vehicle = this->getEigenPose() * Vector3d(id_lm.second->pos.data());
-        std::map<CameraId, Vector3d> out;
-        for (const auto& cam_meas : it->second) out[cam_meas.first] = cameras_.at(cam_meas.first)->getEigenPose() * p_vehicle;
-        return out;
+        std::map<CameraId, Vector3d> in_camera;
+        const auto row = measurements_.find(id_lm.first);
+        if (row != measurements_.cend()) {
+            const Vector3d in_vehicle = getEigenPose() * Vector3d(id_lm.second->pos.data());
+            for (const auto& cm : row->second)
+                in_camera.emplace_hint(in_camera.end(), cm.first, cameras_.at(cm.first)->getEigenPose() * in_vehicle);
+        }
+        return in_camera;
     }
     EigenPose getEigenPose() const { return convert(pose_); }
     std::shared_ptr<Pose> getPosePtr() const { return std::make_shared<Pose>(pose_); }
+
+private:
+    void setup(TimestampNSec stamp, std::map<CameraId, Camera::Ptr> rig, const EigenPose& p, FixationStatus fix, const Plane& plane) {
+        timestamp_ = stamp;
+        cameras_ = std::move(rig);
+        fixation_status_ = fix;
+        local_ground_plane_ = plane;
+        is_active_ = true;
+        assignPose(p);
+    }
+    size_t stampColumn(const std::vector<TimestampNSec>& stamps) const {
+        size_t col = 0;
+        while (col < stamps.size() && stamps[col] != timestamp_) ++col;
+        return col;
+    }
 
 public:
     TimestampNSec timestamp_{0};
