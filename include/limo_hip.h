@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define LIMO_ABI_VERSION 1
+#define LIMO_ABI_VERSION 2 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms */
 
 /* Keyframe::FixationStatus, keyframe.hpp:30 */
 enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
@@ -267,6 +267,51 @@ typedef struct limo_speed_prior {
 } limo_speed_prior;
 int limo_ba_adjust_pose_only(limo_ctx* ctx, limo_ba_window* window, const limo_speed_prior* prior,
                              const limo_ba_options* opts, limo_ba_report* report);
+
+/*
+ * The residual rows of a window that are NOT reprojection / depth blocks, linearised at the window's current parameters the
+ * way the solve linearises them (loss corrector / sqrt(weight) applied; Jacobians towards the TANGENT of every parameter block
+ * the residual block touches, constant blocks included - the solve masks those later):
+ *   LIMO_ROW_GROUND_HEIGHT  GroundPlaneHeightRegularization, cost_functors_ceres.hpp:358-385, wired by
+ *                           addGroundPlaneResiduals, bundle_adjuster_keyframes.cpp:517-562 (nearest keyframe, Huber(0.1)
+ *                           scaled by 10 (1 - dist / 25)); one row per selected ground landmark that gets a block
+ *   LIMO_ROW_SCALE          PoseRegularization, cost_functors_ceres.hpp:229-243, wiring :890-904, weight :704-716
+ *   LIMO_ROW_NORMAL_DIFF    VectorDifferenceRegularization (3 rows, sub = component), :775-784
+ *   LIMO_ROW_DIST_DIFF      GroundPlaneDistanceRegularization, :786-791
+ *   LIMO_ROW_PLANE_MOTION   GroundPlaneMotionRegularization, cost_functors_ceres.hpp:533-547, wiring :794-800
+ *   LIMO_ROW_GLOBAL_NORMAL  VectorDifferenceRegularization2 against (0,0,1) (3 rows), :809-816
+ *   LIMO_ROW_SPEED          SpeedRegularizationVector2 (3 rows; adjustPoseOnly problem only), cost_functors_ceres.hpp:300-353,
+ *                           wiring :835-853
+ * kf[0] < kf[1] are the window's keyframe indices the block touches (kf[1] = -1: one keyframe); jac_kf[i] holds the ten
+ * tangent slots of kf[i]: rotation 3 | translation 3 | plane normal 3 | plane distance 1.  fixed = 1: every parameter block
+ * of the residual block is constant (its cost is part of the fixed cost).  pose_only != 0 builds the adjustPoseOnly problem
+ * (window->n_kf == 1, landmarks constant, `prior` as in limo_ba_adjust_pose_only).  Rows come in the order: ground rows
+ * (ascending keyframe, then as packed), scale, per consecutive keyframe pair [normal diff x3, dist diff, plane motion],
+ * per keyframe global normal x3, speed x3.  *n_rows receives the number of rows of the problem; at most cap are written.
+ * The evaluation runs on the device through the same device functions the solve kernels call (gp_lane, reg_row_eval).
+ */
+enum limo_row_kind {
+    LIMO_ROW_GROUND_HEIGHT = 0,
+    LIMO_ROW_SCALE = 1,
+    LIMO_ROW_NORMAL_DIFF = 2,
+    LIMO_ROW_DIST_DIFF = 3,
+    LIMO_ROW_PLANE_MOTION = 4,
+    LIMO_ROW_GLOBAL_NORMAL = 5,
+    LIMO_ROW_SPEED = 6
+};
+typedef struct limo_ba_row {
+    int32_t kind;          /* enum limo_row_kind                                                   */
+    int32_t sub;           /* component of a multi-row block                                       */
+    int32_t kf[2];         /* window keyframe indices (ascending), kf[1] = -1 if only one          */
+    int32_t lm;            /* landmark index in the caller's window (ground rows), else -1         */
+    int32_t fixed;         /* 1 = all parameter blocks of the block are constant                   */
+    double r;              /* residual, corrector applied                                          */
+    double cost;           /* 1/2 rho(|r_block|^2) of the BLOCK, reported on its sub == 0 row      */
+    double jac_kf[2][10];  /* d r / d tangent of kf[0], kf[1]                                      */
+    double jac_lm[3];      /* d r / d landmark (ground rows)                                       */
+} limo_ba_row;
+int limo_ba_evaluate_rows(limo_ctx* ctx, const limo_ba_window* window, const limo_speed_prior* prior, int pose_only,
+                          const limo_ba_options* opts, int32_t cap, limo_ba_row* rows, int32_t* n_rows);
 
 /* --- landmark initialisation ----------------------------------------------------------------------- */
 /*

@@ -99,6 +99,35 @@ class SpeedPrior(C.Structure):  # struct limo_speed_prior
     ]
 
 
+class BaRow(C.Structure):  # struct limo_ba_row
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("sub", C.c_int32),
+        ("kf", C.c_int32 * 2),
+        ("lm", C.c_int32),
+        ("fixed", C.c_int32),
+        ("r", C.c_double),
+        ("cost", C.c_double),
+        ("jac_kf", (C.c_double * 10) * 2),
+        ("jac_lm", C.c_double * 3),
+    ]
+
+
+ROW_GROUND_HEIGHT, ROW_SCALE, ROW_NORMAL_DIFF, ROW_DIST_DIFF, ROW_PLANE_MOTION, ROW_GLOBAL_NORMAL, ROW_SPEED = range(7)
+
+
+def rows_as_dicts(rows, n):
+    """limo_ba_row[n] -> list of dicts keyed the way the tests match rows: (kind, kf0, kf1, lm, sub)."""
+    import numpy as np
+
+    out = []
+    for i in range(n):
+        r = rows[i]
+        out.append({"key": (r.kind, r.kf[0], r.kf[1], r.lm, r.sub), "fixed": r.fixed, "r": r.r, "cost": r.cost,
+                    "jac_kf": np.array([list(r.jac_kf[0]), list(r.jac_kf[1])]), "jac_lm": np.array(list(r.jac_lm))})
+    return out
+
+
 class Ray(C.Structure):  # struct limo_ray
     _fields_ = [
         ("pose_cam_origin", C.c_double * 7),
@@ -161,6 +190,8 @@ class DepthParams(C.Structure):  # struct limo_depth_params
     ]
 
 
+ABI_VERSION = 2  # LIMO_ABI_VERSION of include/limo_hip.h
+
 # every symbol include/limo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "limo_abi_version",
@@ -186,6 +217,7 @@ ABI_SYMBOLS = [
     "limo_ctx_exchange_stats",
     "limo_ba_evaluate",
     "limo_ba_evaluate_batch_time",
+    "limo_ba_evaluate_rows",
     "limo_ba_adjust_pose_only",
     "limo_landmark_init",
     "limo_trim_quantile",
@@ -220,6 +252,8 @@ def load():
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     lib.limo_abi_version.restype = C.c_int
+    if lib.limo_abi_version() != ABI_VERSION:
+        raise RuntimeError("limo_amd: %s has ABI version %d, this binding needs %d - rebuild it (__graft_entry__.build())" % (LIB_PATH, lib.limo_abi_version(), ABI_VERSION))
     lib.limo_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.limo_ctx_destroy.argtypes = [vp]
     lib.limo_ctx_destroy.restype = None
@@ -253,6 +287,7 @@ def load():
         c_double_p,
         c_uint8_p,
     ]
+    lib.limo_ba_evaluate_rows.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(SpeedPrior), C.c_int, C.POINTER(BaOptions), C.c_int32, C.POINTER(BaRow), c_int32_p]
     lib.limo_ba_adjust_pose_only.argtypes = [
         vp,
         C.POINTER(BaWindow),

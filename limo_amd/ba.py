@@ -116,6 +116,18 @@ class Context:
         return float(cost[0]), res, jp, jl, valid
 
 
+    def evaluate_rows(self, window, opts, pose_only=False, prior=None):
+        """limo_ba_evaluate_rows: the non-observation residual rows (ground plane, regularisers, speed prior) as dicts."""
+        s = window.as_struct()
+        n = C.c_int32(0)
+        cap = 64 + window.n_lm + 8 * window.n_kf
+        rows = (_ffi.BaRow * cap)()
+        rc = self.lib.limo_ba_evaluate_rows(self.ptr, C.byref(s), None if prior is None else C.byref(prior), int(pose_only), C.byref(opts), cap, rows, C.byref(n))
+        _check(rc, self.ptr, "limo_ba_evaluate_rows")
+        assert n.value <= cap
+        return _ffi.rows_as_dicts(rows, n.value)
+
+
 class Batch:
     """Many independent windows resident in HBM (limo_ba_batch_*)."""
 

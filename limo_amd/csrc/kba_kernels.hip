@@ -1817,4 +1817,19 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c
     evaluate_lane(bv, c, blockIdx.x, threadIdx.x + blockIdx.y * kBlock, apply_loss, obs_cost, obs_valid);
 }
 
+// ------------------------------------------------------------------------------------------ evaluate rows (limo_ba_evaluate_rows)
+// The rows of window `w` that are not reprojection / depth blocks, through the device functions the solve kernels call:
+// gp_lane (k_lin_lm's ground-plane row: gp_r / gp_F / gp_E planes, gp_cost) and reg_row_eval (k_cam_assemble's regulariser
+// rows).  One workgroup; only behind limo_ba_evaluate_rows.
+__global__ __launch_bounds__(kBlock) void k_eval_rows(BatchView bv, int w, RegRow* rows, int32_t* fixed) {
+    const WinDesc& wd = bv.win[w];
+    for (int g = wd.gp0 + threadIdx.x; g < wd.gp0 + wd.n_gp; g += kBlock) gp_lane(bv, g, false, bv.gp_cost);
+    const int nrows = reg_row_count(wd);
+    for (int i = threadIdx.x; i < nrows; i += kBlock) {
+        int all_const;
+        reg_row_eval(wd, bv.cmask, bv.pose, bv.pdir, bv.pdist, i, true, rows[i], all_const);
+        fixed[i] = all_const;
+    }
+}
+
 }  // namespace kba

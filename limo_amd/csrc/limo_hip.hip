@@ -16,6 +16,7 @@
 #include "kba_kernels.hip"
 
 #include "kba_buffers.hpp"
+#include "kba_rows.hpp"
 
 using namespace kba;
 
@@ -1449,6 +1450,45 @@ int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_
         }
         if (cost) *cost = total;
     }
+    limo_ba_batch_destroy(b);
+    return rc;
+}
+
+int limo_ba_evaluate_rows(limo_ctx* ctx, const limo_ba_window* window, const limo_speed_prior* prior, int pose_only,
+                          const limo_ba_options* opts, int32_t cap, limo_ba_row* rows, int32_t* n_rows) {
+    if (!ctx || !window || !n_rows || cap < 0 || (cap > 0 && !rows)) return LIMO_ERR_INVALID;
+    PackOptions po;
+    po.pose_only = pose_only != 0;
+    po.prior = pose_only ? prior : nullptr;
+    limo_ba_batch* b = nullptr;
+    int rc = batch_create_impl(ctx, 1, window, opts, po, &b);  // the SOLVE problem: ground-plane wiring, regularisers, constness
+    if (rc != LIMO_OK) return rc;
+    const PackedBatch& P = b->P;
+    const WinDesc& wd = P.win[0];
+    const int n_reg = reg_row_count(wd), n_gp = wd.n_gp;
+    RegRow* d_rows = nullptr;
+    int32_t* d_fixed = nullptr;
+    rc = b->dmalloc((void**)&d_rows, sizeof(RegRow) * std::max(1, n_reg));
+    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_fixed, sizeof(int32_t) * std::max(1, n_reg));
+    std::vector<RegRow> hrows(std::max(1, n_reg));
+    std::vector<int32_t> hfixed(std::max(1, n_reg));
+    std::vector<double> gr(std::max<int64_t>(1, P.SG)), gF((size_t)std::max<int64_t>(1, P.SG) * 10), gE((size_t)std::max<int64_t>(1, P.SG) * 3), gcost(std::max(1, P.TG));
+    if (rc == LIMO_OK) {
+        hipLaunchKernelGGL(k_eval_rows, dim3(1), dim3(kBlock), 0, ctx->stream, b->bv, 0, d_rows, d_fixed);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && n_reg) e = hipMemcpyAsync(hrows.data(), d_rows, sizeof(RegRow) * n_reg, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_reg) e = hipMemcpyAsync(hfixed.data(), d_fixed, sizeof(int32_t) * n_reg, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_gp) e = hipMemcpyAsync(gr.data(), b->bv.gp_r, sizeof(double) * P.SG, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_gp) e = hipMemcpyAsync(gF.data(), b->bv.gp_F, sizeof(double) * P.SG * 10, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_gp) e = hipMemcpyAsync(gE.data(), b->bv.gp_E, sizeof(double) * P.SG * 3, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_gp) e = hipMemcpyAsync(gcost.data(), b->bv.gp_cost, sizeof(double) * P.TG, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("evaluate_rows: ") + hipGetErrorString(e);
+            rc = LIMO_ERR_RUNTIME;
+        }
+    }
+    if (rc == LIMO_OK) *n_rows = rows_from_linearisation(P, 0, gr.data(), gF.data(), gE.data(), gcost.data(), hrows.data(), hfixed.data(), cap, rows);
     limo_ba_batch_destroy(b);
     return rc;
 }

@@ -27,10 +27,16 @@ namespace {
 
 using IdMap = std::map<ResidualBlock*, std::pair<unsigned long, int>>;  // ResidualIdMap, robust_solving.hpp:26
 
+struct RowMeta {  // a residual block that is not a reprojection / depth block (oracle_ba_evaluate_rows)
+    ResidualBlock* rb;
+    int kind;  // enum limo_row_kind
+    int lm;    // landmark of a ground-height block, else -1
+};
 struct Built {
     Problem problem;
     IdMap depth, repr, gp;
     int n_depth = 0, n_repr = 0, n_gp = 0;
+    std::vector<RowMeta> other;
 };
 
 Pose7 cam_pose(const double* cam10) {
@@ -103,6 +109,7 @@ void build_solve_problem(const limo_ba_window& w, const limo_ba_options& o, Buil
             ResidualBlock* rb =
                 P.AddResidualBlock(cost, Loss::ScaledHuber(robust_loss_scale, loss_weight), {pose, dir, dist, lm});
             B.gp[rb] = std::make_pair((unsigned long)l, 1);
+            B.other.push_back({rb, LIMO_ROW_GROUND_HEIGHT, l});
         }
     }
     B.n_gp = (int)B.gp.size();
@@ -113,7 +120,7 @@ void build_solve_problem(const limo_ba_window& w, const limo_ba_options& o, Buil
             auto* cost = new AutoDiffCost<PoseRegularization, 1, 7, 7>(PoseRegularization{current_scale});
             ParamBlock* p1 = P.AddParameterBlock(w.kf_pose + 7, 7, PK_POSE_QUAT_R3);
             ParamBlock* p0 = P.AddParameterBlock(w.kf_pose, 7, PK_POSE_QUAT_R3);
-            P.AddResidualBlock(cost, Loss::ScaledTrivial(wgt), {p1, p0});
+            B.other.push_back({P.AddResidualBlock(cost, Loss::ScaledTrivial(wgt), {p1, p0}), LIMO_ROW_SCALE, -1});
         }
     };
     // :704-716
@@ -132,24 +139,28 @@ void build_solve_problem(const limo_ba_window& w, const limo_ba_options& o, Buil
             const int k1 = k0 + 1;
             ParamBlock* d1 = P.AddParameterBlock(w.kf_plane_dir + 3 * k1, 3, PK_FIX_SCALE_VECTOR);
             ParamBlock* d0 = P.AddParameterBlock(w.kf_plane_dir + 3 * k0, 3, PK_FIX_SCALE_VECTOR);
-            P.AddResidualBlock(new AutoDiffCost<VectorDifferenceRegularization, 3, 3, 3>(VectorDifferenceRegularization()),
-                               Loss::ScaledTrivial(3. * wgt), {d1, d0});
+            B.other.push_back({P.AddResidualBlock(new AutoDiffCost<VectorDifferenceRegularization, 3, 3, 3>(VectorDifferenceRegularization()),
+                                                  Loss::ScaledTrivial(3. * wgt), {d1, d0}),
+                               LIMO_ROW_NORMAL_DIFF, -1});
             ParamBlock* h1 = P.AddParameterBlock(w.kf_plane_dist + k1, 1, PK_EUCLIDEAN);
             ParamBlock* h0 = P.AddParameterBlock(w.kf_plane_dist + k0, 1, PK_EUCLIDEAN);
-            P.AddResidualBlock(
-                new AutoDiffCost<GroundPlaneDistanceRegularization, 1, 1, 1>(GroundPlaneDistanceRegularization()),
-                Loss::ScaledTrivial(wgt), {h1, h0});
+            B.other.push_back({P.AddResidualBlock(
+                                   new AutoDiffCost<GroundPlaneDistanceRegularization, 1, 1, 1>(GroundPlaneDistanceRegularization()),
+                                   Loss::ScaledTrivial(wgt), {h1, h0}),
+                               LIMO_ROW_DIST_DIFF, -1});
             ParamBlock* p0 = P.AddParameterBlock(w.kf_pose + 7 * k0, 7, PK_POSE_QUAT_R3);
             ParamBlock* p1 = P.AddParameterBlock(w.kf_pose + 7 * k1, 7, PK_POSE_QUAT_R3);
-            P.AddResidualBlock(
-                new AutoDiffCost<GroundPlaneMotionRegularization, 1, 7, 7, 3>(GroundPlaneMotionRegularization()),
-                Loss::ScaledTrivial(2. * wgt), {p0, p1, d0});
+            B.other.push_back({P.AddResidualBlock(
+                                   new AutoDiffCost<GroundPlaneMotionRegularization, 1, 7, 7, 3>(GroundPlaneMotionRegularization()),
+                                   Loss::ScaledTrivial(2. * wgt), {p0, p1, d0}),
+                               LIMO_ROW_PLANE_MOTION, -1});
         }
         for (int k = 0; k < w.n_kf; ++k) {
             ParamBlock* d = P.AddParameterBlock(w.kf_plane_dir + 3 * k, 3, PK_FIX_SCALE_VECTOR);
-            P.AddResidualBlock(new AutoDiffCost<VectorDifferenceRegularization2, 3, 3>(
-                                   VectorDifferenceRegularization2{{0., 0., 1.}}),
-                               Loss::ScaledTrivial(wgt), {d});
+            B.other.push_back({P.AddResidualBlock(new AutoDiffCost<VectorDifferenceRegularization2, 3, 3>(
+                                                      VectorDifferenceRegularization2{{0., 0., 1.}}),
+                                                  Loss::ScaledTrivial(wgt), {d}),
+                               LIMO_ROW_GLOBAL_NORMAL, -1});
         }
     }
     // :722-728 fix plane distance if it is the only scale information
@@ -163,6 +174,23 @@ void build_solve_problem(const limo_ba_window& w, const limo_ba_options& o, Buil
         if (ParamBlock* p = P.Get(w.kf_pose + 7 * k)) p->constant = true;
         if (ParamBlock* p = P.Get(w.kf_plane_dir + 3 * k)) p->constant = true;
         if (ParamBlock* p = P.Get(w.kf_plane_dist + k)) p->constant = true;
+    }
+}
+
+// adjustPoseOnly problem, :820-862: the observations of ONE keyframe against constant landmarks + the speed prior
+void build_pose_only_problem(const limo_ba_window& w, const limo_speed_prior* prior, const limo_ba_options& o, Built& B) {
+    add_observations(w, o, B, true);
+    for (auto& p : B.problem.params)
+        if (p->size == 3) p->constant = true;  // deactivateLandmarks(), :862
+    if (prior && prior->speed_weight > 0.0) {  // :835-853
+        SpeedRegularizationVector2 f;
+        f.dt_cur_ = prior->dt_cur;
+        for (int i = 0; i < 3; ++i) f.vel_before_before2_[i] = prior->vel_prev[i];
+        f.pose_origin_before_eigen_ = inverse(convert(prior->pose_before));
+        ParamBlock* pose = B.problem.AddParameterBlock(w.kf_pose, 7, PK_POSE_QUAT_R3);
+        B.other.push_back({B.problem.AddResidualBlock(new AutoDiffCost<SpeedRegularizationVector2, 3, 7>(f),
+                                                      Loss::ScaledTrivial(prior->speed_weight), {pose}),
+                           LIMO_ROW_SPEED, -1});
     }
 }
 
@@ -409,18 +437,7 @@ int oracle_ba_adjust_pose_only(limo_ba_window* w, const limo_speed_prior* prior,
     if (!w || !o || w->n_kf != 1) return LIMO_ERR_INVALID;
     auto t0 = std::chrono::steady_clock::now();
     Built B;
-    add_observations(*w, *o, B, true);
-    for (auto& p : B.problem.params)
-        if (p->size == 3) p->constant = true;  // deactivateLandmarks(), :862
-    if (prior && prior->speed_weight > 0.0) {  // :835-853
-        SpeedRegularizationVector2 f;
-        f.dt_cur_ = prior->dt_cur;
-        for (int i = 0; i < 3; ++i) f.vel_before_before2_[i] = prior->vel_prev[i];
-        f.pose_origin_before_eigen_ = inverse(convert(prior->pose_before));
-        ParamBlock* pose = B.problem.AddParameterBlock(w->kf_pose, 7, PK_POSE_QUAT_R3);
-        B.problem.AddResidualBlock(new AutoDiffCost<SpeedRegularizationVector2, 3, 7>(f),
-                                   Loss::ScaledTrivial(prior->speed_weight), {pose});
-    }
+    build_pose_only_problem(*w, prior, *o, B);
     std::vector<int> number_iterations;
     if (w->n_lm > o->min_landmarks_for_trimming)  // :865-869 (caller passes 30)
         for (int i = 0; i < o->num_trim_rounds; ++i) number_iterations.push_back(o->trim_solver_iterations);
@@ -487,6 +504,85 @@ int oracle_ba_evaluate(const limo_ba_window* w, const limo_ba_options* o, int ap
         if (jac_lm) std::memcpy(jac_lm + 9 * (size_t)i, jl, sizeof(jl));
     }
     if (cost) *cost = total;
+    return LIMO_OK;
+}
+
+// The residual blocks of the solve() / adjustPoseOnly problem that are not reprojection / depth blocks, row by row, with
+// their tangent-space Jacobians by dual numbers (see limo_ba_evaluate_rows in include/limo_hip.h: same row struct, same
+// conventions; the ORDER of the rows is this file's construction order - match rows by (kind, kf, lm, sub)).
+int oracle_ba_evaluate_rows(const limo_ba_window* w, const limo_speed_prior* prior, int pose_only, const limo_ba_options* o, int32_t cap,
+                            limo_ba_row* rows, int32_t* n_rows) {
+    if (!w || !o || !n_rows) return LIMO_ERR_INVALID;
+    Built B;
+    if (pose_only)
+        build_pose_only_problem(*w, prior, *o, B);
+    else
+        build_solve_problem(*w, *o, B);
+    int n = 0;
+    for (const RowMeta& m : B.other) {
+        const ResidualBlock& rb = *m.rb;
+        const int nres = rb.cost->nres, np = (int)rb.params.size();
+        double res[3], cost, jac[4][3 * 7];
+        double* jj[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < np; ++i) jj[i] = jac[i];
+        if (!B.problem.EvaluateBlock(rb, true, &cost, res, jj)) return 1;
+        // keyframes of the block's parameters
+        int kfs[2] = {-1, -1};
+        bool all_const = true;
+        auto kf_of = [&](const ParamBlock* p, int& slot0) {
+            const double* u = p->user;
+            if (u >= w->kf_pose && u < w->kf_pose + 7 * (size_t)w->n_kf) {
+                slot0 = 0;
+                return (int)((u - w->kf_pose) / 7);
+            }
+            if (u >= w->kf_plane_dir && u < w->kf_plane_dir + 3 * (size_t)w->n_kf) {
+                slot0 = 6;
+                return (int)((u - w->kf_plane_dir) / 3);
+            }
+            if (u >= w->kf_plane_dist && u < w->kf_plane_dist + w->n_kf) {
+                slot0 = 9;
+                return (int)(u - w->kf_plane_dist);
+            }
+            slot0 = -1;  // a landmark
+            return -1;
+        };
+        for (int i = 0; i < np; ++i) {
+            int s0;
+            const int k = kf_of(rb.params[i], s0);
+            all_const = all_const && rb.params[i]->constant;
+            if (k < 0) continue;
+            if (kfs[0] < 0 || k == kfs[0])
+                kfs[0] = k;
+            else
+                kfs[1] = k;
+        }
+        if (kfs[1] >= 0 && kfs[1] < kfs[0]) std::swap(kfs[0], kfs[1]);
+        for (int r = 0; r < nres; ++r, ++n) {
+            if (n >= cap || !rows) continue;
+            limo_ba_row& out = rows[n];
+            std::memset(&out, 0, sizeof(out));
+            out.kind = m.kind;
+            out.sub = r;
+            out.kf[0] = kfs[0];
+            out.kf[1] = kfs[1];
+            out.lm = m.lm;
+            out.fixed = all_const ? 1 : 0;
+            out.r = res[r];
+            out.cost = r == 0 ? cost : 0.0;
+            for (int i = 0; i < np; ++i) {
+                int s0;
+                const int k = kf_of(rb.params[i], s0);
+                const int l = rb.params[i]->lsize();
+                for (int c = 0; c < l; ++c) {
+                    if (k < 0)
+                        out.jac_lm[c] += jac[i][r * l + c];
+                    else
+                        out.jac_kf[k == kfs[0] ? 0 : 1][s0 + c] += jac[i][r * l + c];
+                }
+            }
+        }
+    }
+    *n_rows = n;
     return LIMO_OK;
 }
 

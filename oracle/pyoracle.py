@@ -35,6 +35,7 @@ def load():
     lib.oracle_last_trimmed.argtypes = [ip, C.c_int]
     lib.oracle_ba_adjust_pose_only.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.SpeedPrior), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int]
     lib.oracle_ba_evaluate.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, dp, dp, dp, dp, u8p]
+    lib.oracle_ba_evaluate_rows.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.SpeedPrior), C.c_int, C.POINTER(_ffi.BaOptions), C.c_int32, C.POINTER(_ffi.BaRow), ip]
     lib.oracle_ba_problem_cost.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), dp, ip]
     lib.oracle_trim_quantile.argtypes = [C.c_int32, _ffi.c_int64_p, dp, C.c_double, _ffi.c_int64_p]
     lib.oracle_trim_fix.argtypes = [C.c_int32, _ffi.c_int64_p, dp, C.c_double, _ffi.c_int64_p]
@@ -101,6 +102,19 @@ def evaluate(window, opts, apply_loss=True):
     if rc != 0:
         raise RuntimeError("oracle_ba_evaluate rc=%d" % rc)
     return float(cost[0]), res, jp, jl, valid
+
+
+def evaluate_rows(window, opts, pose_only=False, prior=None):
+    """The non-observation residual rows of the solve() / adjustPoseOnly problem with dual-number tangent Jacobians."""
+    lib = load()
+    s = window.as_struct()
+    n = C.c_int32(0)
+    cap = 64 + window.n_lm + 8 * window.n_kf
+    rows = (_ffi.BaRow * cap)()
+    rc = lib.oracle_ba_evaluate_rows(C.byref(s), None if prior is None else C.byref(prior), int(pose_only), C.byref(opts), cap, rows, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("oracle_ba_evaluate_rows rc=%d" % rc)
+    return _ffi.rows_as_dicts(rows, n.value)
 
 
 def problem_cost(window, opts):

@@ -14,6 +14,7 @@
 
 #include "../../limo_amd/csrc/kba_buffers.hpp"
 #include "../../limo_amd/csrc/kba_items.hpp"
+#include "../../limo_amd/csrc/kba_rows.hpp"
 
 using namespace kba;
 
@@ -544,6 +545,33 @@ int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int 
         }
     }
     if (cost) *cost = total;
+    return LIMO_OK;
+}
+
+// limo_ba_evaluate_rows on the emulated pipeline: the same lane functions (gp_lane, reg_row_eval) in host loops, the same
+// row assembly (kba_rows.hpp).
+int emu_ba_evaluate_rows(const limo_ba_window* window, const limo_speed_prior* prior, int pose_only, const limo_ba_options* o, int32_t cap,
+                         limo_ba_row* rows, int32_t* n_rows) {
+    EmuBatch B;
+    std::string err;
+    PackOptions po;
+    po.pose_only = pose_only != 0;
+    po.prior = pose_only ? prior : nullptr;
+    int rc = pack_windows(1, window, *o, po, B.P, err);
+    if (rc != LIMO_OK) return rc;
+    B.c = make_consts(*o);
+    B.alloc();
+    const WinDesc& wd = B.bv.win[0];
+    for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g) gp_lane(B.bv, g, false, B.bv.gp_cost);
+    const int n_reg = reg_row_count(wd);
+    std::vector<RegRow> regs(std::max(1, n_reg));
+    std::vector<int32_t> fixed(std::max(1, n_reg));
+    for (int i = 0; i < n_reg; ++i) {
+        int ac;
+        reg_row_eval(wd, B.bv.cmask, B.bv.pose, B.bv.pdir, B.bv.pdist, i, true, regs[i], ac);
+        fixed[i] = ac;
+    }
+    *n_rows = rows_from_linearisation(B.P, 0, B.bv.gp_r, B.bv.gp_F, B.bv.gp_E, B.bv.gp_cost, regs.data(), fixed.data(), cap, rows);
     return LIMO_OK;
 }
 

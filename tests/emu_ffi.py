@@ -112,8 +112,21 @@ def load():
         lib.emu_ba_solve_batch_streaming.argtypes = [C.c_int32, C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.POINTER(_ffi.BaReport), C.c_int]
         lib.emu_last_trimmed.argtypes = [C.c_int, _ffi.c_int32_p, C.c_int]
         lib.emu_ba_solve_sharded.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.BaOptions), C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, C.POINTER(_ffi.BaReport)]
+        lib.emu_ba_evaluate_rows.argtypes = [C.POINTER(_ffi.BaWindow), C.POINTER(_ffi.SpeedPrior), C.c_int, C.POINTER(_ffi.BaOptions), C.c_int32, C.POINTER(_ffi.BaRow), _ffi.c_int32_p]
         _lib = lib
     return _lib
+
+
+def evaluate_rows(window, opts, pose_only=False, prior=None):
+    lib = load()
+    s = window.as_struct()
+    n = C.c_int32(0)
+    cap = 64 + window.n_lm + 8 * window.n_kf
+    rows = (_ffi.BaRow * cap)()
+    rc = lib.emu_ba_evaluate_rows(C.byref(s), None if prior is None else C.byref(prior), int(pose_only), C.byref(opts), cap, rows, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("emu_ba_evaluate_rows rc=%d" % rc)
+    return _ffi.rows_as_dicts(rows, n.value)
 
 
 def solve_batch(windows, opts, pose_only=False, prior=None):

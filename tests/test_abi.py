@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "liblimo_hip.so does not export %s" % name
     assert sorted(_ffi.ABI_SYMBOLS) == declared
-    assert lib.limo_abi_version() == 1
+    assert lib.limo_abi_version() == _ffi.ABI_VERSION
 
 
 def test_struct_sizes_match_the_header_layout():

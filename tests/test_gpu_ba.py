@@ -44,6 +44,15 @@ def test_evaluate_matches_oracle(ctx, oracle, apply_loss):
     assert np.abs(jl0 - jl1).max() <= 1e-9 * np.abs(jl0).max()
 
 
+def test_ground_and_regulariser_rows_match_oracle(ctx, oracle):
+    """SURVEY §8 B3 / B4 per entry on the GPU: ground-plane height rows and every regulariser row (scale, normal / distance
+    smoothness, plane motion, global normal, speed prior) with their tangent-space Jacobians, <= 1e-9 against the oracle's
+    dual numbers, on windows that exercise each wiring rule (tests/rows_common.py)."""
+    import rows_common
+
+    rows_common.run(lambda w, o, pose_only, prior: ctx.evaluate_rows(w, o, pose_only, prior), oracle)
+
+
 def test_solve_c1_reprojection_only(ctx, oracle):
     check_solve_parity(ctx, oracle, synth.config_c1(), default_options())
 
