@@ -220,9 +220,12 @@ private:
     // different back ends are compared call by call with it)
     void trace(const char* what, TimestampNSec stamp, const Pose& p, double cost) const {
         static const bool on = std::getenv("LIMO_STREAM_TRACE") != nullptr;
-        if (on)
-            std::fprintf(stderr, "trace %s %llu cost %.17g pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g selected %zu\n", what, (unsigned long long)stamp, cost, p[0],
-                         p[1], p[2], p[3], p[4], p[5], p[6], ba_.selected_landmark_ids_.size());
+        if (on) {
+            uint64_t h = 1469598103934665603ull;  // FNV-1a over the selected ids: two drives select the same SET iff the hashes agree
+            for (const auto& id : ba_.selected_landmark_ids_) h = (h ^ (uint64_t)id) * 1099511628211ull;
+            std::fprintf(stderr, "trace %s %llu cost %.17g pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g selected %zu set %016llx\n", what,
+                         (unsigned long long)stamp, cost, p[0], p[1], p[2], p[3], p[4], p[5], p[6], ba_.selected_landmark_ids_.size(), (unsigned long long)h);
+        }
     }
     // mono_lidar.cpp:157-186: direction of the motion since the last keyframe from the five-point algorithm (straight ahead
     // when the image flow is too small for it), length = speed of the last two keyframes x time since the last one

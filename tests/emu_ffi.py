@@ -27,12 +27,31 @@ SHIM_TEST_EMU = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_emu")
 SHIM_TEST_GPU = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_gpu")
 
 
-def build_stream_test(gpu=False):
-    """tests/cpp/test_kba_stream.cpp (streaming sequence through the shim) against the emulated C-ABI or liblimo_hip.so."""
+ORACLE_ABI_LIB_PATH = os.path.join(_HERE, "cpp", "_build", "libkba_oracle_abi.so")
+
+
+def build_oracle_abi():
+    """tests/cpp/oracle_abi.cpp: the C-ABI names served by liboracle.so (the restated Ceres loop, NOT the emulated kernels) -
+    the third backend of the shim tests and of limo_stream: a config-5 drive whose arithmetic shares nothing with the GPU's."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    oracle_dir = os.path.abspath(os.path.join(_HERE, "..", "oracle", "_build"))
+    if not os.path.exists(os.path.join(oracle_dir, "liboracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "..", "oracle")])
+    src = os.path.join(_HERE, "cpp", "oracle_abi.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ORACLE_ABI_LIB_PATH, src, "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + oracle_dir])
+    return ["-L" + oracle_dir, ORACLE_ABI_LIB_PATH, "-loracle", "-Wl,-rpath," + os.path.dirname(ORACLE_ABI_LIB_PATH), "-Wl,-rpath," + oracle_dir]
+
+
+def build_stream_test(gpu=False, oracle=False):
+    """tests/cpp/test_kba_stream.cpp (streaming sequence through the shim) against the emulated C-ABI, liblimo_hip.so, or the
+    oracle behind the C-ABI."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
     test_src = os.path.join(_HERE, "cpp", "test_kba_stream.cpp")
-    out = os.path.join(_HERE, "cpp", "_build", "test_kba_stream_gpu" if gpu else "test_kba_stream_emu")
+    out = os.path.join(_HERE, "cpp", "_build", "test_kba_stream_gpu" if gpu else "test_kba_stream_oracle" if oracle else "test_kba_stream_emu")
+    if oracle:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + build_oracle_abi())
+        return out
     if not gpu:
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
@@ -45,12 +64,15 @@ def build_stream_test(gpu=False):
 STREAM_APP_SRC = os.path.join(_HERE, "..", "apps", "limo_stream", "limo_stream.cpp")
 
 
-def build_stream_app(gpu=False):
-    """apps/limo_stream (synthetic drive through limo_amd/kba/stream_driver.hpp) against liblimo_hip.so, or against the
-    emulated C-ABI + the oracle's depth assignment (CPU tier)."""
+def build_stream_app(gpu=False, oracle=False):
+    """apps/limo_stream (synthetic drive through limo_amd/kba/stream_driver.hpp) against liblimo_hip.so, against the
+    emulated C-ABI + the oracle's depth assignment (CPU tier), or with the ORACLE behind every C-ABI call (oracle=True)."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
-    out = os.path.join(_HERE, "cpp", "_build", "limo_stream_gpu" if gpu else "limo_stream_emu")
+    out = os.path.join(_HERE, "cpp", "_build", "limo_stream_gpu" if gpu else "limo_stream_oracle" if oracle else "limo_stream_emu")
+    if oracle:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + build_oracle_abi())
+        return out
     if not gpu:
         oracle_dir = os.path.join(_HERE, "..", "oracle", "_build")
         abi = os.path.join(_HERE, "cpp", "_build", "libkba_emu_abi_depth.so")
@@ -62,11 +84,17 @@ def build_stream_app(gpu=False):
     return out
 
 
-def build_shim_tests(gpu=False):
-    """tests/cpp/test_kba_shim.cpp + the kba shim, linked against the emulated C-ABI (CPU tier) or liblimo_hip.so."""
+SHIM_TEST_ORACLE = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_oracle")
+
+
+def build_shim_tests(gpu=False, oracle=False):
+    """tests/cpp/test_kba_shim.cpp + the kba shim, linked against the emulated C-ABI (CPU tier), liblimo_hip.so, or the oracle."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
     test_src = os.path.join(_HERE, "cpp", "test_kba_shim.cpp")
+    if oracle:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_ORACLE, test_src] + SHIM_SRC + build_oracle_abi())
+        return SHIM_TEST_ORACLE
     if not gpu:
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_EMU, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])

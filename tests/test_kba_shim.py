@@ -21,6 +21,12 @@ def test_reference_scenarios_with_emulated_backend():
     run(emu_ffi.build_shim_tests(gpu=False))
 
 
+def test_reference_scenarios_with_the_oracle_behind_the_shim():
+    """The same gtest scenarios with oracle/kba_oracle.cpp behind the C-ABI (tests/cpp/oracle_abi.cpp): the convergence scenes
+    of test/keyframe_bundle_adjustment.cpp:794-858,1090-1145 hold for the restated Ceres loop as they do for the kernels."""
+    run(emu_ffi.build_shim_tests(oracle=True))
+
+
 @pytest.mark.gpu
 def test_reference_scenarios_on_gpu():
     run(emu_ffi.build_shim_tests(gpu=True))
@@ -152,6 +158,52 @@ def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
     # identical depths go into both drives; what is left is the arithmetic of the two BA implementations (block summation
     # orders), fed back through selection and trimming over 80 frames: 1 mm on a 44 m path
     assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() < 1e-3 and abs(og["ate_rmse"] - oe["ate_rmse"]) < 1e-3
+
+
+def run_traced(exe, frames, poses_path):
+    e = dict(os.environ, LIMO_STREAM_TRACE="1")
+    r = subprocess.run([exe, "--frames", str(frames), "--az", "2000", "--quiet", "--poses", poses_path], capture_output=True, text=True, timeout=3000, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def check_against_oracle_drive(exe, frames, tmp_path, tag):
+    """Config 5 against the ORACLE: the drive through `exe` and the same drive with oracle/kba_oracle.cpp, exact_oracle.cpp and
+    depth_oracle.cpp behind every C-ABI call (tests/cpp/oracle_abi.cpp; call order mono_lidar.cpp:186-260).  Call by call
+    (adjustPoseOnly and solve) the vehicle position agrees within 1e-4 x path travelled (north_star's pose bar) for as long
+    as both drives select the same landmark sets; the first call whose selection differs is reported."""
+    import stream_compare
+
+    orc = emu_ffi.build_stream_app(oracle=True)
+    pa, po = str(tmp_path / (tag + ".txt")), str(tmp_path / "oracle.txt")
+    res = stream_compare.compare(run_traced(exe, frames, pa), run_traced(orc, frames, po))
+    print("%s vs oracle drive, %d frames: %s" % (tag, frames, res))
+    n_before = res["n_calls"] if res["first_divergence"] is None else res["first_divergence"]
+    assert n_before >= min(res["n_calls"], 100), res    # the comparison must cover a real stretch of the drive
+    assert res["max_rel_before"] <= 1e-4 and res["max_rel_cost_before"] <= 1e-4, res
+    a, b = np.loadtxt(pa), np.loadtxt(po)
+    assert a.shape == b.shape == (frames, 12)
+    if res["first_divergence"] is None:  # same windows all the way: the trajectories ARE the same to rounding
+        assert np.abs(a[:, [3, 7, 11]] - b[:, [3, 7, 11]]).max() <= 1e-4 * max(1.0, res["path_before"]), res
+    return res
+
+
+def test_limo_stream_emulated_drive_matches_the_oracle_drive(tmp_path):
+    """CPU tier: the emulated kernels (same lane functions as the HIP binary) against the oracle drive, 80 frames."""
+    res = check_against_oracle_drive(emu_ffi.build_stream_app(gpu=False), 80, tmp_path, "emulated")
+    assert res["first_divergence"] is None and res["max_abs_before"] < 1e-6, res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", [80, 600])
+def test_limo_stream_on_gpu_matches_the_oracle_drive(tmp_path, frames):
+    """GPU tier: liblimo_hip.so (depth.hip, landmark_init.hip, k_solve_coop / k_solve_wg) against the oracle drive - NOT against
+    the emulator that shares its source: 80 frames and 600 frames (330 m, ~900 C-ABI calls)."""
+    res = check_against_oracle_drive(emu_ffi.build_stream_app(gpu=True), frames, tmp_path, "gpu")
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")  # record for profiles/
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "oracle_drive_%d.txt" % frames), "w") as f:
+        f.write(repr(res) + "\n")
 
 
 def test_stream_replicas_launcher_with_emulated_backend():
