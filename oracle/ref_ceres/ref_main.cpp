@@ -1,0 +1,210 @@
+// DORMANT - cannot be compiled in the graft image (no Ceres / Eigen); see Makefile.  TEST INFRASTRUCTURE ONLY.
+//
+// ref_kba <window.bin> <out.txt>: one flattened window (the LIMO_KBA_DUMP format of limo_amd/kba/bundle_adjuster_keyframes.cpp,
+// read back by tests/window_io.py) solved by the REAL reference arithmetic: the reference's functors
+// (internal/cost_functors_ceres.hpp), its plane parameterisation (internal/local_parameterizations.hpp) and its
+// robust_optimization::solveTrimmed (robust_solving.cpp), all #included unmodified from /root/reference, on real Ceres.
+// The only code of ours is the problem CONSTRUCTION from the flat arrays - the statements of
+//   bundle_adjuster_keyframes.cpp:498-627 (residual blocks), :629-767 (solve), :769-818 (plane regularisers),
+//   :890-904 (scale regulariser), :160-232 (parameterisations, constant blocks)
+// re-applied to arrays instead of Keyframe / Landmark objects (those drag in PCL, OpenCV and the tracklet message types).
+// Output (text, %.17g): initial / final cost, termination, poses, planes, landmarks, trimmed landmark ids - what
+// tests/test_ref_ceres.py compares with oracle/kba_oracle.cpp.
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <map>
+#include <memory>
+#include <set>
+#include <vector>
+
+#include <cost_functors_ceres.hpp>        // reference, unmodified
+#include <local_parameterizations.hpp>    // reference, unmodified
+#include REF_ROBUST_SOLVING_CPP           // reference robust_solving.cpp, unmodified (brings robust_solving.hpp)
+
+namespace kba = keyframe_bundle_adjustment;
+namespace cf = keyframe_bundle_adjustment::cost_functors_ceres;
+using Pose = std::array<double, 7>;
+
+struct Window {
+    int32_t n_kf, n_cam, n_lm, n_obs;
+    std::vector<double> kf_pose, kf_plane_dir, kf_plane_dist, cam, lm_pos, lm_weight;
+    std::vector<int32_t> kf_fixation, obs_kf, obs_lm, obs_cam;
+    std::vector<uint8_t> lm_is_ground;
+    std::vector<float> obs_u, obs_v, obs_d;
+};
+
+template <class T>
+static bool take(std::FILE* f, std::vector<T>& v, size_t n) {
+    v.resize(n);
+    return n == 0 || std::fread(v.data(), sizeof(T), n, f) == n;
+}
+
+static bool read_window(const char* path, Window& w) {
+    std::FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    int32_t head[4];
+    bool ok = std::fread(head, sizeof(int32_t), 4, f) == 4;
+    w.n_kf = head[0], w.n_cam = head[1], w.n_lm = head[2], w.n_obs = head[3];
+    ok = ok && take(f, w.kf_pose, 7 * (size_t)w.n_kf) && take(f, w.kf_plane_dir, 3 * (size_t)w.n_kf) && take(f, w.kf_plane_dist, (size_t)w.n_kf) &&
+         take(f, w.kf_fixation, (size_t)w.n_kf) && take(f, w.cam, 10 * (size_t)w.n_cam) && take(f, w.lm_pos, 3 * (size_t)w.n_lm) &&
+         take(f, w.lm_weight, (size_t)w.n_lm) && take(f, w.lm_is_ground, (size_t)w.n_lm) && take(f, w.obs_kf, (size_t)w.n_obs) &&
+         take(f, w.obs_lm, (size_t)w.n_obs) && take(f, w.obs_cam, (size_t)w.n_obs) && take(f, w.obs_u, (size_t)w.n_obs) &&
+         take(f, w.obs_v, (size_t)w.n_obs) && take(f, w.obs_d, (size_t)w.n_obs);
+    std::fclose(f);
+    return ok;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: ref_kba window.bin out.txt [solver_time_sec=20]\n");
+        return 2;
+    }
+    Window w;
+    if (!read_window(argv[1], w)) {
+        std::fprintf(stderr, "ref_kba: cannot read %s\n", argv[1]);
+        return 1;
+    }
+    const double solver_time_sec = argc > 3 ? std::atof(argv[3]) : 20.;  // the reference's tests: set_solver_time(20.), test/keyframe_bundle_adjustment.cpp:486,929
+    const double depth_thres = 0.16, repr_thres = 1.6, depth_quantile = 0.95, repr_quantile = 0.95;  // bundle_adjuster_keyframes.hpp:79-89
+    const int num_trim_rounds = 1;
+
+    ceres::Problem::Options popt{};
+    popt.enable_fast_removal = true;  // :635-637
+    ceres::Problem problem(popt);
+    using robust_optimization::ResidualIdMap;
+    ResidualIdMap ids_depth, ids_repr, ids_gp;
+
+    auto pose_of = [&](int k) { return w.kf_pose.data() + 7 * (size_t)k; };
+    auto cam_pose = [&](int c) {
+        Pose p;
+        for (int i = 0; i < 7; ++i) p[i] = w.cam[10 * (size_t)c + 3 + i];
+        return p;
+    };
+    // addKeyframeToProblem, :564-627: keyframes ascending, inside a keyframe the measurements ascending by landmark id, cameras
+    // ascending - the flat window lists landmarks ascending by id; the observations of one keyframe are visited in that order.
+    std::vector<std::vector<int>> obs_of_kf(w.n_kf);
+    for (int i = 0; i < w.n_obs; ++i) obs_of_kf[w.obs_kf[i]].push_back(i);
+    for (int k = 0; k < w.n_kf; ++k) {
+        auto& v = obs_of_kf[k];
+        std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return w.obs_lm[a] != w.obs_lm[b] ? w.obs_lm[a] < w.obs_lm[b] : w.obs_cam[a] < w.obs_cam[b]; });
+        for (int i : v) {
+            const int l = w.obs_lm[i], c = w.obs_cam[i];
+            double* lm = w.lm_pos.data() + 3 * (size_t)l;
+            if (w.obs_d[i] > 0.0f) {
+                auto id = problem.AddResidualBlock(cf::LandmarkDepthError::Create(static_cast<double>(w.obs_d[i]), cam_pose(c)),
+                                                   new ceres::ScaledLoss(new ceres::CauchyLoss(depth_thres), w.lm_weight[l], ceres::TAKE_OWNERSHIP), pose_of(k), lm);
+                ids_depth[id] = std::make_pair((unsigned long)l, 1);
+            }
+            auto id = problem.AddResidualBlock(
+                cf::ReprojectionErrorWithQuaternions::Create(static_cast<double>(w.obs_u[i]), static_cast<double>(w.obs_v[i]), w.cam[10 * (size_t)c],
+                                                             w.cam[10 * (size_t)c + 1], w.cam[10 * (size_t)c + 2], cam_pose(c)),
+                new ceres::ScaledLoss(new ceres::CauchyLoss(repr_thres), w.lm_weight[l], ceres::TAKE_OWNERSHIP), pose_of(k), lm);
+            ids_repr[id] = std::make_pair((unsigned long)l, 2);
+        }
+    }
+    // addGroundPlaneResiduals(10.), :517-562
+    for (int l = 0; l < w.n_lm; ++l) {
+        if (!w.lm_is_ground[l]) continue;
+        Eigen::Map<Eigen::Vector3d> cur_lm(w.lm_pos.data() + 3 * (size_t)l);
+        double min_dist = std::numeric_limits<double>::max();
+        int kf_id = -1;
+        for (int k = 0; k < w.n_kf; ++k) {
+            if (w.kf_plane_dist[k] < -10.) continue;
+            Pose p;
+            for (int i = 0; i < 7; ++i) p[i] = pose_of(k)[i];
+            const double dist = (kba::convert(p) * cur_lm).norm();
+            if (dist < min_dist) min_dist = dist, kf_id = k;
+        }
+        if (min_dist == std::numeric_limits<double>::max()) continue;
+        const double max_valid_dist = 25.;
+        if (min_dist < max_valid_dist) {
+            auto id = problem.AddResidualBlock(cf::GroundPlaneHeightRegularization::Create(),
+                                               new ceres::ScaledLoss(new ceres::HuberLoss(0.1), 10. * (1. - min_dist / max_valid_dist), ceres::TAKE_OWNERSHIP),
+                                               pose_of(kf_id), w.kf_plane_dir.data() + 3 * (size_t)kf_id, &w.kf_plane_dist[kf_id], w.lm_pos.data() + 3 * (size_t)l);
+            ids_gp[id] = std::make_pair((unsigned long)l, 1);
+        }
+    }
+    auto add_scale = [&](double weight) {  // :890-904
+        if (w.n_kf > 1) {
+            Pose p0, p1;
+            for (int i = 0; i < 7; ++i) p0[i] = pose_of(0)[i], p1[i] = pose_of(1)[i];
+            const double current_scale = (kba::convert(p1) * kba::convert(p0).inverse()).translation().norm();
+            problem.AddResidualBlock(cf::PoseRegularization::Create(current_scale), new ceres::ScaledLoss(new ceres::TrivialLoss(), weight, ceres::TAKE_OWNERSHIP),
+                                     pose_of(1), pose_of(0));
+        }
+    };
+    if (ids_depth.size() > 10 || ids_gp.size() > 10) {  // :704-716
+        if (ids_gp.size() < 30) add_scale(1000. / (static_cast<double>(ids_depth.size() + static_cast<double>(ids_gp.size()))));
+    } else {
+        add_scale(1000.);
+    }
+    if (ids_gp.size() > 0 && w.n_kf > 1) {  // addGroundplaneRegularization(10.), :769-818
+        const double weight = 10.;
+        for (int k0 = 0; k0 + 1 < w.n_kf; ++k0) {
+            const int k1 = k0 + 1;
+            problem.AddResidualBlock(cf::VectorDifferenceRegularization::Create(), new ceres::ScaledLoss(new ceres::TrivialLoss(), 3. * weight, ceres::TAKE_OWNERSHIP),
+                                     w.kf_plane_dir.data() + 3 * (size_t)k1, w.kf_plane_dir.data() + 3 * (size_t)k0);
+            problem.AddResidualBlock(cf::GroundPlaneDistanceRegularization::Create(), new ceres::ScaledLoss(new ceres::TrivialLoss(), weight, ceres::TAKE_OWNERSHIP),
+                                     &w.kf_plane_dist[k1], &w.kf_plane_dist[k0]);
+            problem.AddResidualBlock(cf::GroundPlaneMotionRegularization::Create(), new ceres::ScaledLoss(new ceres::TrivialLoss(), 2. * weight, ceres::TAKE_OWNERSHIP),
+                                     pose_of(k0), pose_of(k1), w.kf_plane_dir.data() + 3 * (size_t)k0);
+        }
+        for (int k = 0; k < w.n_kf; ++k)
+            problem.AddResidualBlock(cf::VectorDifferenceRegularization2::Create(std::array<double, 3>{{0., 0., 1.}}),
+                                     new ceres::ScaledLoss(new ceres::TrivialLoss(), weight, ceres::TAKE_OWNERSHIP), w.kf_plane_dir.data() + 3 * (size_t)k);
+    }
+    if (ids_depth.size() < 10)  // :722-728
+        for (int k = 0; k < w.n_kf; ++k)
+            if (problem.HasParameterBlock(&w.kf_plane_dist[k])) problem.SetParameterBlockConstant(&w.kf_plane_dist[k]);
+    for (int k = 0; k < w.n_kf; ++k) {  // setParameterization(FullDOF), :160-198
+        if (problem.HasParameterBlock(pose_of(k)))
+            problem.SetParameterization(pose_of(k), new ceres::ProductParameterization(new ceres::QuaternionParameterization(), new ceres::IdentityParameterization(3)));
+        double* dir = w.kf_plane_dir.data() + 3 * (size_t)k;
+        if (problem.HasParameterBlock(pose_of(k)) && problem.HasParameterBlock(dir))
+            problem.SetParameterization(dir, new ceres::AutoDiffLocalParameterization<kba::local_parameterizations::FixScaleVectorPlus, 3, 3>(
+                                                 new kba::local_parameterizations::FixScaleVectorPlus(1.0)));
+    }
+    for (int k = 0; k < w.n_kf; ++k) {  // deactivatePoseParameters({Pose}), :200-222; LIMO_FIX_POSE = 0 (include/limo_hip.h:55)
+        if (w.kf_fixation[k] != 0) continue;
+        if (problem.HasParameterBlock(pose_of(k))) problem.SetParameterBlockConstant(pose_of(k));
+        if (problem.HasParameterBlock(w.kf_plane_dir.data() + 3 * (size_t)k)) problem.SetParameterBlockConstant(w.kf_plane_dir.data() + 3 * (size_t)k);
+        if (problem.HasParameterBlock(&w.kf_plane_dist[k])) problem.SetParameterBlockConstant(&w.kf_plane_dist[k]);
+    }
+    std::vector<int> number_iterations;  // :740-745
+    if (w.n_lm > 100)
+        for (int i = 0; i < num_trim_rounds; ++i) number_iterations.push_back(2);
+    std::vector<std::pair<ResidualIdMap, robust_optimization::TrimmerSpecification>> input;
+    input.push_back(std::make_pair(ids_depth, robust_optimization::TrimmerSpecification(robust_optimization::TrimmerType::Quantile, depth_quantile)));
+    input.push_back(std::make_pair(ids_repr, robust_optimization::TrimmerSpecification(robust_optimization::TrimmerType::Quantile, repr_quantile)));
+    input.push_back(std::make_pair(ids_gp, robust_optimization::TrimmerSpecification(robust_optimization::TrimmerType::Quantile, 1.0)));
+    robust_optimization::Options opt = robust_optimization::getStandardSolverOptions(solver_time_sec);  // :759-764
+    opt.max_solver_time_refinement_in_seconds = solver_time_sec;
+    opt.minimum_number_residual_groups = 30;
+    opt.trust_region_relaxation_factor = -10.;
+    opt.num_threads = 3;
+    opt.minimizer_progress_to_stdout = false;
+    auto summary = robust_optimization::solveTrimmed(number_iterations, input, problem, opt);
+
+    // landmarks whose residual groups solveTrimmed removed: every id left in the maps is alive
+    std::set<unsigned long> alive;
+    for (auto& m : input)
+        for (auto& el : m.first) alive.insert(el.second.first);
+    std::FILE* o = std::fopen(argv[2], "w");
+    if (!o) return 1;
+    std::fprintf(o, "initial_cost %.17g\nfinal_cost %.17g\ntermination %d\nnum_solves %zu\n", summary.initial_cost, summary.final_cost,
+                 (int)summary.all_summaries.back().termination_type, summary.all_summaries.size());
+    for (int k = 0; k < w.n_kf; ++k) {
+        std::fprintf(o, "kf %d", k);
+        for (int i = 0; i < 7; ++i) std::fprintf(o, " %.17g", pose_of(k)[i]);
+        std::fprintf(o, " plane %.17g %.17g %.17g %.17g\n", w.kf_plane_dir[3 * k], w.kf_plane_dir[3 * k + 1], w.kf_plane_dir[3 * k + 2], w.kf_plane_dist[k]);
+    }
+    for (int l = 0; l < w.n_lm; ++l) {
+        bool observed = false;
+        for (int i = 0; i < w.n_obs && !observed; ++i) observed = w.obs_lm[i] == l;
+        std::fprintf(o, "lm %d %.17g %.17g %.17g trimmed %d\n", l, w.lm_pos[3 * l], w.lm_pos[3 * l + 1], w.lm_pos[3 * l + 2], (observed && !alive.count((unsigned long)l)) ? 1 : 0);
+    }
+    std::fclose(o);
+    return 0;
+}
