@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define LIMO_ABI_VERSION 2 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms */
+#define LIMO_ABI_VERSION 3 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms; 3: limo_ctx_coop_fallbacks */
 
 /* Keyframe::FixationStatus, keyframe.hpp:30 */
 enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
@@ -229,6 +229,11 @@ int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_o
 /* Exchange accounting of the last limo_ba_solve_sharded on this context: stats3 = (exchange steps = all-reduce calls
  * with a communicator, bytes entering them on this rank, LM iterations of the solve). */
 int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3);
+/* How many one-launch solves (k_solve_coop behind limo_ba_solve / small batches) on this context gave up at a device-wide
+ * barrier and were redone as a launch sequence.  A barrier waits at most KBA_COOP_TIMEOUT_MS (default 2000) of the GPU's
+ * constant clock, which keeps running while a wave is preempted (shared GPU, debugger, profiler); the redo starts from the
+ * batch's initial state and gives the same results - the caller never sees an error, this counter is how it can tell. */
+int64_t limo_ctx_coop_fallbacks(const limo_ctx* ctx);
 
 /*
  * Evaluate the reprojection / depth residual blocks of a window at its current parameters

@@ -190,7 +190,7 @@ class DepthParams(C.Structure):  # struct limo_depth_params
     ]
 
 
-ABI_VERSION = 2  # LIMO_ABI_VERSION of include/limo_hip.h
+ABI_VERSION = 3  # LIMO_ABI_VERSION of include/limo_hip.h
 
 # every symbol include/limo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -215,6 +215,7 @@ ABI_SYMBOLS = [
     "limo_ctx_comm_init",
     "limo_ba_solve_sharded",
     "limo_ctx_exchange_stats",
+    "limo_ctx_coop_fallbacks",
     "limo_ba_evaluate",
     "limo_ba_evaluate_batch_time",
     "limo_ba_evaluate_rows",
@@ -322,6 +323,8 @@ def load():
     lib.limo_depth_estimate_batch.argtypes = [vp, C.c_int32, C.POINTER(DepthFrame), c_double_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                               C.POINTER(DepthParams), C.c_uint32]
     lib.limo_ctx_exchange_stats.argtypes = [vp, c_int64_p]
+    lib.limo_ctx_coop_fallbacks.argtypes = [vp]
+    lib.limo_ctx_coop_fallbacks.restype = C.c_int64
     lib.limo_depth_set_timing.argtypes = [vp, C.c_int32]
     lib.limo_depth_last_kernel_ms.argtypes = [vp, c_double_p]
     lib.limo_depth_last_ground_plane.argtypes = [vp, C.c_int32, c_double_p, c_int32_p]

@@ -75,6 +75,10 @@ class Context:
         _check(self.lib.limo_ctx_exchange_stats(self.ptr, st), self.ptr, "limo_ctx_exchange_stats")
         return {"exchanges": int(st[0]), "bytes": int(st[1]), "iterations": int(st[2])}
 
+    def coop_fallbacks(self):
+        """limo_ctx_coop_fallbacks: one-launch solves on this context that timed out at a barrier and were redone as launches."""
+        return int(self.lib.limo_ctx_coop_fallbacks(self.ptr))
+
     def comm_init(self, unique_id, rank, world):
         _check(self.lib.limo_ctx_comm_init(self.ptr, unique_id, int(rank), int(world)), self.ptr, "limo_ctx_comm_init")
 

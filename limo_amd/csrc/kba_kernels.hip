@@ -1474,6 +1474,7 @@ struct CoopParams {
     int32_t vp, vg;            // k_schur_lean variant (TM) of the plain / ground-plane groups
     int32_t schur_lds;         // doubles of LDS per wave in the Schur phase
     long long cap_ticks;       // wall-clock cap of a solve (100 MHz ticks), 0: none
+    long long timeout_ticks;   // a barrier that waits longer aborts the launch (the host then takes the launch sequence)
     int32_t* bar;              // [n_win][2][4] {arrived, generation, abort, -} x {all workgroups, all but the first}, zeroed before the launch
     int32_t* abort_host;       // pinned: set when a barrier timed out
     double *plane_rep, *plane_dep;
@@ -1481,7 +1482,14 @@ struct CoopParams {
 };
 constexpr int kCoopRedStride = 64 * 64;  // nf_pad <= 64 for fast-class windows (<= 4 free keyframes: 40 slots + rhs)
 
-__device__ __forceinline__ bool coop_sync(int32_t* bar, int G, int& gen, int32_t* abort_host) {
+// One device-wide barrier of the G workgroups of a window.  A barrier that is not met within `timeout` ticks of the 100 MHz
+// constant clock ABORTS the launch: every workgroup of the window returns, the pinned flag tells the host, and the host
+// restores the batch's initial state and solves it through the launch sequence instead (limo_ba_batch_solve) - a timeout is
+// never an error the caller sees.  (That clock keeps running while a wave is preempted - a GPU shared with another process,
+// a debugger or a profiler serialising dispatches - so a healthy launch CAN time out; the default is 2 s, KBA_COOP_TIMEOUT_MS
+// sets it.)  `abort_word` is shared by the window's main barrier and the barrier of its Schur workgroups: whoever gives up
+// first releases everybody at their next poll.
+__device__ __forceinline__ bool coop_sync(int32_t* bar, int32_t* abort_word, int G, int& gen, int32_t* abort_host, long long timeout) {
     if (G == 1) {
         __syncthreads();
         return true;
@@ -1500,8 +1508,8 @@ __device__ __forceinline__ bool coop_sync(int32_t* bar, int G, int& gen, int32_t
             // the fence behind the loop does it once)
             while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
                 __builtin_amdgcn_s_sleep(2);
-                if (__hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > 50000000ll) {
-                    __hip_atomic_store(&bar[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || (long long)wall_clock64() - t0 > timeout) {
+                    __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *(volatile int32_t*)abort_host = 1;
                     __threadfence_system();
                     ok = false;
@@ -1539,7 +1547,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
 #endif
 #define KBA_GSYNC()                                        \
     do {                                                   \
-        if (!coop_sync(bar, G, gen, a.abort_host)) return; \
+        if (!coop_sync(bar, bar + 2, G, gen, a.abort_host, a.timeout_ticks)) return; \
     } while (0)
     const int lb0 = wd.lblk0, lb1 = wd.lblk0 + wd.n_lblk;
     const int n_pg = (wd.n_sblk_plain + c.schur_span - 1) / c.schur_span;
@@ -1640,7 +1648,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                     schur_phase(1);
                     KBA_CTICK(4);
                     if (g >= 1) {
-                        if (!coop_sync(bar + 4, G - 1, gen_sub, a.abort_host)) return;
+                        if (!coop_sync(bar + 4, bar + 2, G - 1, gen_sub, a.abort_host, a.timeout_ticks)) return;
                         slab_sum(1);
                     }
                     slabs_summed = true;

@@ -18,6 +18,7 @@ struct limo_ctx {
     void* comm = nullptr;                   // ncclComm_t of a landmark-sharded solve (limo_ctx_comm_init), else null
     int comm_rank = 0, comm_world = 1;
     long long exchange_stats[3] = {0, 0, 0};  // last landmark-sharded solve: exchange steps, bytes per rank, LM iterations
+    long long coop_fallbacks = 0;           // one-launch solves whose barrier timed out and that were redone as a launch sequence
     // Device blocks released by finished batches, kept for the next one (size class = power of two): a single-window
     // call (limo_ba_solve, limo_ba_adjust_pose_only) would otherwise spend more time in hipMalloc / hipFree than in
     // its kernels.  At most kPoolPerClass blocks per class are kept; everything is freed with the context.

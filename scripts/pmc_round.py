@@ -4,12 +4,24 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["KBA_GROUPS"] = "1"
 os.environ["KBA_SLOTS"] = "1024"
-from limo_amd import ba, default_options, synth
+from limo_amd import synth
 
 B = 1024
+
+
+def _make(seed):
+    return synth.make_window(seed)
+
+
+# host processes generate the windows (10 ms each in numpy), forked before any GPU state exists
+import multiprocessing as mp
+
+with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
+    ws = pool.map(_make, [5000 + i for i in range(B)], chunksize=16)
+from limo_amd import ba, default_options  # noqa: E402
+
 ctx = ba.Context(0)
 o = default_options(max_num_iterations=4, num_trim_rounds=0)
-ws = [synth.make_window(5000 + i) for i in range(B)]
 b = ba.Batch(ctx, ws)
 for _ in range(2):
     b.reset()

@@ -18,7 +18,7 @@ def build(force=False):
     deps = _SRC + [os.path.join(_HERE, "..", "limo_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "limo_amd", "csrc")) if f.endswith(".hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-o", LIB_PATH] + _SRC)
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-fPIC", "-shared", "-o", LIB_PATH] + _SRC)
 
 
 SHIM_SRC = [os.path.join(_HERE, "..", "limo_amd", "kba", "bundle_adjuster_keyframes.cpp")]
@@ -38,7 +38,7 @@ def build_oracle_abi():
     if not os.path.exists(os.path.join(oracle_dir, "liboracle.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "..", "oracle")])
     src = os.path.join(_HERE, "cpp", "oracle_abi.cpp")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ORACLE_ABI_LIB_PATH, src, "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + oracle_dir])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-o", ORACLE_ABI_LIB_PATH, src, "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + oracle_dir])
     return ["-L" + oracle_dir, ORACLE_ABI_LIB_PATH, "-loracle", "-Wl,-rpath," + os.path.dirname(ORACLE_ABI_LIB_PATH), "-Wl,-rpath," + oracle_dir]
 
 
@@ -50,14 +50,14 @@ def build_stream_test(gpu=False, oracle=False):
     test_src = os.path.join(_HERE, "cpp", "test_kba_stream.cpp")
     out = os.path.join(_HERE, "cpp", "_build", "test_kba_stream_gpu" if gpu else "test_kba_stream_oracle" if oracle else "test_kba_stream_emu")
     if oracle:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + build_oracle_abi())
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + build_oracle_abi())
         return out
     if not gpu:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
         return out
     libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
     return out
 
 
@@ -71,16 +71,16 @@ def build_stream_app(gpu=False, oracle=False):
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
     out = os.path.join(_HERE, "cpp", "_build", "limo_stream_gpu" if gpu else "limo_stream_oracle" if oracle else "limo_stream_emu")
     if oracle:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + build_oracle_abi())
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + build_oracle_abi())
         return out
     if not gpu:
         oracle_dir = os.path.join(_HERE, "..", "oracle", "_build")
         abi = os.path.join(_HERE, "cpp", "_build", "libkba_emu_abi_depth.so")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-DKBA_EMU_DEPTH", "-o", abi] + _SRC + [os.path.join(csrc, "host_misc.cpp"), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + [abi, "-Wl,-rpath," + os.path.dirname(abi), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-DKBA_EMU_DEPTH", "-o", abi] + _SRC + [os.path.join(csrc, "host_misc.cpp"), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + [abi, "-Wl,-rpath," + os.path.dirname(abi), "-L" + oracle_dir, "-loracle", "-Wl,-rpath," + os.path.abspath(oracle_dir)])
         return out
     libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", out, STREAM_APP_SRC] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
     return out
 
 
@@ -93,14 +93,14 @@ def build_shim_tests(gpu=False, oracle=False):
     csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
     test_src = os.path.join(_HERE, "cpp", "test_kba_shim.cpp")
     if oracle:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_ORACLE, test_src] + SHIM_SRC + build_oracle_abi())
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", SHIM_TEST_ORACLE, test_src] + SHIM_SRC + build_oracle_abi())
         return SHIM_TEST_ORACLE
     if not gpu:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_EMU, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-fPIC", "-shared", "-DKBA_EMU_EXPORT_ABI", "-o", ABI_LIB_PATH] + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", SHIM_TEST_EMU, test_src] + SHIM_SRC + [ABI_LIB_PATH, "-Wl,-rpath," + os.path.dirname(ABI_LIB_PATH)])
         return SHIM_TEST_EMU
     libdir = os.path.join(_HERE, "..", "limo_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", SHIM_TEST_GPU, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread", "-o", SHIM_TEST_GPU, test_src] + SHIM_SRC + ["-L" + libdir, "-llimo_hip", "-Wl,-rpath," + os.path.abspath(libdir)])
     return SHIM_TEST_GPU
 
 

@@ -245,6 +245,33 @@ def test_single_window_one_launch_equals_lock_step(ctx, cap, monkeypatch):
     assert n_coop >= 10
 
 
+def test_barrier_timeout_of_the_one_launch_solve_is_recovered(ctx, monkeypatch):
+    """A device-wide barrier of k_solve_coop that is not met in time aborts the launch with poses / landmarks / LM state
+    half-updated (the constant clock it waits on keeps running while a wave is preempted: shared GPU, debugger, profiler).
+    limo_ba_batch_solve then restores the batch's initial state and takes the launch sequence: no error reaches the caller
+    and the result is the lock-step result bit for bit.  KBA_COOP_TIMEOUT_MS=0 makes every barrier give up at its first wait."""
+    o = default_options()
+    for w in (synth.config_c2(), synth.make_window(3001)):
+        for k in ("KBA_NO_COOP_SOLVE", "KBA_NO_WG_SOLVE", "KBA_COOP_TIMEOUT_MS"):
+            monkeypatch.delenv(k, raising=False)
+        ref = w.copy()
+        monkeypatch.setenv("KBA_NO_COOP_SOLVE", "1")
+        r_ref = ctx.solve(ref, o)
+        monkeypatch.delenv("KBA_NO_COOP_SOLVE")
+        before = ctx.coop_fallbacks()
+        monkeypatch.setenv("KBA_COOP_TIMEOUT_MS", "0")
+        x = w.copy()
+        r = ctx.solve(x, o)
+        monkeypatch.delenv("KBA_COOP_TIMEOUT_MS")
+        assert ctx.coop_fallbacks() == before + 1            # the launch did give up ...
+        assert x.kf_pose.tobytes() == ref.kf_pose.tobytes() and x.lm_pos.tobytes() == ref.lm_pos.tobytes()  # ... and nothing of it is left
+        for k in ("final_cost", "initial_cost", "iterations_total", "num_solves", "n_trimmed_landmarks", "termination", "num_linearizations"):
+            assert r[k] == r_ref[k], (k, r[k], r_ref[k])
+        y = w.copy()
+        ctx.solve(y, o)                                        # the next call on the context takes the one-launch path again
+        assert ctx.coop_fallbacks() == before + 1 and y.kf_pose.tobytes() == ref.kf_pose.tobytes()
+
+
 @pytest.mark.parametrize("n", [24, 64, 200])
 def test_small_batch_one_launch_equals_streaming(ctx, n, monkeypatch):
     """Batches of up to 64 fast-class windows run as one cooperative launch with fewer workgroups per window (64 windows:
