@@ -33,6 +33,7 @@ def _check(rc, ctx=None, what=""):
 class Context:
     def __init__(self, device=0, stream=None):
         self.lib = _ffi.load()
+        self.device = device
         self.ptr = C.c_void_p()
         rc = self.lib.limo_ctx_create(device, C.byref(self.ptr))
         if rc != 0:
@@ -135,11 +136,13 @@ class Context:
 class Batch:
     """Many independent windows resident in HBM (limo_ba_batch_*)."""
 
-    def __init__(self, ctx, windows):
+    def __init__(self, ctx, windows, arr=None):
+        """arr: struct_array(windows) made earlier (the array of limo_ba_window a C / C++ caller holds anyway: building it from
+        numpy windows is ~20 us of Python per window and not part of the library call)."""
         self.ctx = ctx
         self.lib = ctx.lib
         self.windows = list(windows)
-        self._arr = struct_array(self.windows)
+        self._arr = struct_array(self.windows) if arr is None else arr
         self.ptr = C.c_void_p()
         _check(self.lib.limo_ba_batch_create(ctx.ptr, len(self.windows), self._arr, C.byref(self.ptr)), ctx.ptr, "limo_ba_batch_create")
 

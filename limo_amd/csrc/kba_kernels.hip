@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
 // system in LDS); a barrier that is not met within half a second aborts the launch (pinned flag), it cannot hang the GPU.
 struct CoopParams {
     int32_t G;                 // workgroups per window
+    int32_t xcd_map;           // 1: the workgroups of a window share an XCD (grid = 8 G ceil(n_win / 8))
     int32_t vp, vg;            // k_schur_lean variant (TM) of the plain / ground-plane groups
     int32_t schur_lds;         // doubles of LDS per wave in the Schur phase
     long long cap_ticks;       // wall-clock cap of a solve (100 MHz ticks), 0: none
@@ -1524,7 +1525,22 @@ __device__ __forceinline__ bool coop_sync(int32_t* bar, int32_t* abort_word, int
 }
 
 __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts c, CoopParams a) {
-    const int G = a.G, w = blockIdx.x / G, g = blockIdx.x % G;
+    // Workgroup -> (window, member).  xcd_map: the G workgroups of a window are placed on ONE XCD (block b runs on XCD b % 8 -
+    // observed, not promised: it buys speed, never correctness): what one of them writes with plain stores stays in the L2 the
+    // others read from, so the first touches behind every barrier are L2 hits instead of round trips over the fabric
+    // (MI355X_MICROARCH.md, handoff-payload: same-XCD 1.7x).  Window w lives on XCD w % 8; the grid is 8 G ceil(n_win / 8) and the
+    // blocks that map to no window leave at once.
+    const int G = a.G;
+    int w, g;
+    if (a.xcd_map) {
+        const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+        w = x + 8 * (s / G);
+        g = s % G;
+        if (w >= bv.n_win) return;
+    } else {
+        w = blockIdx.x / G;
+        g = blockIdx.x % G;
+    }
     const int tid = threadIdx.x, wave = tid >> 6;
     const WinDesc& wd = bv.win[w];
     WinState& st = bv.st[w];

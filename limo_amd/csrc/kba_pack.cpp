@@ -70,7 +70,8 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     // host threads over the windows (used by both passes)
     auto for_windows = [&](auto&& f) {
         unsigned nt = std::thread::hardware_concurrency();
-        nt = std::max(1u, std::min({nt, 16u, (unsigned)((n + 7) / 8)}));
+        // (1024 C2 windows on the 256-thread host of an MI355X box: fill 15.5 ms with 16 threads, 6.5 ms with 64, no gain beyond)
+        nt = std::max(1u, std::min({nt, 64u, (unsigned)((n + 7) / 8)}));
         if (const char* e = std::getenv("KBA_PACK_THREADS")) nt = std::max(1, std::atoi(e));
         if (nt == 1) {
             for (int w = 0; w < n; ++w) f(w);

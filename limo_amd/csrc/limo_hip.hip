@@ -858,7 +858,7 @@ struct limo_ba_batch : Executor {
     int32_t* d_coop_bar = nullptr;
     double* d_coop_red = nullptr;
     bool coop_launched = false;
-    int coop_G = 0;
+    int coop_G = 0, coop_xcd = 1;
     int coop_lds_bytes() const {
         const int wave = (std::max(plain_lds_bytes, leangp_lds_bytes) + 15) / 16 * 16;
         return std::max(std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax))), (kBlock / 64) * wave);
@@ -880,7 +880,12 @@ struct limo_ba_batch : Executor {
         // one workgroup per CU, all resident: a batch of up to kCoopMaxWin windows shares the chip with fewer workgroups per
         // window (64 windows: 4 each) - still far ahead of ten launches per iteration over 64 slots
         if (P.n_win > kCoopMaxWg || coop_lds_bytes() > kCamLdsCapBytes) return false;
-        G = std::max(1, std::min(G, kCoopMaxWg / (int)P.n_win));
+        // the workgroups of a window on one XCD (k_solve_coop): the grid is 8 G ceil(n_win / 8), of which n_win G blocks work
+        coop_xcd = 1;
+        if (const char* e = std::getenv("KBA_COOP_XCD")) coop_xcd = std::atoi(e) != 0;  // (read per call: A/B timing)
+        const int per8 = ((int)P.n_win + 7) / 8;
+        if (coop_xcd && 8 * per8 > kCoopMaxWg) coop_xcd = 0;
+        G = std::max(1, std::min(G, coop_xcd ? kCoopMaxWg / (8 * per8) : kCoopMaxWg / (int)P.n_win));
         coop_G = G;
         return true;
     }
@@ -897,6 +902,8 @@ struct limo_ba_batch : Executor {
         h_active[8] = 0;
         CoopParams cp;
         cp.G = coop_G;
+        cp.xcd_map = coop_xcd;
+        const int coop_grid = coop_xcd ? 8 * coop_G * (((int)P.n_win + 7) / 8) : (int)P.n_win * coop_G;
         cp.vp = schur_vp;
         cp.vg = schur_vg;
         cp.schur_lds = (std::max(plain_lds_bytes, leangp_lds_bytes) + 15) / 16 * 16 / (int)sizeof(double);
@@ -912,8 +919,8 @@ struct limo_ba_batch : Executor {
         cp.red = d_coop_red;
         void* args[] = {(void*)&bv, (void*)&c, (void*)&cp};
         static const bool plain_launch = std::getenv("KBA_COOP_PLAIN_LAUNCH") != nullptr;  // (timing aid: no co-residency guarantee)
-        const hipError_t e = plain_launch ? hipLaunchKernel((const void*)k_solve_coop, dim3(P.n_win * coop_G), dim3(kBlock), args, lds, ctx->stream)
-                                          : hipLaunchCooperativeKernel((const void*)k_solve_coop, dim3(P.n_win * coop_G), dim3(kBlock), args, lds, ctx->stream);
+        const hipError_t e = plain_launch ? hipLaunchKernel((const void*)k_solve_coop, dim3(coop_grid), dim3(kBlock), args, lds, ctx->stream)
+                                          : hipLaunchCooperativeKernel((const void*)k_solve_coop, dim3(coop_grid), dim3(kBlock), args, lds, ctx->stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -940,6 +947,9 @@ struct limo_ba_batch : Executor {
         for (size_t gi = 1; gi < groups.size(); ++gi) HIP_TRY(ctx, hipStreamWaitEvent(groups[gi].stream, start_ev, 0));
         const bool time_kernels = groups.size() == 1;  // kernel timing by events is only meaningful without overlap
         constexpr int kLag = 2;
+        // KBA_SCHED_TRACE=1 (profiling aid): windows finished as of every round -> how full the slots are over the solve
+        static const bool sched_trace = std::getenv("KBA_SCHED_TRACE") != nullptr;
+        std::vector<int> done_curve;
         bool finished = false;
         for (int round = 0; !finished; ++round) {
             for (StreamGroup& g : groups) enqueue_round(g, round, time_kernels);
@@ -951,12 +961,22 @@ struct limo_ba_batch : Executor {
                     if (rc != LIMO_OK) break;
                     if (g.h_done[(round - kLag) & 3] < P.n_win) finished = false;
                 }
+                if (sched_trace) done_curve.push_back(groups[0].h_done[(round - kLag) & 3]);
             }
             if (round > 200000) {
                 rc = LIMO_ERR_RUNTIME;
                 ctx->err = "streaming solve did not terminate";
                 break;
             }
+        }
+        if (sched_trace && !done_curve.empty()) {
+            // in flight at round r = min(n_slots, windows not finished); printed as deciles of the round count
+            const int R = (int)done_curve.size();
+            long long occ = 0;
+            std::fprintf(stderr, "[kba] streaming solve: %d windows, %d slots, %d groups, %d rounds; in flight at 0,10,..100 %% of the rounds:", (int)P.n_win, n_slots, (int)groups.size(), R);
+            for (int r = 0; r < R; ++r) occ += std::min(n_slots, (int)P.n_win - done_curve[r]);
+            for (int d = 0; d <= 10; ++d) std::fprintf(stderr, " %d", std::min(n_slots, (int)P.n_win - done_curve[std::min(R - 1, d * R / 10)]));
+            std::fprintf(stderr, "; mean occupancy %.3f\n", (double)occ / ((double)R * n_slots));
         }
         for (StreamGroup& g : groups) {  // everything joins the context's stream again
             note(hipStreamWaitEvent(g.stream, g.trim_ev, 0), "wait trim");
