@@ -87,6 +87,10 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // false when in.live) contributes zeros through a final mask - on the GPU the four passes of a lane are then one
 // straight-line stream and the compiler can keep the loads of the next pass in flight across the stores of this one
 // (with divergent branches around them it drained the memory queue every pass).
+// CAM = false: the view's keyframe has no free pose block (WinDesc::n_view_fixed0): its camera-side sums would be masked out of
+// the camera system anyway, so the pose Jacobian and U / g are not formed (a third of the arithmetic of a pair).  The cost, the
+// residual and the planes are the same statements either way.
+template <bool CAM = true>
 KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4,
                     LinLane& out) {
     const double* H = vl;
@@ -131,6 +135,7 @@ KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, boo
     c4[1] = ok ? xn : 0.0;
     c4[2] = ok ? yn : 0.0;
     c4[3] = sd;
+    if (!CAM) return z_ok || in.live == 0;
     double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft]
     for (int j = 0; j < 3; ++j) {
         J[3 + j] = au * (Rc[0 + j] - xn * Rc[6 + j]);
@@ -235,7 +240,11 @@ KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl,
         lin_fetch(bv, s, gl, in);
         const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);
         double r3[3], c4[4];
-        if (!lin_obs(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
+        if (j < wd.n_view_fixed0) {  // keyframe without a free pose block: cost, residual and planes only
+            if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
+        } else {
+            if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
+        }
         for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + s] = c4[i];  // (the residual stays in the lane: nobody reads it back)
         lin_lm_accum(vl, r3, c4, acc);
     }
@@ -497,14 +506,17 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
     const int n_view = wd.n_view;
     if (state == 1) {
         double a[3] = {0, 0, 0};
-        int s_cur = slot[0];
-        int s_nxt = n_view > 1 ? slot[bv.SL] : -1;
+        // (the leading views of keyframes without a free pose block have delta_c = 0 and dR = 0: their terms of `a` are exact
+        // zeros - the loop starts behind them and their planes are never loaded)
+        const int j0 = wd.n_view_fixed0;
+        int s_cur = j0 < n_view ? slot[(int64_t)j0 * bv.SL] : -1;
+        int s_nxt = j0 + 1 < n_view ? slot[(int64_t)(j0 + 1) * bv.SL] : -1;
         double c4n[4];
         {
             const int64_t o = s_cur >= 0 ? s_cur : 0;
             for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
         }
-        for (int j = 0; j < n_view; ++j) {
+        for (int j = j0; j < n_view; ++j) {
             const bool have = s_cur >= 0;
             double c4[4];
             for (int i = 0; i < 4; ++i) c4[i] = have ? c4n[i] : 0.0;

@@ -98,6 +98,15 @@ __device__ __forceinline__ double halve_dpp(double a, double b, bool bit) {
     const double keep = bit ? b : a, send = bit ? a : b;
     return keep + dpp_mov(send, CTRL);
 }
+// one value summed over the wave with the same exchanges (every lane ends with the total): 6 exchange-adds, no LDS
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = swap32_add(v, v);
+    v = swap16_add(v, v);
+    v += dpp_mov(v, 0);
+    v += dpp_mov(v, 1);
+    v += dpp_mov(v, 2);
+    return v + dpp_mov(v, 3);
+}
 // Index of the value whose wave total lane `lane` holds after wave_reduce_scatter28 (even lanes; -1: duplicate).
 __device__ __forceinline__ int rs28_index(int lane) {
     const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1, b1 = (lane >> 1) & 1;
@@ -398,7 +407,44 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         d_n = bv.obs_d[o];
     }
     const int rs_idx = rs28_index(lane);
-    for (int j = 0; j < n_view; ++j) {
+    // ---- the leading views of keyframes WITHOUT a free pose block (WinDesc::n_view_fixed0: the Pose-fixed oldest keyframe of
+    //      a sliding window): same pipeline, same planes, same landmark-block terms, but no pose Jacobian, no U / g, and only the
+    //      cost leaves the wave (the slice's other 27 entries are zeros).  A loop of its own: the general loop below stays one
+    //      straight-line body (a uniform branch inside it cost more than the skipped third of the arithmetic gave back).
+    const int j_cam0 = wd.n_view_fixed0;
+    for (int j = 0; j < j_cam0; ++j) {
+        double vl[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) vl[i] = vc[(int64_t)j * kViewLin + i];
+        const int s = s_cur;
+        in.u = u_n;
+        in.v = v_n;
+        in.d = d_n;
+        s_cur = s_nxt;
+        s_nxt = j + 2 < n_view ? slot[(int64_t)(j + 2) * bv.SL] : -1;
+        {
+            const int64_t o = s_cur >= 0 ? s_cur : 0;
+            u_n = bv.obs_u[o];
+            v_n = bv.obs_v[o];
+            d_n = bv.obs_d[o];
+        }
+        const bool have = state != 0 && s >= 0;
+        in.live = have;
+        LinLane l;
+        l.cost = 0.0;
+        l.fail = 0;
+        double r3[3], c4[4];
+        if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
+        {
+            const int64_t o = have ? s : dump;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
+        }
+        lin_lm_accum(vl, r3, c4, acc);
+        const double tot = wave_sum_all(l.cost);
+        if (lane < kLinPartial) lv_lds[(j * kLinWaves + wave) * kLinPartial + lane] = lane == 0 ? tot : 0.0;
+    }
+    for (int j = j_cam0; j < n_view; ++j) {
         double vl[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) vl[i] = vc[(int64_t)j * kViewLin + i];
@@ -424,7 +470,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 #pragma unroll
         for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
         double r3[3], c4[4];
-        if (!lin_obs(vl, c, in, want_cost, r3, c4, l)) fail = 1;
+        if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
         {   // the four scalars of the factored Jacobian are what the Schur / back-substitution kernels read; the residual
             // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
             // (limo_ba_evaluate has its own kernel), so it is not stored: 32 instead of 56 B written per pair

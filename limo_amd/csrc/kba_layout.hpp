@@ -63,6 +63,10 @@ struct WinDesc {
     int32_t n_depth, n_repr;  // residual blocks built
     int32_t do_trim;          // n_lm > min_landmarks_for_trimming
     int32_t pose_only;        // adjustPoseOnly problem (landmarks constant)
+    int32_t n_view_fixed0;    // the window's first n_view_fixed0 views belong to keyframes WITHOUT a free pose block (the Pose-fixed
+                              // oldest keyframe of a sliding window): k_lin_lm forms no camera-side sums for them, k_backsub no
+                              // camera-step term - their own short loops in front of the general ones (view order unchanged)
+    int32_t pad_view;
     double scale_w, scale_s0; // PoseRegularization weight and target
     double speed_w, speed_dt, speed_vel[3], speed_Rb[9], speed_tb[3];  // SpeedRegularizationVector2 (pose-only)
     int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer

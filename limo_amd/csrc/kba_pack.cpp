@@ -474,6 +474,9 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             }
         }
         if (d.n_fk > 4) d.schur_fast = 0;
+        d.n_view_fixed0 = 0;  // leading views whose keyframe has no free pose block
+        while (d.n_view_fixed0 < d.n_view && !freem[views[w][d.n_view_fixed0].kf * kCamSlots]) d.n_view_fixed0++;
+        if (po.evaluate_only) d.n_view_fixed0 = 0;
         };
     for_windows(pack_one);
     const auto t_p2 = std::chrono::steady_clock::now();
