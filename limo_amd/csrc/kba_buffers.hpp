@@ -107,69 +107,104 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(trim_rep, TL * D, nullptr);
     KBA_BUF(trim_dep, TL * D, nullptr);
     KBA_BUF(n_active, 8 * I, nullptr);
+    if (P.n_shards > 1) {  // landmark-sharded batches: who owns a landmark workgroup / a ground-plane row (shard_reduce_*)
+        KBA_BUF(lblk_owner, NL * I, P.lblk_owner.data());
+        KBA_BUF(gp_owner, TG * I, P.gp_owner.data());
+    }
 #undef KBA_BUF
 }
 
-// Per-workgroup partial arrays that cross from the landmark-side kernels (owned by ONE shard of a landmark-sharded
-// solve) to the window-level kernels (replicated on every shard): the exchange set of SURVEY §8e.
+// Landmark-sharded solve: what crosses from the landmark-side kernels (owned by ONE shard) to the window-level
+// kernels (replicated on every shard).
 //
-// A sharded solve keeps them in ONE contiguous arena of doubles per view (the consumer view and every local shard), laid
-// out so that each exchange point is ONE contiguous range: one k_sum_shards launch + one all-reduce per point, three per
-// LM iteration (before k_cam_assemble / k_cam_solve / k_step_decide) and one per trimming round:
-//   [ lv_part | lblk_linfail | gp_r | gp_F | gp_cost | gp_cost_c | lblk_part | S_red ]   [ trim_rep | trim_dep ]
-//     point 1 ------------------------------------------------------------>|
-//     point 4                                          |<-------------------|
-//     point 2                                                      |<-------------->|          point 8 (own range)
-// (gp_cost_c rides along at point 1: its values there are the previous iteration's, nobody reads them before point 4
-// rewrites them).  Every entry has exactly one owner and is zero elsewhere, so the sums are exact in any order.
-// S_part (the per-workgroup Schur slabs) is private to a shard and never exchanged: k_slab_reduce folds it into S_red.
-struct ExchangeLayout {
-    struct Slot {
-        size_t member;  // offset of the pointer inside BatchView
-        size_t off, count;  // doubles inside the arena
-    };
-    std::vector<Slot> slots;
-    size_t total = 0;                    // doubles per arena
-    size_t off[4] = {0, 0, 0, 0};        // range of exchange point 1, 2, 4, 8 (index = log2 of the point)
-    size_t count[4] = {0, 0, 0, 0};
-    size_t spart_count = 1;              // doubles of the private S_part
-};
+// A shard folds its per-workgroup partial arrays into ONE contiguous block of doubles (kba_items.hpp:shard_reduce_lin / _step,
+// slab_reduce_entry) - camera-side sums per view, ground-plane rows as F^T F | F^T r per keyframe, the landmark-side scalars,
+// and the entries of [S | rhs] the camera solve reads (upper triangle + rhs):
+//     block = [ x_lv | x_lf | x_gp | x_gc | x_gcc | x_lb | S ]
+//               point A1 (first linearisation of a solve: the camera assembly defines the Jacobi scale the Schur
+//               |<------------------------------------>|    complement needs)            point A2 |<->|
+//               point A  = the whole block: every other iteration, ONE exchange before camera assembly + camera solve
+//               point B                    |<--------->|    before the step decision (9 doubles per window)
+// An exchange is an ALL-GATHER of the blocks (one per shard, 41 KB at a 10-keyframe / 8000-landmark window) followed by
+// unpack_entry: the consumer view holds the P contributions side by side, in shard order, behind the ordinary members
+// (lv_part, lblk_linfail, gp_cost, gp_cost_c, lblk_part, S_red) and gp_red, with a WinDesc that says "P workgroups, P rows" -
+// cam_assemble / cam_solve / reduce_step add them in shard order.  Nothing is summed on the wire, so the result does not
+// depend on how the P shards are spread over ranks (P virtual shards on one GPU = P ranks, bit for bit).
+// The trimming step exchanges the per-landmark residual maxima (one owner per entry, zero elsewhere: an exact sum) once per
+// trimming round.  S_part (the per-workgroup Schur slabs) is private to a shard and never exchanged.
+// (struct ExchangeLayout: kba_layout.hpp - the kernels that unpack an exchange read it too)
 inline ExchangeLayout exchange_layout(const PackedBatch& P) {
-    const size_t NL = (size_t)std::max(1, P.n_lblk), TG = (size_t)std::max(1, P.TG), TL = (size_t)std::max(1, P.TL);
     ExchangeLayout L;
-    auto add = [&](size_t member, size_t count) {
-        const size_t o = L.total;
-        L.slots.push_back({member, o, count});
-        L.total += (count + 31) / 32 * 32;  // 256-byte steps; the padding stays zero in every view
-        return o;
-    };
-    const size_t o_lv = add(offsetof(BatchView, lv_part), (size_t)std::max<int64_t>(1, P.lvpart_total));
-    add(offsetof(BatchView, lblk_linfail), NL);
-    add(offsetof(BatchView, gp_r), (size_t)P.SG);
-    add(offsetof(BatchView, gp_F), (size_t)P.SG * 10);
-    add(offsetof(BatchView, gp_cost), TG);
-    const size_t o_gcc = add(offsetof(BatchView, gp_cost_c), TG);
-    const size_t o_lp = add(offsetof(BatchView, lblk_part), NL * 8);
-    const size_t e_lp = L.total;
-    add(offsetof(BatchView, S_red), (size_t)std::max<int64_t>(1, P.sred_total));
-    const size_t e_sred = L.total;
-    const size_t o_trim = add(offsetof(BatchView, trim_rep), TL);
-    add(offsetof(BatchView, trim_dep), TL);
-    L.off[0] = o_lv;
-    L.count[0] = e_lp - o_lv;
-    L.off[1] = o_lp;
-    L.count[1] = e_sred - o_lp;
-    L.off[2] = o_gcc;
-    L.count[2] = e_lp - o_gcc;
-    L.off[3] = o_trim;
-    L.count[3] = L.total - o_trim;
+    auto pad = [](size_t n) { return (n + 31) / 32 * 32; };  // 256-byte steps
+    L.P = P.n_shards;
+    L.n_win = P.n_win;
+    L.TK = P.TK;
+    L.n_lv = pad((size_t)std::max<int64_t>(1, P.xlv_total));
+    L.n_w = pad((size_t)std::max(1, P.n_win));
+    L.n_gp = pad((size_t)std::max(1, P.TK) * kGpRed);
+    L.n_lb = pad((size_t)std::max(1, P.n_win) * 8);
+    L.n_S = pad((size_t)std::max<int64_t>(1, P.sred_total / std::max(1, P.n_shards)));
+    size_t o = 0;
+    L.b_lv = o, o += L.n_lv;
+    L.b_lf = o, o += L.n_w;
+    L.b_gp = o, o += L.n_gp;
+    L.b_gc = o, o += L.n_w;
+    L.b_gcc = o, o += L.n_w;
+    L.b_lb = o, o += L.n_lb;
+    L.b_S = o, o += L.n_S;
+    L.b_total = o;
+    const size_t Pn = (size_t)L.P;
+    o = 0;
+    L.c_lv = o, o += Pn * L.n_lv;
+    L.c_lf = o, o += Pn * L.n_w;
+    L.c_gp = o, o += Pn * L.n_gp;
+    L.c_gc = o, o += Pn * L.n_w;
+    L.c_gcc = o, o += Pn * L.n_w;
+    L.c_lb = o, o += Pn * L.n_lb;
+    L.c_S = o, o += Pn * L.n_S;
+    L.c_total = o;
+    L.trim_count = 2 * (size_t)std::max(1, P.TL);
     L.spart_count = (size_t)std::max<int64_t>(1, P.spart_total);
     return L;
 }
-inline int exchange_index(int point) { return point == 1 ? 0 : point == 2 ? 1 : point == 4 ? 2 : 3; }
-// point `view` at the slices of `arena`
-inline void exchange_bind(const ExchangeLayout& L, BatchView& view, double* arena) {
-    for (const ExchangeLayout::Slot& sl : L.slots) *reinterpret_cast<double**>(reinterpret_cast<char*>(&view) + sl.member) = arena + sl.off;
+// producer view of one shard: x_* and S_red point into the shard's block, trim_rep / trim_dep into its trimming arena
+inline void exchange_bind_producer(const ExchangeLayout& L, BatchView& v, double* block, double* trim) {
+    v.x_lv = block + L.b_lv;
+    v.x_lf = block + L.b_lf;
+    v.x_gp = block + L.b_gp;
+    v.x_gc = block + L.b_gc;
+    v.x_gcc = block + L.b_gcc;
+    v.x_lb = block + L.b_lb;
+    v.S_red = block + L.b_S;
+    v.trim_rep = trim;
+    v.trim_dep = trim + L.trim_count / 2;
+}
+// consumer view: the P contributions behind the ordinary members; `win_c` = the windows' descriptors with the consumer's
+// lblk0 / n_lblk / lvpart_off / gp0 / n_gp (exchange_consumer_windows)
+inline void exchange_bind_consumer(const ExchangeLayout& L, BatchView& v, double* arena, double* trim, const WinDesc* win_c) {
+    v.lv_part = arena + L.c_lv;
+    v.lblk_linfail = arena + L.c_lf;
+    v.gp_red = arena + L.c_gp;
+    v.gp_red_P = L.P;
+    v.gp_cost = arena + L.c_gc;
+    v.gp_cost_c = arena + L.c_gcc;
+    v.lblk_part = arena + L.c_lb;
+    v.S_red = arena + L.c_S;
+    v.trim_rep = trim;
+    v.trim_dep = trim + L.trim_count / 2;
+    v.win = win_c;
+}
+inline std::vector<WinDesc> exchange_consumer_windows(const PackedBatch& P) {
+    std::vector<WinDesc> out(P.win.begin(), P.win.end());
+    for (int w = 0; w < P.n_win; ++w) {
+        WinDesc& d = out[w];
+        d.lblk0 = w * P.n_shards;
+        d.n_lblk = P.n_shards;
+        d.lvpart_off = (int64_t)P.n_shards * d.xlv_off;
+        d.gp0 = w * P.n_shards;
+        d.n_gp = d.n_gp > 0 ? P.n_shards : 0;
+    }
+    return out;
 }
 
 }  // namespace kba

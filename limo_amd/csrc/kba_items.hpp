@@ -462,18 +462,37 @@ KBA_HD int schur_group_last(const WinDesc& wd, int sb, int span, int span_gp) {
     return wd.sblk0 + (i + sp < end ? i + sp : end) - 1;
 }
 
-// Landmark-sharded solve: entry e of slab `shard` of S_red = sum over ALL partial slabs of the window in this shard's
-// private S_part (slabs of other shards' workgroups are never written there and stay zero).
-KBA_HD void slab_reduce_entry(const BatchView& bv, int w, int shard, int e) {
+// The entries of [S | rhs] the camera solve reads: upper triangle of the nf free slots + the rhs, enumerated row by row
+// (row ca: cb = ca .. nf, cb == nf is the rhs).  Entry i of that enumeration -> (ca, cb); its place in a full nfp x nfp slab.
+KBA_HD int schur_need_count(int nf) { return nf * (nf + 1) / 2 + nf; }
+KBA_HD int schur_need_pad(int nf) { return (schur_need_count(nf) + 31) / 32 * 32; }
+KBA_HD void schur_need_decode(int i, int nf, int& ca, int& cb) {
+    const int lda = nf + 1;  // row ca starts at ca * lda - ca (ca - 1) / 2
+    ca = (int)(((2 * lda + 1) - sqrt((double)((2 * lda + 1) * (2 * lda + 1) - 8 * i))) * 0.5);
+    while (ca > 0 && ca * lda - ca * (ca - 1) / 2 > i) --ca;
+    while ((ca + 1) * lda - (ca + 1) * ca / 2 <= i) ++ca;
+    cb = ca + (i - (ca * lda - ca * (ca - 1) / 2));
+}
+KBA_HD int schur_col(int i, int nfq);
+KBA_HD int64_t schur_need_offset(int ca, int cb, int nf, int nfq, int nfp) {
+    if (cb < nf) return (int64_t)schur_col(ca, nfq) * nfp + schur_col(cb, nfq);
+    const int za = schur_col(ca, nfq);  // upper-triangle entry (za, nfq) or (nfq, za)
+    return za < nfq ? (int64_t)za * nfp + nfq : (int64_t)nfq * nfp + za;
+}
+// Landmark-sharded solve: entry i (of the enumeration above) of the shard's contribution = sum over ALL partial slabs of the
+// window in this shard's private S_part (slabs of other shards' workgroups are never written there and stay zero), in slab
+// order.  bv.S_red of a producer view is the S part of the shard's own block (exchange_layout).
+KBA_HD void slab_reduce_entry(const BatchView& bv, int w, int n_shards, int i) {
     const WinDesc& wd = bv.win[w];
     const int64_t slab = (int64_t)wd.nf_pad * wd.nf_pad;
-    const double* sp = bv.S_part + wd.spart_off + e;
+    int ca, cb;
+    schur_need_decode(i, wd.nf, ca, cb);
+    const double* sp = bv.S_part + wd.spart_off + schur_need_offset(ca, cb, wd.nf, wd.nfq, wd.nf_pad);
     double a = 0.0;
     for (int q = 0; q < wd.n_sblk; ++q) a += sp[q * slab];
-    bv.S_red[wd.sred_off + shard * slab + e] = a;
+    bv.S_red[wd.sred_off / n_shards + i] = a;
 }
 
-// column of compact slot i in the Schur tile / slab (the rhs sits at column nfq)
 KBA_HD int schur_col(int i, int nfq) {
     return i + (i >= nfq ? 1 : 0);
 }
@@ -974,7 +993,7 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
             gps[(i % ng) * 12 + q] = v;
         }
     };
-    if (wd.n_gp > 0) gp_stage(wd.gp0);
+    if (wd.n_gp > 0 && !bv.gp_red) gp_stage(wd.gp0);
     KBA_SYNC();
     // (1) observations: U_k (6x6) and g_k per keyframe = sum of the camera-side partial sums of its views over the
     //     window's landmark workgroups and their waves (k_lin_lm); one lane per (keyframe, entry): single writer, fixed order.
@@ -1013,7 +1032,24 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     if (c.pad == 41) return;  // (41-44: profiling aids, early exits after the phases)
     // (2) ground-plane rows: F^T F on the 10x10 block of their keyframe: one lane per (keyframe, entry) adds the staged
     //     rows of ITS keyframe in row order.
-    for (int g0 = wd.gp0; g0 < wd.gp0 + wd.n_gp; g0 += kGpChunk) {
+    if (bv.gp_red) {
+        // landmark-sharded solve: every shard has folded ITS rows into F^T F | F^T r per keyframe (shard_reduce_lin); here the
+        // P contributions are added in shard order (wd.gp0 / n_gp of the consumer view describe "one row per shard")
+        for (int e = tid; e < wd.n_kf * 110; e += nt) {
+            const int kl = e / 110, q = e % 110;
+            const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : 10;
+            const int lo = bb == 10 ? a : (a < bb ? a : bb), hi = bb == 10 ? 10 : (a < bb ? bb : a);
+            const int idx = hi == 10 ? 55 + lo : lo * 10 - lo * (lo - 1) / 2 + (hi - lo);
+            double acc = 0.0;
+            for (int sh = 0; sh < bv.gp_red_P; ++sh) acc += bv.gp_red[((int64_t)sh * bv.TK + wd.kf0 + kl) * kGpRed + idx];
+            if (bb < 10)
+                H[(kl * kCamSlots + a) * nc + kl * kCamSlots + bb] += acc;
+            else
+                gc[kl * kCamSlots + a] += acc;
+        }
+        KBA_SYNC();
+    }
+    for (int g0 = wd.gp0; !bv.gp_red && g0 < wd.gp0 + wd.n_gp; g0 += kGpChunk) {
         const int ng = (wd.gp0 + wd.n_gp - g0) < kGpChunk ? (wd.gp0 + wd.n_gp - g0) : kGpChunk;
         if (g0 != wd.gp0) {  // (the first chunk is in LDS already)
             gp_stage(g0);
@@ -1197,7 +1233,7 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     const int32_t* cs = bv.cslot + wd.cam0;
     double* yc = bv.yc + wd.cam0;
     double* dc = bv.delta_c + wd.cam0;
-    const int slab = nfp * nfp;
+    const int slab = c.schur_packed ? schur_need_pad(nf) : nfp * nfp;
     const int nfq = wd.nfq;
     KBA_TICK(8);
     for (int a = tid; a < nc; a += nt)
@@ -1223,23 +1259,19 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             s[e] = 0.0;
             for (int r = 0; r < 4; ++r) acc[e][r] = 0.0;
             if (i >= n_need) continue;
-            // row ca starts at ca * lda - ca (ca - 1) / 2
-            int ca = (int)(((2 * lda + 1) - sqrt((double)((2 * lda + 1) * (2 * lda + 1) - 8 * i))) * 0.5);
-            while (ca > 0 && ca * lda - ca * (ca - 1) / 2 > i) --ca;
-            while ((ca + 1) * lda - (ca + 1) * ca / 2 <= i) ++ca;
-            const int cb = ca + (i - (ca * lda - ca * (ca - 1) / 2));
+            int ca, cb;
+            schur_need_decode(i, nf, ca, cb);
             const int a = fl[ca];
             if (cb < nf) {
                 const int b = fl[cb];
                 double v = sc[a] * sc[b] * Hg[a * nc + b];
                 if (ca == cb) v += fmin(fmax(v, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
                 s[e] = v;
-                off[e] = (int64_t)schur_col(ca, nfq) * nfp + schur_col(cb, nfq);
             } else {
                 s[e] = sc[a] * bv.gc[wd.cam0 + a];
-                const int za = schur_col(ca, nfq);  // upper-triangle entry (za, nfq) or (nfq, za)
-                off[e] = za < nfq ? (int64_t)za * nfp + nfq : (int64_t)nfq * nfp + za;
             }
+            // (packed slabs of a sharded solve hold exactly these entries in this order)
+            off[e] = c.schur_packed ? (int64_t)i : schur_need_offset(ca, cb, nf, nfq, nfp);
             dst[e] = ca * lda + cb;
         }
         int q = 0;
@@ -1497,6 +1529,125 @@ KBA_HD void reduce_step(const BatchView& bv, int w, int tid, int nt, double* red
         r.cand_fail = cfail != 0.0;
     }
 }
+
+// ======================================================================================= landmark sharding: a shard's contribution
+// What shard `shard` of P puts into an exchange, folded over ITS landmark workgroups / ground-plane rows in their order
+// (BatchView::x_*; the consumer adds the P contributions in shard order).  One workgroup (nt lanes) per window.
+//   after the linearisation (before cam_assemble):  x_lv, x_lf, x_gp, x_gc, x_lb[0, 1, 5]
+KBA_HD void shard_reduce_lin(const BatchView& bv, int w, int shard, int tid, int nt) {
+    const WinDesc& wd = bv.win[w];
+    const int n_e = wd.n_view * kLinPartial;
+    for (int e = tid; e < n_e; e += nt) {
+        double acc = 0.0;
+        for (int b = 0; b < wd.n_lblk; ++b)
+            if (bv.lblk_owner[wd.lblk0 + b] == shard) acc += bv.lv_part[wd.lvpart_off + (int64_t)b * n_e + e];
+        bv.x_lv[wd.xlv_off + e] = acc;
+    }
+    for (int e = tid; e < wd.n_kf * kGpRed; e += nt) {
+        const int kl = e / kGpRed, idx = e % kGpRed;
+        int a, bb;  // idx -> (a <= bb) of the 10 x 10 upper triangle, or (a, rhs)
+        if (idx >= 55) {
+            a = idx - 55;
+            bb = 10;
+        } else {
+            a = 0;
+            int rem = idx;
+            while (rem >= 10 - a) {
+                rem -= 10 - a;
+                ++a;
+            }
+            bb = a + rem;
+        }
+        const int g0 = bv.kf_gp0[wd.kf0 + kl], g1 = g0 + bv.kf_ngp[wd.kf0 + kl];  // rows are sorted by keyframe
+        double acc = 0.0;
+        for (int g = g0; g < g1; ++g)
+            if (bv.gp_owner[g] == shard) acc += bv.gp_F[a * bv.SG + g] * (bb < 10 ? bv.gp_F[bb * bv.SG + g] : bv.gp_r[g]);
+        bv.x_gp[(int64_t)(wd.kf0 + kl) * kGpRed + idx] = acc;
+    }
+    if (tid == 0) {
+        double gmax = 0.0, xn2 = 0.0, lf = 0.0, df = 0.0, gc = 0.0;
+        for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
+            if (bv.lblk_owner[b] != shard) continue;
+            gmax = fmax(gmax, bv.lblk_part[(int64_t)b * 8 + 0]);
+            xn2 += bv.lblk_part[(int64_t)b * 8 + 1];
+            if (bv.lblk_part[(int64_t)b * 8 + 5] != 0.0) df = 1.0;
+            if (bv.lblk_linfail[b] != 0.0) lf = 1.0;
+        }
+        for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g)
+            if (bv.gp_owner[g] == shard) gc += bv.gp_cost[g];
+        bv.x_lb[(int64_t)w * 8 + 0] = gmax;
+        bv.x_lb[(int64_t)w * 8 + 1] = xn2;
+        bv.x_lb[(int64_t)w * 8 + 5] = df;
+        bv.x_lf[w] = lf;
+        bv.x_gc[w] = gc;
+    }
+}
+// One double of a shard's block -> its place among the P contributions of the consumer view (after the all-gather of an
+// exchange).  e = index inside the block; `cw` = the ORIGINAL window descriptors (offsets xlv_off / sred_off).
+// `range` = the doubles of the block from offset `base` on (what an exchange of a sub-range of the block moved).
+KBA_HD void unpack_entry(const ExchangeLayout& L, const WinDesc* cw, const double* range, size_t base, double* arena, int shard, size_t e) {
+    const double v = range[e - base];
+    const size_t P = (size_t)L.P, s = (size_t)shard;
+    if (e < L.b_lf) {  // x_lv: window w holds [xlv_off, xlv_off + n_view * 28)
+        const size_t k = e - L.b_lv;
+        int w = 0;
+        while (w + 1 < L.n_win && (size_t)cw[w + 1].xlv_off <= k) ++w;
+        const size_t n = (size_t)cw[w].n_view * kLinPartial, in = k - (size_t)cw[w].xlv_off;
+        if (in < n) arena[L.c_lv + P * (size_t)cw[w].xlv_off + s * n + in] = v;
+    } else if (e < L.b_gp) {
+        const size_t w = e - L.b_lf;
+        if (w < (size_t)L.n_win) arena[L.c_lf + w * P + s] = v;
+    } else if (e < L.b_gc) {
+        const size_t k = e - L.b_gp;
+        if (k < (size_t)L.TK * kGpRed) arena[L.c_gp + s * (size_t)L.TK * kGpRed + k] = v;
+    } else if (e < L.b_gcc) {
+        const size_t w = e - L.b_gc;
+        if (w < (size_t)L.n_win) arena[L.c_gc + w * P + s] = v;
+    } else if (e < L.b_lb) {
+        const size_t w = e - L.b_gcc;
+        if (w < (size_t)L.n_win) arena[L.c_gcc + w * P + s] = v;
+    } else if (e < L.b_S) {
+        const size_t k = e - L.b_lb, w = k / 8;
+        if (w < (size_t)L.n_win) arena[L.c_lb + (w * P + s) * 8 + k % 8] = v;
+    } else {
+        const size_t k = e - L.b_S;
+        int w = 0;
+        while (w + 1 < L.n_win && (size_t)cw[w + 1].sred_off / P <= k) ++w;
+        const size_t n = (size_t)schur_need_pad(cw[w].nf), in = k - (size_t)cw[w].sred_off / P;
+        if (in < n) arena[L.c_S + (size_t)cw[w].sred_off + s * n + in] = v;
+    }
+}
+//   after a rejected step's damping (lm_damp_lane sets the failure flag again)
+KBA_HD void shard_reduce_damp(const BatchView& bv, int w, int shard) {
+    const WinDesc& wd = bv.win[w];
+    double df = 0.0;
+    for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b)
+        if (bv.lblk_owner[b] == shard && bv.lblk_part[(int64_t)b * 8 + 5] != 0.0) df = 1.0;
+    bv.x_lb[(int64_t)w * 8 + 5] = df;
+}
+//   after the back-substitution (before the step decision):  x_lb[2, 3, 4, 6, 7], x_gcc
+KBA_HD void shard_reduce_step(const BatchView& bv, int w, int shard) {
+    const WinDesc& wd = bv.win[w];
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = wd.lblk0; b < wd.lblk0 + wd.n_lblk; ++b) {
+        if (bv.lblk_owner[b] != shard) continue;
+        v[2] += bv.lblk_part[(int64_t)b * 8 + 2];
+        v[3] += bv.lblk_part[(int64_t)b * 8 + 3];
+        v[4] += bv.lblk_part[(int64_t)b * 8 + 4];
+        v[6] += bv.lblk_part[(int64_t)b * 8 + 6];
+        if (bv.lblk_part[(int64_t)b * 8 + 7] != 0.0) v[7] = 1.0;
+    }
+    double gcc = 0.0;
+    for (int g = wd.gp0; g < wd.gp0 + wd.n_gp; ++g)
+        if (bv.gp_owner[g] == shard) gcc += bv.gp_cost_c[g];
+    bv.x_lb[(int64_t)w * 8 + 2] = v[2];
+    bv.x_lb[(int64_t)w * 8 + 3] = v[3];
+    bv.x_lb[(int64_t)w * 8 + 4] = v[4];
+    bv.x_lb[(int64_t)w * 8 + 6] = v[6];
+    bv.x_lb[(int64_t)w * 8 + 7] = v[7];
+    bv.x_gcc[w] = gcc;
+}
+
 
 // ======================================================================================= trimming
 // Per landmark: max over its observations of the un-robustified block norms (getMaximumResidual,

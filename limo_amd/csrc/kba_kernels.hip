@@ -1835,13 +1835,39 @@ __global__ void k_sum_shards(T* dst, ShardPtrs src, int n_shards, int64_t n) {
     dst[i] = acc;
 }
 
-// One slab per (window, shard) before the exchange: 74 KB instead of 9 MB on the wire for a C4 window.
-__global__ __launch_bounds__(kBlock) void k_slab_reduce(BatchView bv, const int32_t* wl, int shard) {
+// A shard's contribution to [S | rhs] before the exchange: the entries the camera solve reads (upper triangle + rhs),
+// summed over the shard's partial slabs - 33 KB on the wire for a C4 window instead of 9 MB of slabs.
+__global__ __launch_bounds__(kBlock) void k_slab_reduce(BatchView bv, const int32_t* wl, int n_shards) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     if (!bv.st[w].active) return;
-    const int n = bv.win[w].nf_pad * bv.win[w].nf_pad;
-    for (int e = blockIdx.y * kBlock + threadIdx.x; e < n; e += gridDim.y * kBlock) slab_reduce_entry(bv, w, shard, e);
+    const int n = schur_need_count(bv.win[w].nf);
+    for (int e = blockIdx.y * kBlock + threadIdx.x; e < n; e += gridDim.y * kBlock) slab_reduce_entry(bv, w, n_shards, e);
+}
+
+// The rest of a shard's block (kba_items.hpp:shard_reduce_*): phase 0 after the linearisation, 1 after a rejected step's
+// damping, 2 after the back-substitution.  One workgroup per listed window.
+__global__ __launch_bounds__(kBlock) void k_shard_reduce(BatchView bv, const int32_t* wl, int shard, int phase) {
+    const int w = wl_at(bv, wl, blockIdx.x);
+    if (w < 0) return;
+    const WinState& st = bv.st[w];
+    if (!st.active) return;
+    if (phase == 0) {
+        if (st.need_lin) shard_reduce_lin(bv, w, shard, threadIdx.x, kBlock);
+    } else if (threadIdx.x == 0) {
+        if (phase == 1) {
+            if (st.redamp) shard_reduce_damp(bv, w, shard);
+        } else {
+            shard_reduce_step(bv, w, shard);
+        }
+    }
+}
+
+// After the all-gather of an exchange: the doubles [off, off + count) of shard `shard`'s block go to their places among the
+// P contributions of the consumer view (kba_items.hpp:unpack_entry).  `win` = the batch's original window descriptors.
+__global__ void k_unpack(ExchangeLayout L, const WinDesc* win, const double* range, double* arena, int shard, int64_t off, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) unpack_entry(L, win, range, (size_t)off, arena, shard, (size_t)(off + i));
 }
 
 // out = landmark positions of the landmarks this shard owns, zero elsewhere (input of the final all-reduce that

@@ -11,6 +11,7 @@
 //   * residuals/Jacobians are materialised as planes  plane[c][obs]  (8-byte coalesced stores/loads).
 // The reduced camera system of a window has 10 slots per keyframe: [rot 3 | trans 3 | plane normal 3 | plane dist 1].
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/limo_hip.h"
@@ -33,6 +34,7 @@ constexpr int kSchurLmPerBlock = 64;   // landmarks per Schur block; a wave take
 constexpr int kMaxRegRows = 1 + (kMaxKf - 1) * 5 + 3 * kMaxKf;  // scale + per pair (3+1+1) + global normal 3/kf
 
 // number of doubles in a block partial of the linearize kernel: cost, 21 (U upper) + 6 (g)
+constexpr int kGpRed = 65;  // per keyframe: upper triangle of F^T F (10 x 10: 55) + F^T r (10) of ground-plane rows (BatchView::x_gp)
 constexpr int kLinPartial = 28;
 constexpr int kLinWaves = 4;      // waves of a landmark workgroup: each keeps its own camera-side partial sums (no barrier per view)
 
@@ -71,7 +73,10 @@ struct WinDesc {
     double speed_w, speed_dt, speed_vel[3], speed_Rb[9], speed_tb[3];  // SpeedRegularizationVector2 (pose-only)
     int64_t hcc_off;          // offset (doubles) of this window's nc x nc matrix in the Hcc buffer
     int64_t spart_off;        // offset of this window's Schur partial slabs
-    int64_t sred_off;         // offset of this window's per-shard slabs (n_shards x nf_pad^2) in S_red
+    int64_t sred_off;         // offset of this window's per-shard contributions in the consumer's S_red: n_shards x schur_need_pad(nf)
+                              // (a shard's own block holds one of them at sred_off / n_shards)
+    int64_t xlv_off;          // offset of this window's [view][kLinPartial] sums inside a shard's x_lv (the consumer's lv_part holds P
+                              // of them at P * xlv_off)
     int64_t lvpart_off;       // offset of this window's camera-side partial sums in BatchView::lv_part:
                               // [landmark workgroup of the window][view][kLinPartial]
     int64_t cam_scr_off;      // >= 0: the window's camera system does not fit into LDS (more than ~12 keyframes): offset of its
@@ -129,7 +134,10 @@ struct SolveConsts {  // subset of limo_ba_options the kernels need
     int32_t schur_span;   // plain Schur blocks per wave in this iteration (kba_items.hpp:schur_slab_of)
     int32_t schur_span_gp;  // ground-plane Schur blocks per wave
     int32_t num_trim_rounds, trim_iters, max_iters;  // the schedule, for the device-side scheduler
-    int32_t schur_nslab;  // > 0: landmark-sharded solve - k_cam_solve sums this many per-shard slabs from S_red instead
+    int32_t schur_nslab;  // > 0: k_cam_solve sums this many slabs from S_red instead of the window's partial slabs
+    int32_t schur_packed; // 1 (landmark-sharded solve): a slab of S_red holds ONLY the entries the camera solve reads - upper triangle
+                          // of the free slots + rhs, in the order cam_solve enumerates them (kba_items.hpp:schur_need_offset), stride
+                          // schur_need_pad(nf) - what a shard puts on the wire per LM iteration (33 KB at 90 free slots, not 74 KB)
 };
 
 // Raw pointers to every buffer of a batch (device pointers in the library, host pointers in the emulator).
@@ -177,6 +185,22 @@ struct BatchView {
     const int32_t* sblk_lm0;
     const int32_t* sblk_n;
     // --- ground-plane residuals
+    // --- landmark-sharded solve: what a shard contributes per LM iteration, already summed over ITS workgroups /
+    //     rows (kba_items.hpp:shard_reduce_*), in the shard's own contiguous block (kba_buffers.hpp:exchange_layout):
+    const int32_t* lblk_owner;  // [n_lblk] shard that owns the landmark workgroup (null in unsharded batches)
+    const int32_t* gp_owner;    // [TG] shard that owns the ground-plane row
+    double* x_lv;               // [window][view][kLinPartial]  camera-side sums of the shard's landmark workgroups, in workgroup order
+    double* x_lf;               // [window]     a functor failed
+    double* x_gp;               // [TK][kGpRed] per keyframe: F^T F (upper, 55) | F^T r (10) of the shard's ground-plane rows, in row order
+    double* x_gc;               // [window]     their cost at the linearisation point
+    double* x_gcc;              // [window]     their cost at the candidate
+    double* x_lb;               // [window][8]  the lblk_part entries folded over the shard's workgroups (max / sum / or)
+    // ... and how the CONSUMER view (window-level kernels, replicated on every shard) sees the P contributions: through the
+    // ordinary members lv_part / lblk_linfail / gp_cost / gp_cost_c / lblk_part with a WinDesc whose lblk0 / n_lblk / lvpart_off /
+    // gp0 / n_gp describe "P workgroups, P rows" (one per shard, shard order) - the summation loops of cam_assemble and
+    // reduce_step run unchanged - plus gp_red for the one place that consumed raw rows:
+    const double* gp_red;       // [P][TK][kGpRed] or null
+    int32_t gp_red_P, pad_x;
     const int32_t* gp_lm;       // [TG] global landmark
     const int32_t* gp_kf;       // [TG] global keyframe
     const double* gp_w;         // [TG] loss weight
@@ -219,6 +243,25 @@ struct BatchView {
     int32_t* sched_lists;       // the worklists, back to back
     int32_t sched_off[SL_COUNT];  // offset of list k's count word inside sched_lists
     int32_t* sched_done_host;   // pinned ring (4 words): windows finished as of round r at [r & 3]
+};
+
+// Sizes and offsets of a landmark-sharded solve's exchange (kba_buffers.hpp:exchange_layout builds it and explains it).
+struct ExchangeLayout {
+    int P = 1, n_win = 0, TK = 0;
+    size_t n_lv = 0, n_w = 0, n_gp = 0, n_lb = 0, n_S = 0;      // doubles per shard: x_lv, per-window scalars, x_gp, x_lb, S
+    size_t b_lv = 0, b_lf = 0, b_gp = 0, b_gc = 0, b_gcc = 0, b_lb = 0, b_S = 0, b_total = 0;  // offsets inside a block
+    size_t c_lv = 0, c_lf = 0, c_gp = 0, c_gc = 0, c_gcc = 0, c_lb = 0, c_S = 0, c_total = 0;  // offsets inside the consumer arena
+    size_t trim_count = 0;               // doubles of [trim_rep | trim_dep]
+    size_t spart_count = 1;              // doubles of the private S_part
+    // range of exchange point 1 (A1), 2 (A2), 3 (A), 4 (B) inside a block
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    void range(int point, size_t& off, size_t& count) const {
+        off = point == 2 ? b_S : point == 4 ? b_gcc : 0;
+        const size_t end = point == 1 || point == 4 ? b_S : b_total;
+        count = end - off;
+    }
 };
 
 }  // namespace kba

@@ -522,7 +522,9 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.spart_off = P.spart_total;
         P.spart_total += (int64_t)d.n_sblk * ((int64_t)d.nf_pad * d.nf_pad);
         d.sred_off = P.sred_total;
-        if (P.n_shards > 1) P.sred_total += (int64_t)P.n_shards * d.nf_pad * d.nf_pad;
+        if (P.n_shards > 1) P.sred_total += (int64_t)P.n_shards * schur_need_pad(d.nf);  // packed: upper triangle + rhs only
+        d.xlv_off = P.xlv_total;
+        P.xlv_total += (int64_t)d.n_view * kLinPartial;
         d.lvpart_off = P.lvpart_total;
         P.lvpart_total += (int64_t)d.n_lblk * d.n_view * kLinPartial;
         {   // camera system too large for LDS: scratch in global memory (kba_items.hpp:kCamLdsCapBytes)

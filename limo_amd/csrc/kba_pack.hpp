@@ -40,7 +40,7 @@ using uvec = std::vector<T, default_init_allocator<T>>;
 struct PackedBatch {
     int32_t n_win = 0, TK = 0, TL = 0, TO = 0, TV = 0, TG = 0, n_blk = 0, n_lblk = 0, n_sblk = 0, Vmax = 0;
     int64_t SO = 0, SL = 0, SG = 0;
-    int64_t hcc_total = 0, spart_total = 0, sred_total = 0, camscr_total = 0, lvpart_total = 0;
+    int64_t hcc_total = 0, spart_total = 0, sred_total = 0, camscr_total = 0, lvpart_total = 0, xlv_total = 0;
     bool evaluate_only = false;  // planes hold the full Jacobians instead of the factored form
     int32_t n_shards = 1;        // landmark shards; owner of landmark l = (caller's index of l) mod n_shards
     std::vector<int32_t> blk_owner, lblk_owner, sblk_owner, gp_owner;  // owning shard of every workgroup / gp row

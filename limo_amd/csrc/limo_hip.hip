@@ -101,7 +101,12 @@ struct limo_ba_batch : Executor {
     std::vector<int> local_shards;
     std::vector<BatchView> pv;
     ExchangeLayout xl;
-    std::vector<double*> arenas;  // exchange arenas: [0] = consumer view, [1 + i] = local shard i
+    double* arena_c = nullptr;          // consumer view: the P contributions side by side (kba_buffers.hpp:exchange_layout)
+    std::vector<double*> blocks;        // block of local shard i (what it contributes per LM iteration)
+    std::vector<double*> trims;         // trimming arenas: [0] consumer, [1 + i] local shard i
+    double* d_gather = nullptr;         // [world][block] staging of the all-gather
+    WinDesc* d_win_orig = nullptr;      // the batch's own window descriptors (bv.win of the consumer view is modified)
+    bool first_lin = false, assemble_pending = false;
     int64_t n_exchanges = 0, exchange_bytes = 0;  // all-reduce calls / bytes of this batch so far (limo_ba_batch_exchange_stats)
     struct RankLists {
         int32_t *full_blk = nullptr, *full_lblk = nullptr, *full_sblk = nullptr;  // every window listed
@@ -239,22 +244,31 @@ struct limo_ba_batch : Executor {
         pv.assign(1, bv);
         if (shard_P > 1) {
             xl = exchange_layout(P);
-            pv.assign(local_shards.size(), bv);
-            auto arena = [&](double** out) -> int {
-                if (dmalloc((void**)out, sizeof(double) * xl.total)) return LIMO_ERR_RUNTIME;
-                HIP_TRY(ctx, hipMemsetAsync(*out, 0, sizeof(double) * xl.total, ctx->stream));
-                arenas.push_back(*out);
+            d_win_orig = const_cast<WinDesc*>(bv.win);
+            pv.assign(local_shards.size(), bv);  // producers keep the batch's own per-workgroup arrays (every entry has ONE owner)
+            auto zeros = [&](double** out, size_t n) -> int {
+                if (dmalloc((void**)out, sizeof(double) * std::max<size_t>(1, n))) return LIMO_ERR_RUNTIME;
+                HIP_TRY(ctx, hipMemsetAsync(*out, 0, sizeof(double) * std::max<size_t>(1, n), ctx->stream));
                 return LIMO_OK;
             };
-            double* q = nullptr;
-            if (arena(&q)) return LIMO_ERR_RUNTIME;
-            exchange_bind(xl, bv, q);
+            if (zeros(&arena_c, xl.c_total)) return LIMO_ERR_RUNTIME;
+            trims.assign(1 + local_shards.size(), nullptr);
+            for (double*& t : trims)
+                if (zeros(&t, xl.trim_count)) return LIMO_ERR_RUNTIME;
+            blocks.assign(local_shards.size(), nullptr);
+            if (!shard_virtual && zeros(&d_gather, (size_t)ctx->comm_world * xl.b_total)) return LIMO_ERR_RUNTIME;
+            {   // consumer view: "P workgroups, P rows" per window
+                std::vector<WinDesc> wc = exchange_consumer_windows(P);
+                WinDesc* d_wc = nullptr;
+                if (dmalloc((void**)&d_wc, sizeof(WinDesc) * wc.size())) return LIMO_ERR_RUNTIME;
+                HIP_TRY(ctx, hipMemcpy(d_wc, wc.data(), sizeof(WinDesc) * wc.size(), hipMemcpyHostToDevice));
+                exchange_bind_consumer(xl, bv, arena_c, trims[0], d_wc);
+            }
             rl.assign(local_shards.size(), RankLists());
             for (size_t i = 0; i < local_shards.size(); ++i) {
-                if (arena(&q)) return LIMO_ERR_RUNTIME;  // the shard's own exchange arena ...
-                exchange_bind(xl, pv[i], q);
-                if (dmalloc((void**)&pv[i].S_part, sizeof(double) * xl.spart_count)) return LIMO_ERR_RUNTIME;  // ... and its private Schur slabs
-                HIP_TRY(ctx, hipMemsetAsync(pv[i].S_part, 0, sizeof(double) * xl.spart_count, ctx->stream));
+                if (zeros(&blocks[i], xl.b_total)) return LIMO_ERR_RUNTIME;  // the shard's own block ...
+                exchange_bind_producer(xl, pv[i], blocks[i], trims[1 + i]);
+                if (zeros(&pv[i].S_part, xl.spart_count)) return LIMO_ERR_RUNTIME;  // ... and its private Schur slabs
                 const int r = local_shards[i];
                 auto make = [&](const std::vector<int32_t>& owner, int32_t** full, int32_t** act, int* n) -> int {
                     std::vector<int32_t> v;
@@ -389,6 +403,7 @@ struct limo_ba_batch : Executor {
         if (const char* e = std::getenv("KBA_SPAN")) c.schur_span = std::max(1, std::atoi(e));  // A/B timing aids
         if (shard_P > 1) c.schur_span = c.schur_span_gp = 1;  // Schur blocks are cut at shard boundaries
         c.schur_nslab = shard_P > 1 ? shard_P : 0;
+        c.schur_packed = shard_P > 1 ? 1 : 0;
     }
 
     // ---- sharding helpers
@@ -402,20 +417,47 @@ struct limo_ba_batch : Executor {
     int count_sblk_fgp(size_t i) const { return shard_P > 1 ? rl[i].n_sblk_fgp : n_wl_sblk_fgp; }
     int shard_of(size_t i) const { return shard_P > 1 ? local_shards[i] : 0; }
 
-    // Exchange step: sum the shards' partial arrays of `point` into the consumer view - ONE contiguous range of the
-    // exchange arenas per point (kba_buffers.hpp:exchange_layout): one k_sum_shards launch, one all-reduce.
-    void allreduce(int point) {
+    // Per-iteration exchange (point 1 = A1, 2 = A2, 3 = A, 4 = B; kba_buffers.hpp:exchange_layout): ALL-GATHER of the shards'
+    // blocks over the ranks - one call per local slot, normally one shard per rank: ONE ncclAllGather of 41 KB at a C4 window -
+    // then k_unpack puts every contribution at its shard's place in the consumer view.  Shard s lives on rank s mod world, in
+    // local slot s / world.  Virtual shards (no communicator): the unpack alone.
+    void exchange(int point) {
         if (shard_P == 1) return;
         hipStream_t s = ctx->stream;
-        const int x = exchange_index(point);
-        double* dst = arenas[0] + xl.off[x];
-        const int64_t n = (int64_t)xl.count[x];
+        size_t off, count;
+        xl.range(point, off, count);
+        for (size_t i = 0; i < pv.size(); ++i) {
+            if (shard_virtual) {
+                hipLaunchKernelGGL(k_unpack, dim3(cdiv((int64_t)count, 256)), dim3(256), 0, s, xl, (const WinDesc*)d_win_orig, (const double*)(blocks[i] + off), arena_c,
+                                   local_shards[i], (int64_t)off, (int64_t)count);
+                LAUNCH_CHECK("k_unpack");
+            } else {
+                ncclResult_t r = ncclAllGather(blocks[i] + off, d_gather, count, ncclDouble, (ncclComm_t)ctx->comm, s);
+                if (r != ncclSuccess && rc == LIMO_OK) {
+                    rc = LIMO_ERR_RUNTIME;
+                    ctx->err = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+                }
+                for (int q = 0; q < ctx->comm_world; ++q) {
+                    hipLaunchKernelGGL(k_unpack, dim3(cdiv((int64_t)count, 256)), dim3(256), 0, s, xl, (const WinDesc*)d_win_orig,
+                                       (const double*)(d_gather + (size_t)q * count), arena_c, (int)i * ctx->comm_world + q, (int64_t)off, (int64_t)count);
+                    LAUNCH_CHECK("k_unpack");
+                }
+            }
+            ++n_exchanges;
+            exchange_bytes += (int64_t)count * (int64_t)sizeof(double);
+        }
+    }
+    // Trimming round: per-landmark residual maxima, one owner per entry and zero elsewhere - an exact sum in any order.
+    void exchange_trim() {
+        if (shard_P == 1) return;
+        hipStream_t s = ctx->stream;
+        const int64_t n = (int64_t)xl.trim_count;
         ShardPtrs sp;
-        for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = arenas[1 + i] + xl.off[x];
-        hipLaunchKernelGGL(k_sum_shards<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, dst, sp, (int)pv.size(), n);  // local shards, in shard order
+        for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = trims[1 + i];
+        hipLaunchKernelGGL(k_sum_shards<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, trims[0], sp, (int)pv.size(), n);
         LAUNCH_CHECK("k_sum_shards");
-        if (!shard_virtual) {  // ... then over the ranks (in place)
-            ncclResult_t r = ncclAllReduce(dst, dst, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+        if (!shard_virtual) {
+            ncclResult_t r = ncclAllReduce(trims[0], trims[0], (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
             if (r != ncclSuccess && rc == LIMO_OK) {
                 rc = LIMO_ERR_RUNTIME;
                 ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
@@ -517,6 +559,7 @@ struct limo_ba_batch : Executor {
 
     void solve_init(int max_iter, int select) override {
         it_no = 0;
+        first_lin = true;  // the next linearisation defines the Jacobi scaling (WinState::compute_scale)
         full_lists();
         hipLaunchKernelGGL(k_solve_init, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv, c, max_iter, select);
         LAUNCH_CHECK("k_solve_init");
@@ -554,9 +597,29 @@ struct limo_ba_batch : Executor {
                 }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
-        allreduce(1);
-        // active-window counter: a ring of 4 slots so the host can read iteration i-1 while iteration i runs
-        const int slot = it_no & 3;
+        if (shard_P > 1) {
+            for (size_t i = 0; i < pv.size(); ++i)
+                if (n_wl_win) {
+                    hipLaunchKernelGGL(k_shard_reduce, dim3(n_wl_win), dim3(kBlock), 0, s, pv[i], use_wl ? (const int32_t*)d_wl_win : (const int32_t*)nullptr, shard_of(i), 0);
+                    LAUNCH_CHECK("k_shard_reduce");
+                }
+            // Sharded: the camera assembly only has to come before the Schur complement when it defines the Jacobi scale (the
+            // first linearisation of a solve).  Every other iteration it waits for the slabs and ONE exchange serves both (step()).
+            if (!first_lin) {
+                assemble_pending = true;
+                return;
+            }
+            first_lin = false;
+            exchange(1);
+        }
+        assemble(it_no);
+    }
+
+    // k_cam_assemble + the active-window counter of iteration `iter`: a ring of 4 slots so the host can read iteration i-1
+    // while iteration i runs
+    void assemble(int iter) {
+        hipStream_t s = ctx->stream;
+        const int slot = iter & 3;
         BatchView bvs = bv;
         bvs.n_active = bv.n_active + 2 * slot;
         bvs.n_active_host = d_h_active + slot;
@@ -621,13 +684,22 @@ struct limo_ba_batch : Executor {
             }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
-        if (shard_P > 1 && n_wl_win) {
-            for (size_t i = 0; i < pv.size(); ++i) {
-                hipLaunchKernelGGL(k_slab_reduce, dim3(n_wl_win, 8), dim3(kBlock), 0, s, pv[i], use_wl ? d_wl_win : nullptr, shard_of(i));
-                LAUNCH_CHECK("k_slab_reduce");
+        if (shard_P > 1) {
+            if (n_wl_win)
+                for (size_t i = 0; i < pv.size(); ++i) {
+                    const int32_t* wlw = use_wl ? (const int32_t*)d_wl_win : (const int32_t*)nullptr;
+                    hipLaunchKernelGGL(k_shard_reduce, dim3(n_wl_win), dim3(kBlock), 0, s, pv[i], wlw, shard_of(i), 1);
+                    hipLaunchKernelGGL(k_slab_reduce, dim3(n_wl_win, 8), dim3(kBlock), 0, s, pv[i], wlw, shard_P);
+                    LAUNCH_CHECK("k_slab_reduce");
+                }
+            if (assemble_pending) {  // ONE exchange: camera-side sums + ground-plane blocks + scalars + [S | rhs]
+                assemble_pending = false;
+                exchange(3);
+                assemble(it_no - 1);  // (active_count() has moved it_no on to the next iteration)
+            } else {
+                exchange(2);
             }
         }
-        allreduce(2);
         if (n_wl_win) hipLaunchKernelGGL(k_cam_solve, dim3(n_wl_win), dim3(kBlock), solve_bytes, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_cam_solve");
         for (size_t i = 0; i < pv.size(); ++i) {
@@ -636,7 +708,12 @@ struct limo_ba_batch : Executor {
                 LAUNCH_CHECK("k_backsub");
             }
         }
-        allreduce(4);
+        if (shard_P > 1 && n_wl_win)
+            for (size_t i = 0; i < pv.size(); ++i) {
+                hipLaunchKernelGGL(k_shard_reduce, dim3(n_wl_win), dim3(kBlock), 0, s, pv[i], use_wl ? (const int32_t*)d_wl_win : (const int32_t*)nullptr, shard_of(i), 2);
+                LAUNCH_CHECK("k_shard_reduce");
+            }
+        exchange(4);
         if (n_wl_win) hipLaunchKernelGGL(k_step_decide, dim3(n_wl_win), dim3(64), 0, s, bv, c, use_wl ? d_wl_win : nullptr);
         LAUNCH_CHECK("k_step_decide");
         hipLaunchKernelGGL(k_accept, dim3(cdiv((int64_t)P.TK + P.TL, 256)), dim3(256), 0, s, bv);
@@ -663,7 +740,7 @@ struct limo_ba_batch : Executor {
                 LAUNCH_CHECK("k_trim_max");
             }
         }
-        allreduce(8);
+        exchange_trim();
         hipLaunchKernelGGL(k_trim_select, dim3(P.n_win), dim3(kBlock), trim_bytes, s, bv, c);
         LAUNCH_CHECK("k_trim_select");
     }
@@ -1136,8 +1213,14 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     if (opts) {
         if (opts->min_landmarks_for_trimming != b->opts.min_landmarks_for_trimming) {
             for (int w = 0; w < b->P.n_win; ++w) b->P.win[w].do_trim = b->P.win[w].n_lm > opts->min_landmarks_for_trimming;
-            HIP_TRY(ctx, hipMemcpyAsync((void*)b->bv.win, b->P.win.data(), sizeof(WinDesc) * b->P.n_win, hipMemcpyHostToDevice,
-                                        ctx->stream));
+            if (b->shard_P > 1) {  // (the consumer view of a sharded batch carries its own descriptors: both copies follow)
+                const std::vector<WinDesc> wc = exchange_consumer_windows(b->P);
+                HIP_TRY(ctx, hipMemcpy((void*)b->d_win_orig, b->P.win.data(), sizeof(WinDesc) * b->P.n_win, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy((void*)b->bv.win, wc.data(), sizeof(WinDesc) * b->P.n_win, hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(ctx, hipMemcpyAsync((void*)b->bv.win, b->P.win.data(), sizeof(WinDesc) * b->P.n_win, hipMemcpyHostToDevice,
+                                            ctx->stream));
+            }
         }
         b->opts = *opts;
         b->c = make_consts(*opts);

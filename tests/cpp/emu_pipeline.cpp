@@ -21,8 +21,9 @@ using namespace kba;
 namespace {
 
 // Exchange callback of a landmark-sharded run whose shards are separate processes (tests: torch.distributed / gloo):
-// recv = element-wise sum over all ranks of send.
-typedef void (*emu_allreduce_fn)(const void* send, void* recv, int64_t count, int is_int, void* user);
+// kind 0: recv[count] = element-wise sum over all ranks of send[count] (trimming maxima, final landmarks);
+// kind 2: ALL-GATHER - recv[world][count] = every rank's send[count], in rank order (the per-iteration exchange of the solve).
+typedef void (*emu_allreduce_fn)(const void* send, void* recv, int64_t count, int kind, void* user);
 
 struct EmuBatch : Executor {
     PackedBatch P;
@@ -35,8 +36,14 @@ struct EmuBatch : Executor {
     std::vector<int> local_shards;
     std::vector<BatchView> pv;
     ExchangeLayout xl;
-    std::vector<double*> arenas;  // [0] = consumer view, [1 + i] = local shard i
+    std::vector<WinDesc> win_c;    // the consumer's window descriptors ("P workgroups, P rows")
+    double* arena_c = nullptr;     // the P contributions, side by side
+    std::vector<double*> blocks;   // block of local shard i
+    std::vector<double*> trims;    // trimming arenas: [0] consumer, [1 + i] local shard i
+    int world = 1, rank = 0;
+    bool first_lin = false, assemble_pending = false;
     long n_exchanges = 0;
+    long long exchange_doubles = 0;  // doubles this rank SENT in the per-iteration exchanges
     emu_allreduce_fn cb = nullptr;
     void* cb_user = nullptr;
 
@@ -62,19 +69,24 @@ struct EmuBatch : Executor {
             if (local_shards.empty())
                 for (int r = 0; r < shard_P; ++r) local_shards.push_back(r);
             xl = exchange_layout(P);
-            pv.assign(local_shards.size(), bv);
-            auto arena = [&]() {
-                double* q = static_cast<double*>(std::calloc(xl.total, sizeof(double)));
+            auto zeros = [&](size_t n) {
+                double* q = static_cast<double*>(std::calloc(n ? n : 1, sizeof(double)));
                 allocs.push_back(q);
-                arenas.push_back(q);
                 return q;
             };
-            exchange_bind(xl, bv, arena());
-            for (BatchView& v : pv) {
-                exchange_bind(xl, v, arena());
-                v.S_part = static_cast<double*>(std::calloc(xl.spart_count, sizeof(double)));  // private per shard
-                allocs.push_back(v.S_part);
+            pv.assign(local_shards.size(), bv);  // producers keep the batch's own per-workgroup arrays (every entry has ONE owner)
+            for (size_t i = 0; i < pv.size(); ++i) blocks.push_back(zeros(xl.b_total));
+            trims.assign(1 + pv.size(), nullptr);
+            for (double*& t : trims) t = zeros(xl.trim_count);
+            for (size_t i = 0; i < pv.size(); ++i) {
+                exchange_bind_producer(xl, pv[i], blocks[i], trims[1 + i]);
+                pv[i].S_part = zeros(xl.spart_count);  // private per shard
             }
+            win_c = exchange_consumer_windows(P);
+            arena_c = zeros(xl.c_total);
+            exchange_bind_consumer(xl, bv, arena_c, trims[0], win_c.data());
+            c.schur_nslab = shard_P;
+            c.schur_packed = 1;
         }
     }
     bool owns(size_t i, int owner) const { return shard_P == 1 || owner == local_shards[i]; }
@@ -84,17 +96,37 @@ struct EmuBatch : Executor {
             if (owns_lm(i, gl)) return true;
         return false;
     }
+    // Per-iteration exchange (points 1 = A1, 2 = A2, 3 = A, 4 = B of kba_buffers.hpp): all-gather of the shards' blocks - one
+    // call per local slot (normally one shard per rank: ONE call) - then unpack_entry puts every contribution at its shard's
+    // place in the consumer view.  Shard s lives on rank s mod world, in local slot s / world.
     void exchange(int point) {
         if (shard_P == 1) return;
-        const int x = exchange_index(point);
-        double* dst = arenas[0] + xl.off[x];
-        for (size_t k = 0; k < xl.count[x]; ++k) {  // sum of the local shards, in shard order ...
-            double a = arenas[1][xl.off[x] + k];
-            for (size_t i = 1; i < pv.size(); ++i) a += arenas[1 + i][xl.off[x] + k];
-            dst[k] = a;
+        size_t off, count;
+        xl.range(point, off, count);
+        std::vector<double> recv;
+        for (size_t i = 0; i < pv.size(); ++i) {
+            ++n_exchanges;
+            exchange_doubles += (long long)count;
+            if (cb) {
+                recv.assign((size_t)world * count, 0.0);
+                cb(blocks[i] + off, recv.data(), (int64_t)count, 2, cb_user);
+                for (int r = 0; r < world; ++r)
+                    for (size_t e = 0; e < count; ++e) unpack_entry(xl, P.win.data(), recv.data() + (size_t)r * count, off, arena_c, (int)i * world + r, off + e);
+            } else {
+                for (size_t e = 0; e < count; ++e) unpack_entry(xl, P.win.data(), blocks[i] + off, off, arena_c, local_shards[i], off + e);
+            }
+        }
+    }
+    // Trimming round: per-landmark residual maxima, one owner per entry and zero elsewhere - an exact sum.
+    void exchange_trim() {
+        if (shard_P == 1) return;
+        for (size_t k = 0; k < xl.trim_count; ++k) {
+            double a = trims[1][k];
+            for (size_t i = 1; i < pv.size(); ++i) a += trims[1 + i][k];
+            trims[0][k] = a;
         }
         ++n_exchanges;
-        if (cb) cb(dst, dst, (int64_t)xl.count[x], 0, cb_user);  // ... then over the ranks, in place: ONE call per point
+        if (cb) cb(trims[0], trims[0], (int64_t)xl.trim_count, 0, cb_user);
     }
 
     void solve_init(int max_iter, int select) override {
@@ -104,6 +136,17 @@ struct EmuBatch : Executor {
             if (select >= 1) sel = bv.win[w].do_trim != 0;
             if (select == 2) sel = sel && (s.solve_initial_cost - s.solve_final_cost <= 0.0);
             lm_solve_init(s, sel, max_iter, c);
+        }
+        first_lin = true;  // the next linearisation defines the Jacobi scaling (WinState::compute_scale)
+    }
+
+    // camera assembly + the LM decision at the linearisation point (k_cam_assemble)
+    void assemble() {
+        std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1));
+        for (int w = 0; w < bv.n_win; ++w) {
+            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
+            cam_assemble(bv, c, w, 0, 1, H.data());
+            lm_decide_lin(bv.st[w], bv.red[w], bv.reg_cost[2 * w + 1], c);
         }
     }
 
@@ -156,14 +199,20 @@ struct EmuBatch : Executor {
                 v.lblk_linfail[b] = fail;
             }
         }
-        exchange(1);
-        // camera assemble + LM decision
-        std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1));
-        for (int w = 0; w < bv.n_win; ++w) {
-            if (!bv.st[w].active || !bv.st[w].need_lin) continue;
-            cam_assemble(bv, c, w, 0, 1, H.data());
-            lm_decide_lin(bv.st[w], bv.red[w], bv.reg_cost[2 * w + 1], c);
+        if (shard_P > 1) {
+            for (size_t si = 0; si < pv.size(); ++si)
+                for (int w = 0; w < bv.n_win; ++w)
+                    if (pv[si].st[w].active && pv[si].st[w].need_lin) shard_reduce_lin(pv[si], w, local_shards[si], 0, 1);
+            // Sharded: the camera assembly only has to come before the Schur complement when it defines the Jacobi scale (first
+            // linearisation of a solve).  Every other iteration it waits for the slabs and ONE exchange serves both.
+            if (!first_lin) {
+                assemble_pending = true;
+                return;
+            }
+            first_lin = false;
+            exchange(1);
         }
+        assemble();
     }
 
     int active_count() override {
@@ -230,13 +279,19 @@ struct EmuBatch : Executor {
         if (shard_P > 1) {
             for (size_t si = 0; si < pv.size(); ++si)
                 for (int w = 0; w < bv.n_win; ++w) {
-                    if (!bv.st[w].active) continue;
-                    const int n = bv.win[w].nf_pad * bv.win[w].nf_pad;
-                    for (int e = 0; e < n; ++e) slab_reduce_entry(pv[si], w, local_shards[si], e);
+                    if (!pv[si].st[w].active) continue;
+                    if (pv[si].st[w].redamp) shard_reduce_damp(pv[si], w, local_shards[si]);
+                    const int n = schur_need_count(pv[si].win[w].nf);
+                    for (int e = 0; e < n; ++e) slab_reduce_entry(pv[si], w, shard_P, e);
                 }
-            c.schur_nslab = shard_P;
+            if (assemble_pending) {  // ONE exchange: camera-side sums + ground-plane blocks + scalars + [S | rhs]
+                assemble_pending = false;
+                exchange(3);
+                assemble();
+            } else {
+                exchange(2);
+            }
         }
-        exchange(2);
         // camera solve
         std::vector<double> S((size_t)cam_solve_scratch(kMaxNc, 1));
         for (int w = 0; w < bv.n_win; ++w) {
@@ -274,6 +329,10 @@ struct EmuBatch : Executor {
                     if (owns_lm(si, v.gp_lm[g])) gp_lane(v, g, true, v.gp_cost_c);
             }
         }
+        if (shard_P > 1)
+            for (size_t si = 0; si < pv.size(); ++si)
+                for (int w = 0; w < bv.n_win; ++w)
+                    if (pv[si].st[w].active) shard_reduce_step(pv[si], w, local_shards[si]);
         exchange(4);
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active) continue;
@@ -313,7 +372,7 @@ struct EmuBatch : Executor {
                     if (owns_lm(si, wd.lm0 + l)) trim_max_lane(v, wd.lm0 + l, plane_rep.data(), plane_dep.data());
             }
         }
-        exchange(8);
+        exchange_trim();
         for (int w = 0; w < bv.n_win; ++w) {
             const WinDesc& wd = bv.win[w];
             if (!wd.do_trim) continue;
@@ -398,7 +457,7 @@ struct EmuBatch : Executor {
 
 void fill_report(const EmuBatch& B, int w, limo_ba_report* r) {
     const WinState& s = B.bv.st[w];
-    const WinDesc& d = B.bv.win[w];
+    const WinDesc& d = B.P.win[w];  // (the consumer view of a sharded solve carries modified descriptors)
     std::memset(r, 0, sizeof(*r));
     r->termination = s.term;
     r->num_solves = s.acc_solves;
@@ -502,6 +561,8 @@ int emu_ba_solve_sharded(limo_ba_window* window, const limo_ba_options* o, int n
             if (r % world == rank) B.local_shards.push_back(r);
         B.cb = cb;
         B.cb_user = user;
+        B.world = world;
+        B.rank = rank;
     }
     B.alloc();
     run_schedule(B, *o);

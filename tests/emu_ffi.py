@@ -107,20 +107,25 @@ def build_shim_tests(gpu=False, oracle=False):
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
-def solve_sharded(window, opts, n_shards, rank=0, world=1, allreduce=None):
+def solve_sharded(window, opts, n_shards, rank=0, world=1, allreduce=None, allgather=None):
     """Landmark-sharded emulation.  allreduce = None: n_shards virtual shards in this process; else this process is
-    shard `rank` and allreduce(send_ndarray, recv_ndarray) must leave the element-wise sum over all ranks in recv."""
+    rank `rank` of `world` (shard s lives on rank s mod world) and
+      allreduce(send_ndarray, recv_ndarray) must leave the element-wise sum over all ranks in recv (trimming, final landmarks),
+      allgather(send_ndarray[count], recv_ndarray[world, count]) every rank's send, in rank order (the per-iteration exchange)."""
     lib = load()
     s = window.as_struct()
     rep = _ffi.BaReport()
     if allreduce is None:
         cb = C.cast(None, ALLREDUCE_FN)
     else:
-        def _cb(send, recv, count, is_int, _user):
-            ct = C.c_int32 if is_int else C.c_double
-            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(ct)), shape=(count,))
-            b = np.ctypeslib.as_array(C.cast(recv, C.POINTER(ct)), shape=(count,))
-            allreduce(a, b)  # send and recv may alias (in-place exchange)
+        def _cb(send, recv, count, kind, _user):
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(count,))
+            if kind == 2:
+                b = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(world, count))
+                allgather(a, b)
+            else:
+                b = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(count,))
+                allreduce(a, b)  # send and recv may alias (in-place exchange)
 
         cb = ALLREDUCE_FN(_cb)
     rc = lib.emu_ba_solve_sharded(C.byref(s), C.byref(opts), int(n_shards), int(rank), int(world), cb, None, C.byref(rep))
