@@ -28,13 +28,19 @@ struct limo_ctx {
     void* staging = nullptr;                // pinned host staging buffer of small uploads
     size_t staging_cap = 0;
 
+    // Larger blocks (the arena of a 1024-window batch is ~1.5 GB) are kept too, in 64 MB classes, one per class and at most
+    // kPoolLargeBytes altogether: hipMalloc / hipFree of blocks that size synchronise the DEVICE, so a caller that streams
+    // batches through two contexts (pack + upload of batch k + 1 under the solve of batch k) would otherwise serialise on them.
+    static constexpr size_t kLargeStep = 64u << 20;
+    static constexpr size_t kPoolLargeBytes = size_t(16) << 30;
+    size_t pooled_large = 0;
     static size_t size_class(size_t bytes) {
+        if (bytes > kPoolMaxBlock) return (bytes + kLargeStep - 1) / kLargeStep * kLargeStep;
         size_t c = 256;
         while (c < bytes) c <<= 1;
         return c;
     }
     hipError_t pool_alloc(void** p, size_t bytes) {
-        if (bytes > kPoolMaxBlock) return hipMalloc(p, bytes);
         const size_t c = size_class(bytes);
         static const bool no_reuse = std::getenv("KBA_NO_POOL") != nullptr;  // debugging aid
         if (no_reuse) return hipMalloc(p, c);
@@ -42,21 +48,22 @@ struct limo_ctx {
         if (it != pool.end() && !it->second.empty()) {
             *p = it->second.back();
             it->second.pop_back();
+            if (bytes > kPoolMaxBlock) pooled_large -= c;
             return hipSuccess;
         }
         return hipMalloc(p, c);
     }
     void pool_free(void* p, size_t bytes) {
-        if (bytes > kPoolMaxBlock) {
-            (void)hipFree(p);
-            return;
-        }
-        auto& v = pool[size_class(bytes)];
+        const size_t c = size_class(bytes);
+        auto& v = pool[c];
         static const bool no_reuse = std::getenv("KBA_NO_POOL") != nullptr;
-        if ((int)v.size() < kPoolPerClass && !no_reuse)
+        const bool large = bytes > kPoolMaxBlock;
+        if (!no_reuse && (large ? (v.empty() && pooled_large + c <= kPoolLargeBytes) : (int)v.size() < kPoolPerClass)) {
             v.push_back(p);
-        else
+            if (large) pooled_large += c;
+        } else {
             (void)hipFree(p);
+        }
     }
     hipError_t host_alloc(void** p, size_t bytes) {
         const size_t c = size_class(bytes);
@@ -82,6 +89,7 @@ struct limo_ctx {
         for (auto& kv : pool)
             for (void* p : kv.second) (void)hipFree(p);
         pool.clear();
+        pooled_large = 0;
         if (staging) (void)hipHostFree(staging);
         staging = nullptr;
         staging_cap = 0;
