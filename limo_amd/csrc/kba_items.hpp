@@ -1297,6 +1297,109 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     (void)flag;
     const int tw = nt >= 16 ? 16 : 1, th = nt / tw, tx = tid % tw;
     const int ty = nt == 256 ? ((tid >> 4) & 3) * 4 + (tid >> 6) : tid / tw;  // wave w: rows w, w + 4, w + 8, w + 12 (+16 ...)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950, 256 lanes: the same elimination in blocks of FOUR pivots (round 4).  The chain of one pivot - read the pivot, divide,
+    // update, barrier - is ~1150 cycles however the lanes are dealt (rounds 2-3), 40 of them in a row at C2.  Here ONE wave runs
+    // the four pivots of a block on the block's own (<= 3) remaining rows, ordered by wave-level fences only; then all four waves
+    // apply the block to the trailing rows as a rank-4 update, A[i][j] -= sum_k (A[k][i] / d_k) A[k][j], one 16 x 16 tile per
+    // v_mfma_f64_16x16x4 (A operand: the negated multipliers, B operand: the pivot rows, C: the tile, all straight from LDS).
+    // Two workgroup barriers per block instead of four.  Same pivots, same failure rule; the four products of an entry are added
+    // inside the MFMA instead of one after the other, so results differ from the loop below by rounding (all device paths share
+    // this code; the CPU-tier emulation keeps the loop).
+    if (nt == 256) {
+        typedef double v4d_t __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+        double* invd = y;  // (y is free until the factorisation is over)
+        if (tid == 0) *flag = 0;
+        KBA_SYNC();
+        for (int kb = 0; kb < nf; kb += 4) {
+            const int kbe = kb + 4 < nf ? kb + 4 : nf;
+            if (wave == 0 && nf < 64) {
+                // the block's four rows in registers, lane = column: pivots and multipliers travel by v_readlane, no memory round
+                // trip between the four pivots (through LDS the block's own rows cost ~850 cycles per pivot - no gain over the loop)
+                auto bcast = [](double v, int from) {
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), from), __builtin_amdgcn_readlane(__double2loint(v), from));
+                };
+                double rw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rw[q] = (kb + q < kbe && lane <= nf) ? A[(kb + q) * lda + lane] : 0.0;
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (kb + q < kbe && !bad) {
+                        const double d = bcast(rw[q], kb + q);
+                        if (!(d > 0.0)) {  // (uniform over the wave)
+                            bad = true;
+                        } else {
+                            const double inv_d = 1.0 / d;
+                            if (lane == 0) invd[q] = inv_d;
+#pragma unroll
+                            for (int pr = q + 1; pr < 4; ++pr) {
+                                if (kb + pr < kbe) {
+                                    const double aki = bcast(rw[q], kb + pr) * inv_d;
+                                    if (lane >= kb + pr) rw[pr] -= aki * rw[q];
+                                }
+                            }
+                        }
+                    }
+                }
+                if (bad && lane == 0) *flag = 1;
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    if (kb + q < kbe && lane >= kb + q && lane <= nf) A[(kb + q) * lda + lane] = rw[q];
+            } else if (wave == 0) {
+                for (int k = kb; k < kbe; ++k) {
+                    const double d = A[k * lda + k];
+                    if (!(d > 0.0)) {  // (uniform over the wave)
+                        if (lane == 0) *flag = 1;
+                        break;
+                    }
+                    const double inv_d = 1.0 / d;
+                    if (lane == 0) invd[k - kb] = inv_d;
+                    for (int i = k + 1; i < kbe; ++i) {
+                        const double aki = A[k * lda + i] * inv_d;
+                        for (int j = i + lane; j <= nf; j += 64) A[i * lda + j] -= aki * A[k * lda + j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
+            KBA_SYNC();
+            if (*flag) break;  // (uniform over the workgroup)
+            const int n_tr = nf - kbe;  // trailing rows kbe .. nf - 1; trailing columns kbe .. nf (the rhs rides along)
+            if (n_tr > 0) {
+                const int Ti = (n_tr + 15) / 16, Tj = (n_tr + 1 + 15) / 16;
+                const int kp = kb + kq;  // this lane's pivot of the block (operand index k of the MFMA)
+                const bool kin = kp < kbe;
+                const double ivd = kin ? invd[kq] : 0.0;
+                int t = 0;
+                for (int ti = 0; ti < Ti; ++ti)
+                    for (int tj = ti; tj < Tj; ++tj, ++t) {
+                        if ((t & 3) != wave) continue;
+                        const int i_op = kbe + 16 * ti + li, j_op = kbe + 16 * tj + li;
+                        const double wv = kin && i_op < nf ? -(A[kp * lda + i_op] * ivd) : 0.0;
+                        const double pv = kin && j_op <= nf ? A[kp * lda + j_op] : 0.0;
+                        v4d_t cacc;
+                        const int jc = kbe + 16 * tj + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ic = kbe + 16 * ti + kq + 4 * r;
+                            cacc[r] = (ic < nf && jc <= nf && jc >= ic) ? A[ic * lda + jc] : 0.0;
+                        }
+                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, pv, cacc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ic = kbe + 16 * ti + kq + 4 * r;
+                            if (ic < nf && jc <= nf && jc >= ic) A[ic * lda + jc] = cacc[r];
+                        }
+                    }
+            }
+            KBA_SYNC();
+        }
+        failed = *flag != 0;
+    } else
+#endif
     for (int k = 0; k < nf; ++k) {
         const double d = A[k * lda + k];
         if (!(d > 0.0)) {

@@ -44,3 +44,24 @@ def test_gpus_flag_without_launcher_starts_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_counter_collection_degrades_without_a_profiler(monkeypatch):
+    """scripts/pmc_collect.py (the in-run traffic measurement of bench.py): without rocprofv3 on PATH it reports why and returns
+    nothing - bench.py then falls back to the stored, sha-bound profile or leaves `traffic` null; the sha it stamps is the one
+    bench.py checks."""
+    import importlib.util
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmc_collect", os.path.join(root, "scripts", "pmc_collect.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    monkeypatch.setenv("PATH", "/nonexistent")
+    out, err = pmc.collect(["hbm"], 10.0)
+    assert out is None and "rocprofv3" in err
+    sys.path.insert(0, root)
+    import bench
+
+    assert pmc.kernel_source_sha16() == bench.kernel_source_sha16()
