@@ -570,7 +570,16 @@ std::string BundleAdjusterKeyframes::solve() {
     using clk = std::chrono::steady_clock;
     static const bool shim_trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;  // where the host time of solve() goes
     const auto t_s0 = clk::now();
-    const auto active_lms = getActiveLandmarkConstPtrs();
+    // (getActiveLandmarkConstPtrs() as a sorted vector: the selector's schemes read it in this form, no map is built for them)
+    LandmarkView active_lms;
+    {
+        active_lms.reserve(active_landmark_ids_.size());
+        SortedFinder<decltype(landmarks_)> known(landmarks_);
+        for (const auto& id : active_landmark_ids_) {
+            auto it = known.find(id);
+            if (it != landmarks_.cend()) active_lms.push_back({id, it->second});
+        }
+    }
     const auto active_kfs = getActiveKeyframeConstPtrs();
     const auto t_s0b = clk::now();
     selected_landmark_ids_ = landmark_selector_->select(active_lms, active_kfs);

@@ -170,12 +170,26 @@ public:
 
     std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
         std::set<LandmarkId> out;
-        for (const auto& el : getCategorizedSelection(landmarks, keyframes)) out.insert(el.first);
+        for (const auto& el : categorized(landmarks, keyframes)) out.insert(out.end(), el.first);
         return out;
     }
-
+    std::vector<LandmarkId> getSelectionSorted(const LandmarkView& landmarks, const KeyframeMap& keyframes) const override {
+        std::vector<LandmarkId> out;
+        for (const auto& el : categorized(landmarks, keyframes)) out.push_back(el.first);
+        return out;
+    }
     std::map<LandmarkId, Category> getCategorizedSelection(const LandmarkMap& lms, const KeyframeMap& keyframes) const override {
         std::map<LandmarkId, Category> out;
+        for (const auto& el : categorized(lms, keyframes)) out.insert(out.end(), el);
+        return out;
+    }
+    std::vector<std::pair<LandmarkId, Category>> getCategorizedSelectionSorted(const LandmarkView& lms, const KeyframeMap& keyframes) const override {
+        return categorized(lms, keyframes);
+    }
+
+    template <class Range>  // a LandmarkMap or a LandmarkView; returns (id, category) sorted by id
+    std::vector<std::pair<LandmarkId, Category>> categorized(const Range& lms, const KeyframeMap& keyframes) const {
+        std::vector<std::pair<LandmarkId, Category>> out;
         if (keyframes.empty()) return out;
         const auto newest = std::max_element(keyframes.cbegin(), keyframes.cend(), [](const auto& a, const auto& b) {
             return a.second->timestamp_ < b.second->timestamp_;
@@ -239,10 +253,12 @@ public:
             c0 = c1;
         }
         const auto flow = landmark_helpers::calcFlow(ids_near, keyframes, false);
-        for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, ids_near, flow)) out[id] = Category::NearField;
+        for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, ids_near, flow)) out.push_back({id, Category::NearField});
         for (const auto& id : landmark_helpers::chooseMiddleLmIds(params_.max_num_landmarks_middle, ids_middle, newest->second->timestamp_))
-            out[id] = Category::MiddleField;
-        for (const auto& id : landmark_helpers::chooseFarLmIds(params_.max_num_landmarks_far, ids_far, keyframes)) out[id] = Category::FarField;
+            out.push_back({id, Category::MiddleField});
+        for (const auto& id : landmark_helpers::chooseFarLmIds(params_.max_num_landmarks_far, ids_far, keyframes)) out.push_back({id, Category::FarField});
+        // (the three fields are disjoint; a std::map filled in this order kept the LAST category of an id - none repeats)
+        std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         return out;
     }
 
@@ -265,14 +281,22 @@ public:
     explicit LandmarkSelectionSchemeAddDepth(Parameters p) : params_(p) {}
 
     std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
-        std::set<LandmarkId> out;
+        const std::vector<LandmarkId> v = picked(landmarks, keyframes);
+        return std::set<LandmarkId>(v.begin(), v.end());
+    }
+    std::vector<LandmarkId> getSelectionSorted(const LandmarkView& landmarks, const KeyframeMap& keyframes) const override {
+        return picked(landmarks, keyframes);
+    }
+    template <class Range>  // a LandmarkMap or a LandmarkView; returns the picked ids, sorted, each once
+    std::vector<LandmarkId> picked(const Range& landmarks, const KeyframeMap& keyframes) const {
+        std::vector<LandmarkId> out;
         std::vector<Keyframe::ConstPtr> kfs;  // active keyframes, oldest first
         for (const auto& kf : keyframes)
             if (kf.second->is_active_) kfs.push_back(kf.second);
         std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
         // the landmarks every configuration's predicate lets through, collected in ONE pass over the landmark map
         const size_t n_cfg = params_.params_per_keyframe.size();
-        std::vector<std::vector<LandmarkMap::const_iterator>> qualifies(n_cfg);
+        std::vector<std::vector<typename Range::const_iterator>> qualifies(n_cfg);
         for (auto it = landmarks.cbegin(); it != landmarks.cend(); ++it)
             for (size_t c = 0; c < n_cfg; ++c) {
                 const FrameIndex ind = std::get<0>(params_.params_per_keyframe[c]);
@@ -316,8 +340,10 @@ public:
                 return a.second < b.second || (a.second == b.second && a.first < b.first);
             });
             const int n = std::min(std::get<1>(el), (int)keyed.size());
-            for (int i = 0; i < n; ++i) out.insert(keyed[i].first);
+            for (int i = 0; i < n; ++i) out.push_back(keyed[i].first);
         }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
         return out;
     }
     static LandmarkSelectionSchemeBase::ConstPtr createConst(Parameters p) { return std::make_shared<const LandmarkSelectionSchemeAddDepth>(p); }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <iterator>
 #include <random>
 #include <string>
 
@@ -15,12 +16,29 @@
 
 namespace keyframe_bundle_adjustment {
 
+// The same landmarks as a LandmarkMap, as a vector sorted by id (entries carry the member names of a map entry).  The selector
+// hands the landmarks from scheme to scheme in this form: every std::map / std::set of ~3000 landmarks that the map-based
+// interface makes it build costs 0.2 - 0.3 ms of node allocations per solve(), and there were a dozen of them.
+struct LandmarkEntry {
+    LandmarkId first;
+    Landmark::ConstPtr second;
+};
+using LandmarkView = std::vector<LandmarkEntry>;
+
 class LandmarkSchemeBase {
 public:
     using LandmarkMap = std::map<LandmarkId, Landmark::ConstPtr>;
     using KeyframeMap = std::map<KeyframeId, Keyframe::ConstPtr>;
     virtual ~LandmarkSchemeBase() = default;
     virtual std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const = 0;
+    // The same selection from / as sorted vectors - what LandmarkSelector calls.  A scheme that only implements the reference's
+    // interface above is served by this default (it builds the map for it); the schemes of this package override it.
+    virtual std::vector<LandmarkId> getSelectionSorted(const LandmarkView& landmarks, const KeyframeMap& keyframes) const {
+        LandmarkMap m;
+        for (const auto& e : landmarks) m.insert(m.end(), {e.first, e.second});
+        const std::set<LandmarkId> s = getSelection(m, keyframes);
+        return std::vector<LandmarkId>(s.begin(), s.end());
+    }
     std::string identifier = "";
 };
 struct LandmarkSelectionSchemeBase : LandmarkSchemeBase {  // landmarks that MUST be taken
@@ -43,6 +61,14 @@ public:
     virtual ~LandmarkCategorizatonInterface() = default;
     virtual std::map<LandmarkId, Category> getCategorizedSelection(const LandmarkSchemeBase::LandmarkMap& landmarks,
                                                                    const LandmarkSchemeBase::KeyframeMap& keyframes) const = 0;
+    // (id, category) sorted by id, from a sorted vector (see LandmarkSchemeBase::getSelectionSorted)
+    virtual std::vector<std::pair<LandmarkId, Category>> getCategorizedSelectionSorted(const LandmarkView& landmarks,
+                                                                                      const LandmarkSchemeBase::KeyframeMap& keyframes) const {
+        LandmarkSchemeBase::LandmarkMap m;
+        for (const auto& e : landmarks) m.insert(m.end(), {e.first, e.second});
+        const auto c = getCategorizedSelection(m, keyframes);
+        return std::vector<std::pair<LandmarkId, Category>>(c.begin(), c.end());
+    }
 };
 
 // landmark_selection_scheme_cheirality.cpp:22-60: keep a landmark iff it lies in front (z >= 0) of every camera
@@ -50,6 +76,14 @@ public:
 class LandmarkRejectionSchemeCheirality : public LandmarkRejectionSchemeBase {
 public:
     std::set<LandmarkId> getSelection(const LandmarkMap& landmarks, const KeyframeMap& keyframes) const override {
+        const std::vector<LandmarkId> v = kept(landmarks, keyframes);
+        return std::set<LandmarkId>(v.begin(), v.end());
+    }
+    std::vector<LandmarkId> getSelectionSorted(const LandmarkView& landmarks, const KeyframeMap& keyframes) const override {
+        return kept(landmarks, keyframes);
+    }
+    template <class Range>  // a LandmarkMap or a LandmarkView: entries (first = id, second = landmark) in id order
+    static std::vector<LandmarkId> kept(const Range& landmarks, const KeyframeMap& keyframes) {
         // Same test as Keyframe::getProjectedLandmarkPosition per (landmark, keyframe) - camera <- vehicle <- origin applied
         // to the landmark, z < 0 rejects - as ONE merge pass per keyframe over its measurements and the landmarks (both
         // sorted by id), the keyframe's and the cameras' transforms formed once: the per-pair std::map the accessor
@@ -80,10 +114,11 @@ public:
                 }
             }
         }
-        std::set<LandmarkId> out;
+        std::vector<LandmarkId> out;
+        out.reserve(landmarks.size());
         size_t i = 0;
         for (const auto& lm : landmarks) {
-            if (!bad[i]) out.insert(out.end(), lm.first);
+            if (!bad[i]) out.push_back(lm.first);
             ++i;
         }
         return out;
@@ -123,23 +158,45 @@ public:
     // landmark_selector.hpp:118-253: drop flagged outliers, apply every rejection scheme (set shrinks), collect the
     // must-have selections, sparsify the rest, union, remember what was not selected.
     std::set<LandmarkId> select(const LandmarkMap& landmarks, const KeyframeMap& kfs) {
+        LandmarkView view;
+        view.reserve(landmarks.size());
+        for (const auto& el : landmarks) view.push_back({el.first, el.second});
+        return select(view, kfs);
+    }
+    // The same on a sorted vector of (id, landmark) - what BundleAdjusterKeyframes::solve() calls (no std::map of the active
+    // landmarks is built for it).  Between the schemes the landmarks travel as sorted vectors (LandmarkSchemeBase::
+    // getSelectionSorted); the decisions are those of the map-based statements, id for id.
+    std::set<LandmarkId> select(const LandmarkView& landmarks, const KeyframeMap& kfs) {
         using clk = std::chrono::steady_clock;
         static const bool trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;
         const auto t0 = clk::now();
-        LandmarkMap pool;
-        for (const auto& el : landmarks)
-            if (!outlier_ids_.count(el.first)) pool.insert(pool.end(), el);
-        for (const auto& scheme : rejection_schemes_) pool = restrict(landmarks, run(scheme, pool, kfs));
+        LandmarkView pool;
+        if (outlier_ids_.empty()) {
+            pool = landmarks;
+        } else {
+            pool.reserve(landmarks.size());
+            auto io = outlier_ids_.cbegin();
+            for (const auto& el : landmarks) {
+                while (io != outlier_ids_.cend() && *io < el.first) ++io;
+                if (io == outlier_ids_.cend() || *io != el.first) pool.push_back(el);
+            }
+        }
+        for (const auto& scheme : rejection_schemes_) pool = restrict(pool, run(scheme, pool, kfs));
         const auto t1 = clk::now();
-        LandmarkMap must;
-        for (const auto& scheme : selection_schemes_)
-            for (const auto& el : restrict(pool, run(scheme, pool, kfs))) must[el.first] = el.second;
+        std::vector<LandmarkId> must;  // sorted union of the selection schemes' picks (all inside pool)
+        for (const auto& scheme : selection_schemes_) {
+            const std::vector<LandmarkId> ids = ids_of(restrict(pool, run(scheme, pool, kfs)));
+            std::vector<LandmarkId> u;
+            u.reserve(must.size() + ids.size());
+            std::set_union(must.begin(), must.end(), ids.begin(), ids.end(), std::back_inserter(u));
+            must.swap(u);
+        }
         const auto t2 = clk::now();
-        // thin = pool passed through every sparsification scheme in turn (the first one reads pool itself: no copy of the map)
-        LandmarkMap thin_store;
-        const LandmarkMap* thin = &pool;
+        // thin = pool passed through every sparsification scheme in turn
+        LandmarkView thin_store;
+        const LandmarkView* thin = &pool;
         for (const auto& scheme : sparsification_schemes_) {
-            LandmarkMap next = restrict(pool, run(scheme, *thin, kfs));
+            LandmarkView next = restrict(pool, run(scheme, *thin, kfs));
             thin_store.swap(next);
             thin = &thin_store;
         }
@@ -150,11 +207,11 @@ public:
             auto ia = thin->cbegin();
             auto ib = must.cbegin();
             while (ia != thin->cend() || ib != must.cend()) {
-                if (ib == must.cend() || (ia != thin->cend() && ia->first < ib->first)) {
+                if (ib == must.cend() || (ia != thin->cend() && ia->first < *ib)) {
                     selection.insert(selection.end(), ia->first);
                     ++ia;
-                } else if (ia == thin->cend() || ib->first < ia->first) {
-                    selection.insert(selection.end(), ib->first);
+                } else if (ia == thin->cend() || *ib < ia->first) {
+                    selection.insert(selection.end(), *ib);
                     ++ib;
                 } else {
                     selection.insert(selection.end(), ia->first);
@@ -240,6 +297,11 @@ public:
     }
     const std::map<LandmarkId, unsigned int>& getUnselectedLandmarks() const { return unselected_lms_; }
     const std::map<LandmarkId, LandmarkCategorizatonInterface::Category>& getLandmarkCategories() const {
+        if (categories_stale_) {  // (the map is built when somebody asks for it, not in every solve())
+            landmark_categories_.clear();
+            for (const auto& el : categories_) landmark_categories_.insert(landmark_categories_.end(), el);
+            categories_stale_ = false;
+        }
         return landmark_categories_;
     }
     const std::set<LandmarkId>& getLastSelection() const { return last_selected_lms_; }
@@ -268,17 +330,20 @@ private:
         return from;
     }
     template <typename S>
-    std::set<LandmarkId> run(const std::shared_ptr<const S>& scheme, const LandmarkMap& lms, const KeyframeMap& kfs) {
+    std::vector<LandmarkId> run(const std::shared_ptr<const S>& scheme, const LandmarkView& lms, const KeyframeMap& kfs) {
         auto cat = std::dynamic_pointer_cast<const LandmarkCategorizatonInterface>(scheme);
-        if (!cat) return scheme->getSelection(lms, kfs);
-        landmark_categories_ = cat->getCategorizedSelection(lms, kfs);
-        std::set<LandmarkId> out;
-        for (const auto& el : landmark_categories_) out.insert(out.end(), el.first);
+        if (!cat) return scheme->getSelectionSorted(lms, kfs);
+        categories_ = cat->getCategorizedSelectionSorted(lms, kfs);
+        categories_stale_ = true;
+        std::vector<LandmarkId> out;
+        out.reserve(categories_.size());
+        for (const auto& el : categories_) out.push_back(el.first);
         return out;
     }
     // the entries of `all` whose id is in `ids` (both sorted: one merge pass, appended in order)
-    static LandmarkMap restrict(const LandmarkMap& all, const std::set<LandmarkId>& ids) {
-        LandmarkMap out;
+    static LandmarkView restrict(const LandmarkView& all, const std::vector<LandmarkId>& ids) {
+        LandmarkView out;
+        out.reserve(std::min(all.size(), ids.size()));
         auto ia = all.cbegin();
         auto ii = ids.cbegin();
         while (ia != all.cend() && ii != ids.cend()) {
@@ -287,11 +352,17 @@ private:
             else if (*ii < ia->first)
                 ++ii;
             else {
-                out.insert(out.end(), *ia);
+                out.push_back(*ia);
                 ++ia;
                 ++ii;
             }
         }
+        return out;
+    }
+    static std::vector<LandmarkId> ids_of(const LandmarkView& v) {
+        std::vector<LandmarkId> out;
+        out.reserve(v.size());
+        for (const auto& e : v) out.push_back(e.first);
         return out;
     }
     std::map<LandmarkId, unsigned int> unselected_lms_;
@@ -299,7 +370,9 @@ private:
     std::deque<std::pair<TimestampNSec, LandmarkId>> marks_;  // every markUnselected call, oldest first
     bool marks_in_time_order_ = true;
     std::set<LandmarkId> last_selected_lms_;
-    std::map<LandmarkId, LandmarkCategorizatonInterface::Category> landmark_categories_;
+    std::vector<std::pair<LandmarkId, LandmarkCategorizatonInterface::Category>> categories_;  // of the last categorising scheme, by id
+    mutable std::map<LandmarkId, LandmarkCategorizatonInterface::Category> landmark_categories_;  // the same as the map the API returns
+    mutable bool categories_stale_ = false;
 };
 
 }  // namespace keyframe_bundle_adjustment
