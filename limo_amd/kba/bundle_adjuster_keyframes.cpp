@@ -447,14 +447,15 @@ void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmar
             }
         }
     }
-    {
-        std::set<LandmarkId> still_active;
+    {   // the ids nobody measures any more leave the set in place (a few hundred of ~3000 when a keyframe drops out of the window:
+        // rebuilding the set allocated a node for every id that STAYS)
         size_t i = 0;
-        for (const auto& id : active_landmark_ids_) {
-            if (keep[i]) still_active.insert(still_active.end(), id);
-            ++i;
+        for (auto it = active_landmark_ids_.begin(); it != active_landmark_ids_.end(); ++i) {
+            if (keep[i])
+                ++it;
+            else
+                it = active_landmark_ids_.erase(it);
         }
-        active_landmark_ids_.swap(still_active);
     }
     // oldest active keyframe fixes the gauge, second oldest carries the scale prior (:962-986)
     auto rest = getSortedIdsWithActiveKeyframePtrs();
@@ -495,7 +496,7 @@ struct Flat {
                              ? LIMO_FIX_POSE
                              : kf.fixation_status_ == Keyframe::FixationStatus::Scale ? LIMO_FIX_SCALE : LIMO_FIX_NONE);
     }
-    void add_observations(int k, const Keyframe& kf, const std::map<LandmarkId, int>& lm_index) {
+    void add_observations(int k, const Keyframe& kf, const std::vector<std::pair<LandmarkId, int>>& lm_index) {
         const size_t room = obs_kf.size() + lm_index.size();
         obs_kf.reserve(room);
         obs_lm.reserve(room);
@@ -587,12 +588,12 @@ std::string BundleAdjusterKeyframes::solve() {
 
     Flat F;
     for (const auto& id : active_keyframe_ids_) F.add_keyframe(*keyframes_.at(id));
-    std::map<LandmarkId, int> lm_index;
+    std::vector<std::pair<LandmarkId, int>> lm_index;  // (selected ids come in id order: sorted as built)
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
         auto it = known.find(id);
         if (it == landmarks_.cend()) continue;
-        lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
+        lm_index.push_back({id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
         F.lm_w.push_back(it->second->weight);
@@ -633,12 +634,12 @@ std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
     selected_landmark_ids_ = landmark_selector_->getLastSelection();  // :828
     Flat F;
     F.add_keyframe(kf);
-    std::map<LandmarkId, int> lm_index;
+    std::vector<std::pair<LandmarkId, int>> lm_index;  // (selected ids come in id order: sorted as built)
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
         auto it = known.find(id);
         if (it == landmarks_.cend()) continue;
-        lm_index.insert(lm_index.end(), {id, (int)F.lms.size()});
+        lm_index.push_back({id, (int)F.lms.size()});
         F.lms.push_back(it->second.get());
         for (int i = 0; i < 3; ++i) F.lm_pos.push_back(it->second->pos[i]);
         F.lm_w.push_back(it->second->weight);

@@ -222,80 +222,65 @@ public:
         }
         const auto t4 = clk::now();
         if (!kfs.empty()) {
+            // markUnselected(id, newest) for every landmark that was not selected, then clean(newest - 10 s)
+            // (landmark_selector.hpp:226-252) - as ONE merge pass: landmarks, selection and the bookkeeping entries are all sorted
+            // by id; entries last marked more than ten seconds ago are dropped on the way.  (Two std::maps with a lookup each per
+            // unselected landmark and a queue of the marks were 0.5 ms of every solve().)
             TimestampNSec newest = 0;
             for (const auto& kf : kfs) newest = std::max(newest, kf.second->timestamp_);
-            auto is = selection.cbegin();  // (landmarks and selection are both sorted by id: one merge pass ...
-            auto iu = unselected_lms_.begin();
-            auto it = last_time_seen_.begin();
-            bool first = true;
+            const TimestampNSec ten_s = convert(TimestampSec(10.));
+            const TimestampNSec oldest = newest > ten_s ? newest - ten_s : 0;
+            std::vector<Unselected> merged;
+            merged.reserve(unselected_.size() + landmarks.size());
+            auto is = selection.cbegin();
+            auto iu = unselected_.cbegin();
             for (const auto& lm : landmarks) {
                 while (is != selection.cend() && *is < lm.first) ++is;
                 if (is != selection.cend() && *is == lm.first) continue;
-                // ... and the two bookkeeping maps are entered at / next to the previous position: markUnselected(lm.first,
-                // newest) without a descent from the root per landmark)
                 const LandmarkId id = lm.first;
-                if (first) {
-                    iu = unselected_lms_.lower_bound(id);
-                    it = last_time_seen_.lower_bound(id);
-                    first = false;
+                for (; iu != unselected_.cend() && iu->id < id; ++iu)
+                    if (!(iu->last_seen < oldest)) merged.push_back(*iu);
+                if (iu != unselected_.cend() && iu->id == id) {
+                    merged.push_back({id, iu->count + 1, newest});
+                    ++iu;
                 } else {
-                    iu = advance_to(unselected_lms_, iu, id);
-                    it = advance_to(last_time_seen_, it, id);
+                    merged.push_back({id, 1u, newest});
                 }
-                if (iu == unselected_lms_.end() || iu->first != id) iu = unselected_lms_.emplace_hint(iu, id, 0u);
-                iu->second += 1;
-                if (it == last_time_seen_.end() || it->first != id) it = last_time_seen_.emplace_hint(it, id, newest);
-                it->second = newest;
-                if (!marks_.empty() && newest < marks_.back().first) marks_in_time_order_ = false;
-                marks_.push_back({newest, id});
             }
-            const TimestampNSec ten_s = convert(TimestampSec(10.));
-            clean(newest > ten_s ? newest - ten_s : 0);
+            for (; iu != unselected_.cend(); ++iu)
+                if (!(iu->last_seen < oldest)) merged.push_back(*iu);
+            unselected_.swap(merged);
+            unselected_stale_ = true;
         }
         last_selected_lms_ = selection;
         if (trace) {
             auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
             std::fprintf(stderr, "[shim] select: rejection %.0f us, must-have %.0f us, sparsification %.0f us, union %.0f us, unselected bookkeeping %.0f us (%zu tracked)\n",
-                         us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, clk::now()), last_time_seen_.size());
+                         us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, clk::now()), unselected_.size());
         }
         return selection;
     }
 
     void markUnselected(LandmarkId lm_id, TimestampNSec last_time_seen) {
-        unselected_lms_[lm_id] += 1;
-        last_time_seen_[lm_id] = last_time_seen;
-        if (!marks_.empty() && last_time_seen < marks_.back().first) marks_in_time_order_ = false;
-        marks_.push_back({last_time_seen, lm_id});
+        auto it = std::lower_bound(unselected_.begin(), unselected_.end(), lm_id, [](const Unselected& u, LandmarkId id) { return u.id < id; });
+        if (it == unselected_.end() || it->id != lm_id) it = unselected_.insert(it, {lm_id, 0u, last_time_seen});
+        it->count += 1;
+        it->last_seen = last_time_seen;
+        unselected_stale_ = true;
     }
-    // Forget the landmarks last marked before `oldest` (landmark_selector.hpp:240-252).  The marks are also kept as a queue
-    // in the order they were made - time order, the callers' stamps only grow -, so the expired ones are at its front:
-    // a scan of the whole map per call (15 k landmarks after ten seconds of driving) was 1 ms of every solve().
+    // Forget the landmarks last marked before `oldest` (landmark_selector.hpp:240-252).
     void clean(TimestampNSec oldest) {
-        if (!marks_in_time_order_) {  // (marks with a decreasing stamp: fall back to the full scan, then start over)
-            for (auto it = last_time_seen_.begin(); it != last_time_seen_.end();) {
-                if (it->second < oldest) {
-                    unselected_lms_.erase(it->first);
-                    it = last_time_seen_.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            marks_.clear();
-            for (const auto& el : last_time_seen_) marks_.push_back({el.second, el.first});
-            std::sort(marks_.begin(), marks_.end());
-            marks_in_time_order_ = true;
-            return;
-        }
-        while (!marks_.empty() && marks_.front().first < oldest) {
-            const auto it = last_time_seen_.find(marks_.front().second);
-            if (it != last_time_seen_.end() && it->second < oldest) {  // (not marked again since)
-                unselected_lms_.erase(it->first);
-                last_time_seen_.erase(it);
-            }
-            marks_.pop_front();
-        }
+        unselected_.erase(std::remove_if(unselected_.begin(), unselected_.end(), [&](const Unselected& u) { return u.last_seen < oldest; }), unselected_.end());
+        unselected_stale_ = true;
     }
-    const std::map<LandmarkId, unsigned int>& getUnselectedLandmarks() const { return unselected_lms_; }
+    const std::map<LandmarkId, unsigned int>& getUnselectedLandmarks() const {
+        if (unselected_stale_) {  // (the map the API returns is built when somebody asks for it)
+            unselected_lms_.clear();
+            for (const auto& u : unselected_) unselected_lms_.insert(unselected_lms_.end(), {u.id, u.count});
+            unselected_stale_ = false;
+        }
+        return unselected_lms_;
+    }
     const std::map<LandmarkId, LandmarkCategorizatonInterface::Category>& getLandmarkCategories() const {
         if (categories_stale_) {  // (the map is built when somebody asks for it, not in every solve())
             landmark_categories_.clear();
@@ -319,16 +304,6 @@ public:
     std::set<LandmarkId> outlier_ids_;
 
 private:
-    // first entry of m with key >= id, reached from `from` (an entry with a smaller or equal key) by a short walk if it is near
-    template <class M>
-    static typename M::iterator advance_to(M& m, typename M::iterator from, LandmarkId id) {
-        int steps = 0;
-        while (from != m.end() && from->first < id) {
-            ++from;
-            if (++steps > 32) return m.lower_bound(id);
-        }
-        return from;
-    }
     template <typename S>
     std::vector<LandmarkId> run(const std::shared_ptr<const S>& scheme, const LandmarkView& lms, const KeyframeMap& kfs) {
         auto cat = std::dynamic_pointer_cast<const LandmarkCategorizatonInterface>(scheme);
@@ -365,10 +340,14 @@ private:
         for (const auto& e : v) out.push_back(e.first);
         return out;
     }
-    std::map<LandmarkId, unsigned int> unselected_lms_;
-    std::map<LandmarkId, TimestampNSec> last_time_seen_;
-    std::deque<std::pair<TimestampNSec, LandmarkId>> marks_;  // every markUnselected call, oldest first
-    bool marks_in_time_order_ = true;
+    struct Unselected {
+        LandmarkId id;
+        unsigned int count;      // how often it was passed over
+        TimestampNSec last_seen; // stamp of the newest keyframe when it last was
+    };
+    std::vector<Unselected> unselected_;  // sorted by id
+    mutable std::map<LandmarkId, unsigned int> unselected_lms_;
+    mutable bool unselected_stale_ = false;
     std::set<LandmarkId> last_selected_lms_;
     std::vector<std::pair<LandmarkId, LandmarkCategorizatonInterface::Category>> categories_;  // of the last categorising scheme, by id
     mutable std::map<LandmarkId, LandmarkCategorizatonInterface::Category> landmark_categories_;  // the same as the map the API returns
