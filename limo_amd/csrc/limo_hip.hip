@@ -557,6 +557,26 @@ struct limo_ba_batch : Executor {
         listed = n_wl_win;
     }
 
+    // k_lin_lm at 3 waves / SIMD.  Occupancy experiment (read once): KBA_LIN_WAVES=4 takes the 128-register build (spills 44 B),
+    // KBA_LIN_LDS_PAD=<bytes> adds dynamic LDS per workgroup (80000: two workgroups per CU = 2 waves / SIMD).
+    void launch_lin_lm(int grid, hipStream_t s, const BatchView& v, const int32_t* wl) {
+        static const int lw = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
+        static const int pad = std::getenv("KBA_LIN_LDS_PAD") ? std::atoi(std::getenv("KBA_LIN_LDS_PAD")) : 0;
+        const int lds = lin_lm_lds_bytes(P.Vmax) + pad;
+        if (pad) {
+            static bool once = false;
+            if (!once) {
+                once = true;
+                (void)hipFuncSetAttribute((const void*)k_lin_lm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute((const void*)k_lin_lm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            }
+        }
+        if (lw == 4)
+            hipLaunchKernelGGL(k_lin_lm<4>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
+        else
+            hipLaunchKernelGGL(k_lin_lm<3>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
+    }
+
     void solve_init(int max_iter, int select) override {
         it_no = 0;
         first_lin = true;  // the next linearisation defines the Jacobi scaling (WinState::compute_scale)
@@ -592,7 +612,7 @@ struct limo_ba_batch : Executor {
             EventPair* ep = timed(LIMO_KERNEL_LINEARIZE);
             for (size_t i = 0; i < pv.size(); ++i)
                 if (count_lblk(i)) {
-                    hipLaunchKernelGGL(k_lin_lm<3>, dim3(count_lblk(i)), dim3(kBlock), lin_lm_lds_bytes(P.Vmax), s, pv[i], c, list_lblk(i));
+                    launch_lin_lm(count_lblk(i), s, pv[i], list_lblk(i));
                     LAUNCH_CHECK("k_lin_lm");
                 }
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
@@ -868,7 +888,7 @@ struct limo_ba_batch : Executor {
         hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
         {
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_LINEARIZE, s) : nullptr;
-            if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lin_lm<3>, dim3(cap[SL_LBLK]), dim3(kBlock), lin_lm_lds_bytes(P.Vmax), s, sv, c, L(SL_LBLK));
+            if (cap[SL_LBLK]) launch_lin_lm(cap[SL_LBLK], s, sv, L(SL_LBLK));
             if (ep) note(hipEventRecord(ep->b, s), "hipEventRecord");
         }
         hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
