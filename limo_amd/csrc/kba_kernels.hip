@@ -748,7 +748,9 @@ __device__ __forceinline__ void schur_wave_sync() {
 template <int TM, bool GP, bool COOP>
 __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, int span, int span_gp, double* smem) {
     const int w = bv.sblk_win[sb];
-    if (!bv.st[w].active) return;
+    // (COOP: k_solve_coop only gets here for a window that iterates - and workgroup 0 may be writing the window's LM state at
+    // this very moment (lm_decide_lin runs beside the Schur phase), so the state is not read here)
+    if (!COOP && !bv.st[w].active) return;
     const WinDesc& wd = bv.win[w];
     const int nfq = wd.nfq, nfp = wd.nf_pad;
     const int ncol = GP ? wd.nf + 1 : nfq + 1;  // columns of the tile, the rhs (column nfq) included
@@ -1703,7 +1705,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 if (scale_first) {
                     KBA_GSYNC();
                     KBA_CTICK(3);
-                    schur_phase(0);
+                    if (st.active) schur_phase(0);  // (behind the barrier: lm_decide_lin has finished writing the state)
                 } else {
                     // ... and they also sum the slabs while workgroup 0 is still assembling (the camera system takes longer
                     // than the Schur complement): a barrier among the workgroups 1 .. G - 1 only
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 KBA_CTICK(13);
                 KBA_GSYNC();
                 KBA_CTICK(1);
-                schur_phase(0);
+                if (st.active) schur_phase(0);  // (nobody writes the LM state in this phase; a window that is not selected for this solve idles)
                 KBA_CTICK(4);
             }
             KBA_GSYNC();
