@@ -88,8 +88,12 @@ def test_weakly_determined_windows_stay_inside_the_oracles_own_spread(oracle, em
     assert ok, "window %d: %s" % (idx, detail)
 
 
+# LIMO_FUZZ_EXTRA="seed:n[,seed:n]" adds sweeps with fresh seeds (one-off evidence after kernel changes; profiles/r04_fuzz_*.log)
+_SWEEPS = [(123, 290), (77, 60), (2026, 240)] + [tuple(int(x) for x in e.split(":")) for e in os.environ.get("LIMO_FUZZ_EXTRA", "").split(",") if e]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n", [(123, 290), (77, 60), (2026, 240)])
+@pytest.mark.parametrize("seed,n", _SWEEPS)
 def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
     from limo_amd import ba
 
