@@ -208,16 +208,18 @@ int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int6
 /*
  * Landmark-sharded solve of ONE (large) window, SURVEY §8e / BASELINE.json configs[3]: shard s owns the landmarks
  * whose index in the window satisfies  index mod n_shards == s  together with all their observations and
- * ground-plane rows; camera-side parameters are replicated.  Per LM iteration the shards exchange their partial
- * camera blocks (U_k, g_k, cost), Schur-complement slabs and step-norm parts in THREE all-reduces - one packed,
- * contiguous buffer per exchange point, before the camera assembly, the camera solve and the step decision (one more
- * per trimming round, one at the end for the landmarks) -, then every shard factors the reduced camera system
- * redundantly and back-substitutes its own landmarks.  Every partial entry
- * has exactly one owner, so the sum is exact and the result does not depend on the reduction order.
+ * ground-plane rows; camera-side parameters are replicated.  Per LM iteration a shard contributes ONE contiguous block -
+ * its camera-side sums per view, its ground-plane rows folded per keyframe (F^T F | F^T r) and the entries of [S | rhs] the
+ * camera solve reads (upper triangle of the free slots + rhs): 42 KB for a 10-keyframe / 8000-landmark window - exchanged
+ * by ONE all-gather before camera assembly + camera solve (two pieces of it in the first iteration of a solve, where the
+ * assembly defines the Jacobi scale the Schur complement needs), and nine doubles by a second all-gather before the step
+ * decision; one all-reduce per trimming round and one at the end for the landmarks.  Then every shard factors the reduced
+ * camera system redundantly and back-substitutes its own landmarks.  Nothing is summed on the wire: every rank adds the P
+ * contributions in shard order, so the result does not depend on how the shards are spread over ranks.
  *   - with a communicator (limo_ctx_comm_init): one process per GPU, shard s lives on rank s mod world (n_shards a
- *     multiple of world, normally == world); every rank calls with the same window; the exchange is a local sum
- *     over the rank's shards followed by an RCCL all-reduce; all ranks return the full result;
- *   - without: n_shards (<= 8) VIRTUAL shards on this GPU - the same kernels, the exchange is the local sum only
+ *     multiple of world, normally == world); every rank calls with the same window; the exchange is an RCCL
+ *     all-gather of the blocks (one call per local shard); all ranks return the full result;
+ *   - without: n_shards (<= 8) VIRTUAL shards on this GPU - the same kernels, the same blocks, no wire
  *     (the single-GPU mode SURVEY §8e asks for to check the sharding arithmetic).
  * Replaces the same reference call as limo_ba_solve (bundle_adjuster_keyframes.cpp:629-767).
  */
@@ -226,8 +228,8 @@ int limo_comm_unique_id(unsigned char id[LIMO_COMM_ID_BYTES]);            /* ran
 int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES], int rank, int world);
 int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
                           limo_ba_report* report);
-/* Exchange accounting of the last limo_ba_solve_sharded on this context: stats3 = (exchange steps = all-reduce calls
- * with a communicator, bytes entering them on this rank, LM iterations of the solve). */
+/* Exchange accounting of the last limo_ba_solve_sharded on this context: stats3 = (exchange steps = collective calls with a
+ * communicator, counted per local shard; bytes this rank's shards put into them; LM iterations of the solve). */
 int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3);
 /* How many one-launch solves (k_solve_coop behind limo_ba_solve / small batches) on this context gave up at a device-wide
  * barrier and were redone as a launch sequence.  A barrier waits at most KBA_COOP_TIMEOUT_MS (default 2000) of the GPU's
