@@ -402,8 +402,12 @@ public:
         }
         std::vector<LandmarkId> near = landmark_helpers::chooseNearLmIds(b.max_num_landmarks_near, near_d, flow);
         for (const auto& id : landmark_helpers::chooseNearLmIds(b.max_num_landmarks_near - near.size(), near_n, flow)) near.push_back(id);
-        std::vector<LandmarkId> mid = landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle, mid_d);
-        for (const auto& id : landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle - mid.size(), mid_n)) mid.push_back(id);
+        // (the random subset is drawn afresh per solve, like the reference's shuffle: the newest keyframe's stamp is the seed - with a
+        // fixed seed the same ids would win for a whole drive)
+        TimestampNSec newest = 0;
+        for (const auto& kf : keyframes) newest = std::max(newest, kf.second->timestamp_);
+        std::vector<LandmarkId> mid = landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle, mid_d, newest);
+        for (const auto& id : landmark_helpers::chooseMiddleLmIds(b.max_num_landmarks_middle - mid.size(), mid_n, newest)) mid.push_back(id);
         for (const auto& id : near) out[id] = Category::NearField;
         for (const auto& id : mid) out[id] = Category::MiddleField;
         for (const auto& id : landmark_helpers::chooseFarLmIds(b.max_num_landmarks_far, far, keyframes)) out[id] = Category::FarField;
