@@ -281,6 +281,12 @@ private:
             if (h.size() > 16) h.erase(h.begin());
             for (size_t k = 1; k < tr.feature_points.size() && k < ts.stamps.size(); ++k) {
                 if (tr.feature_points[k].d >= 0.f) continue;
+                // (a track seen in consecutive frames has the entry of stamps[k] k places from the end: looked at first; stamps are
+                // unique inside a history, so the scan below finds the same entry or none)
+                if (k < h.size() && h[h.size() - 1 - k].first == ts.stamps[k]) {
+                    tr.feature_points[k].d = h[h.size() - 1 - k].second;
+                    continue;
+                }
                 for (const auto& e : h)
                     if (e.first == ts.stamps[k]) tr.feature_points[k].d = e.second;
             }
