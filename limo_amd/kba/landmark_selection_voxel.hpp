@@ -90,6 +90,87 @@ inline std::map<LandmarkId, double> calcFlow(const std::vector<LandmarkId>& ids,
     return calcFlow(ids, kfs, use_mean);
 }
 
+// calcFlow for ids SORTED ascending, as (id, flow) in id order: per keyframe ONE merge pass over its measurements and the ids
+// instead of a map lookup per (id, keyframe) - same keyframe order, same camera order, same sums as above.
+inline std::vector<std::pair<LandmarkId, double>> calcFlowSorted(const std::vector<LandmarkId>& ids_sorted,
+                                                                 const std::map<KeyframeId, Keyframe::ConstPtr>& keyframes, bool use_mean) {
+    std::vector<Keyframe::ConstPtr> kfs;
+    for (const auto& k : keyframes) kfs.push_back(k.second);
+    std::sort(kfs.begin(), kfs.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });
+    struct PerCam {
+        CameraId cam;
+        Measurement last;
+        double sum;
+        int cnt;
+    };
+    constexpr int kCams = 4;  // cameras that see one landmark (more: the general function takes over)
+    const size_t n = ids_sorted.size();
+    std::vector<PerCam> cams(n * kCams);
+    std::vector<unsigned char> n_cams(n, 0);
+    bool overflow = false;
+    for (const auto& kf : kfs) {
+        auto im = kf->measurements_.cbegin();
+        const auto end = kf->measurements_.cend();
+        for (size_t i = 0; i < n && im != end; ++i) {
+            const LandmarkId id = ids_sorted[i];
+            int steps = 0;
+            while (im != end && im->first < id) {
+                ++im;
+                if (++steps > 24) {  // far ahead: one descent instead of a long walk
+                    im = kf->measurements_.lower_bound(id);
+                    break;
+                }
+            }
+            if (im == end) break;
+            if (im->first != id) continue;
+            for (const auto& cm : im->second) {
+                if (!kf->cameras_.count(cm.first)) continue;
+                PerCam* pc = nullptr;
+                for (int c = 0; c < n_cams[i]; ++c)
+                    if (cams[i * kCams + c].cam == cm.first) pc = &cams[i * kCams + c];
+                if (pc) {
+                    const double du = double(pc->last.u) - double(cm.second.u), dv = double(pc->last.v) - double(cm.second.v);
+                    pc->sum += std::sqrt(du * du + dv * dv);
+                    pc->cnt += 1;
+                    pc->last = cm.second;
+                } else if (n_cams[i] < kCams) {
+                    cams[i * kCams + n_cams[i]++] = {cm.first, cm.second, 0., 0};
+                } else {
+                    overflow = true;
+                }
+            }
+        }
+    }
+    std::vector<std::pair<LandmarkId, double>> out;
+    if (overflow) {
+        for (const auto& el : calcFlow(ids_sorted, kfs, use_mean)) out.push_back(el);
+        return out;
+    }
+    out.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        double best = -1.;
+        bool any = false;
+        for (int c = 0; c < n_cams[i]; ++c) {
+            const PerCam& pc = cams[i * kCams + c];
+            if (pc.cnt == 0) continue;
+            any = true;
+            best = std::max(best, use_mean ? pc.sum / pc.cnt : pc.sum);
+        }
+        if (any) out.push_back({ids_sorted[i], best});
+    }
+    return out;
+}
+// the max_num ids of largest flow (ties by id), from (id, flow) pairs
+inline std::vector<LandmarkId> chooseNearLmIds(size_t max_num, const std::vector<std::pair<LandmarkId, double>>& flow_of_near) {
+    std::vector<std::pair<double, LandmarkId>> keyed;
+    keyed.reserve(flow_of_near.size());
+    for (const auto& el : flow_of_near) keyed.push_back({el.second, el.first});
+    std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    keyed.resize(std::min(max_num, keyed.size()));
+    std::vector<LandmarkId> ids;
+    for (const auto& k : keyed) ids.push_back(k.second);
+    return ids;
+}
 inline std::vector<LandmarkId> chooseNearLmIds(size_t max_num, const std::vector<LandmarkId>& near_ids,
                                                const std::map<LandmarkId, double>& flow) {
     std::vector<std::pair<double, LandmarkId>> keyed;  // (the flow of an id is looked up once, not in every comparison)
@@ -115,12 +196,14 @@ inline std::vector<LandmarkId> chooseMiddleLmIds(size_t max_num, const std::vect
         x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
         return x ^ (x >> 31);
     };
-    std::vector<LandmarkId> a(middle_ids);
-    std::sort(a.begin(), a.end(), [&](LandmarkId x, LandmarkId y) {
-        const uint64_t rx = rank(x), ry = rank(y);
-        return rx < ry || (rx == ry && x < y);
-    });
-    a.resize(std::min(max_num, a.size()));
+    std::vector<std::pair<uint64_t, LandmarkId>> keyed;  // (the rank of an id is computed once, not in every comparison)
+    keyed.reserve(middle_ids.size());
+    for (const auto& id : middle_ids) keyed.push_back({rank(id), id});
+    std::sort(keyed.begin(), keyed.end());
+    keyed.resize(std::min(max_num, keyed.size()));
+    std::vector<LandmarkId> a;
+    a.reserve(keyed.size());
+    for (const auto& k : keyed) a.push_back(k.second);
     return a;
 }
 inline std::vector<LandmarkId> chooseFarLmIds(size_t max_num, const std::vector<LandmarkId>& far_ids,
@@ -217,12 +300,38 @@ public:
         // voxel grid over the pipe: one representative per occupied voxel.  (voxel key, pipe index) pairs sorted by key, the
         // members of a voxel in pipe order (= landmark id order, the order their coordinates are summed in) - instead of a
         // std::map of cells with a member vector each.
-        std::vector<std::pair<std::array<long, 3>, size_t>> cells(pipe.size());
-        for (size_t i = 0; i < pipe.size(); ++i)
-            cells[i] = {{{(long)std::floor(pipe[i].p[0] / params_.voxel_size_xyz[0]), (long)std::floor(pipe[i].p[1] / params_.voxel_size_xyz[1]),
-                          (long)std::floor(pipe[i].p[2] / params_.voxel_size_xyz[2])}},
-                        i};
-        std::sort(cells.begin(), cells.end());
+        // The three cell indices packed into ONE 64-bit key that sorts like the triple (21 bits each, offset 2^20: cells within
+        // +-1e6 of the origin in every axis, i.e. 500 km at the finest 0.5 m voxel; outside that the triple itself is compared).
+        std::vector<std::pair<uint64_t, size_t>> cells(pipe.size());
+        bool packed = true;
+        auto cell_of = [&](size_t i, long* c) {
+            c[0] = (long)std::floor(pipe[i].p[0] / params_.voxel_size_xyz[0]);
+            c[1] = (long)std::floor(pipe[i].p[1] / params_.voxel_size_xyz[1]);
+            c[2] = (long)std::floor(pipe[i].p[2] / params_.voxel_size_xyz[2]);
+        };
+        for (size_t i = 0; i < pipe.size() && packed; ++i) {
+            long c[3];
+            cell_of(i, c);
+            const long off = 1l << 20;
+            packed = c[0] > -off && c[0] < off && c[1] > -off && c[1] < off && c[2] > -off && c[2] < off;
+            cells[i] = {((uint64_t)(c[0] + off) << 42) | ((uint64_t)(c[1] + off) << 21) | (uint64_t)(c[2] + off), i};
+        }
+        if (packed) {
+            std::sort(cells.begin(), cells.end());
+        } else {  // (rank the triples instead: the key becomes the triple's position in sorted order)
+            std::vector<std::pair<std::array<long, 3>, size_t>> wide(pipe.size());
+            for (size_t i = 0; i < pipe.size(); ++i) {
+                long c[3];
+                cell_of(i, c);
+                wide[i] = {{{c[0], c[1], c[2]}}, i};
+            }
+            std::sort(wide.begin(), wide.end());
+            uint64_t key = 0;
+            for (size_t q = 0; q < wide.size(); ++q) {
+                if (q > 0 && wide[q].first != wide[q - 1].first) ++key;
+                cells[q] = {key, wide[q].second};
+            }
+        }
         std::vector<LandmarkId> ids_near, ids_middle;
         for (size_t c0 = 0; c0 < cells.size();) {
             size_t c1 = c0;
@@ -252,8 +361,9 @@ public:
             (pipe[best].dist < params_.roi_middle_xyz[0] ? ids_near : ids_middle).push_back(pipe[best].id);
             c0 = c1;
         }
-        const auto flow = landmark_helpers::calcFlow(ids_near, keyframes, false);
-        for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, ids_near, flow)) out.push_back({id, Category::NearField});
+        std::sort(ids_near.begin(), ids_near.end());  // (voxel order so far; the choice below does not depend on the order)
+        const auto flow = landmark_helpers::calcFlowSorted(ids_near, keyframes, false);
+        for (const auto& id : landmark_helpers::chooseNearLmIds(params_.max_num_landmarks_near, flow)) out.push_back({id, Category::NearField});
         for (const auto& id : landmark_helpers::chooseMiddleLmIds(params_.max_num_landmarks_middle, ids_middle, newest->second->timestamp_))
             out.push_back({id, Category::MiddleField});
         for (const auto& id : landmark_helpers::chooseFarLmIds(params_.max_num_landmarks_far, ids_far, keyframes)) out.push_back({id, Category::FarField});
