@@ -10,9 +10,11 @@
 // re-applied to arrays instead of Keyframe / Landmark objects (those drag in PCL, OpenCV and the tracklet message types).
 // Output (text, %.17g): initial / final cost, termination, poses, planes, landmarks, trimmed landmark ids - what
 // tests/test_ref_ceres.py compares with oracle/kba_oracle.cpp.
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <memory>
