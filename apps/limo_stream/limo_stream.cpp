@@ -6,10 +6,14 @@
 // drive is synthesised by synth_world.hpp) and of the node's callback (limo_amd/kba/stream_driver.hpp).
 //
 //   limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses out.txt] [--gt-poses gt.txt]
-//               [--dump-velodyne DIR] [--velodyne DIR] [--no-depth] [--quiet]
+//               [--dump-velodyne DIR] [--velodyne DIR] [--no-depth] [--no-prefetch] [--quiet]
 // --dump-velodyne writes every synthetic sweep as a KITTI velodyne scan (DIR/NNNNNN.bin); --velodyne replays scans from
 // such a directory instead of ray-casting them (the scans of a real KITTI sequence have the same format; the tracked
 // features of a real sequence come from the feature tracker, which is outside this path).
+// The sweeps are received into page-locked buffers (limo_host_alloc) and the input runs one frame ahead of the pipeline: the driver
+// starts the depth assignment of frame t+1 as soon as it has collected that of frame t (StreamDriver::announceNextFrame), so it runs
+// on the GPU under the pose refinement and the solve of frame t - the reference's depth estimator is a process of its own beside the
+// BA node.  --no-prefetch assigns every frame's depth inside its own process() call; the pose rows are the same, bit for bit.
 // Prints one summary line per run and `key value` lines for scripts: fps of the pipeline (input synthesis excluded and
 // reported separately), ATE against the ground truth, share of features that received a LiDAR depth.
 #include <chrono>
@@ -30,7 +34,7 @@ int main(int argc, char** argv) {
     int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
     uint64_t seed = 7;
     std::string poses_path, gt_path, dump_dir, replay_dir;
-    bool use_depth = true, quiet = false, five_point_prior = false;
+    bool use_depth = true, quiet = false, five_point_prior = false, prefetch = true;
     double min_flow = -1., time_between_keyframes = -1.;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
@@ -46,10 +50,11 @@ int main(int argc, char** argv) {
         else if (arg("--dump-velodyne")) dump_dir = argv[++i];
         else if (arg("--velodyne")) replay_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
+        else if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else if (!std::strcmp(argv[i], "--five-point-prior")) five_point_prior = true;  // the node's prior without tf (mono_lidar.cpp:157-186)
         else {
-            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--five-point-prior] [--quiet]\n");
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--no-prefetch] [--five-point-prior] [--quiet]\n");
             return 2;
         }
     }
@@ -77,27 +82,47 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> cloud_ground;
     double sec_synth = 0., sec_pipeline = 0.;
     size_t n_points = 0;
-    for (int t = 0; t < n_frames; ++t) {
-        const auto t0 = clk::now();
+    // a frame as the sensor drivers deliver it: the tracker's message and the sweep in a page-locked buffer
+    struct Frame {
+        Tracklets ts;
+        float* scan = nullptr;
+        size_t cap = 0, n_pts = 0, n_tracks = 0;
+    } frames[2];
+    auto release = [&]() {
+        driver.cancelPrefetch();
+        for (Frame& fr : frames)
+            if (fr.scan) limo_host_free(fr.scan);
+    };
+    auto synthesize = [&](int t, Frame& out) -> bool {
         world.sweep(t, cloud, cloud_ground);  // (also labels the returns that hit the ground: the features' class labels come from it)
         if (!replay_dir.empty()) {
             std::vector<float> scan;
             if (!kitti_io::readVelodyneBin(kitti_io::velodynePath(replay_dir, t), scan) || scan.size() != cloud.size()) {
                 std::fprintf(stderr, "limo_stream: cannot replay %s\n", kitti_io::velodynePath(replay_dir, t).c_str());
-                return 1;
+                return false;
             }
             cloud.swap(scan);
         }
         if (!dump_dir.empty() && !kitti_io::writeVelodyneBin(kitti_io::velodynePath(dump_dir, t), cloud.data(), cloud.size() / 4)) {
             std::fprintf(stderr, "limo_stream: cannot write %s\n", kitti_io::velodynePath(dump_dir, t).c_str());
-            return 1;
+            return false;
         }
         n_points += cloud.size() / 4;
+        if (cloud.size() > out.cap) {
+            if (out.scan) limo_host_free(out.scan);
+            out.cap = cloud.size() + cloud.size() / 8;
+            out.scan = static_cast<float*>(limo_host_alloc(out.cap * sizeof(float)));
+            if (!out.scan) {
+                std::fprintf(stderr, "limo_stream: limo_host_alloc failed\n");
+                return false;
+            }
+        }
+        std::memcpy(out.scan, cloud.data(), cloud.size() * sizeof(float));
+        out.n_pts = cloud.size() / 4;
         // tracks that survive into this frame (still visible, not occluded), then new ones up to n_feat
         const Vector3d here = world.origin_veh[t].translation();
         const std::vector<int> near = world.boxes_near(here, 70.);
         std::vector<int> now;
-        std::vector<double> uvz;
         for (int id : live) {
             double u, v, z;
             if (world.visible(t, world.lms[id], near, u, v, z)) now.push_back(id);
@@ -129,19 +154,40 @@ int main(int argc, char** argv) {
             ts.tracks.push_back(tr);
         }
         live = now;
+        out.n_tracks = ts.tracks.size();
+        out.ts = std::move(ts);
+        return true;
+    };
+    {
+        const auto t0 = clk::now();
+        if (n_frames > 0 && !synthesize(0, frames[0])) {
+            release();
+            return 1;
+        }
+        sec_synth += std::chrono::duration<double>(clk::now() - t0).count();
+    }
+    for (int t = 0; t < n_frames; ++t) {
+        Frame& cur = frames[t & 1];
+        Frame& next = frames[(t + 1) & 1];
+        const auto t0 = clk::now();
+        if (t + 1 < n_frames && !synthesize(t + 1, next)) {  // the input runs one frame ahead
+            release();
+            return 1;
+        }
         const auto t1 = clk::now();
-        const size_t n_tracks = ts.tracks.size();
-        driver.process(std::move(ts), cloud.data(), cloud.size() / 4);  // (the tracker's message is handed over: the driver fills in depths)
+        if (prefetch && t + 1 < n_frames) driver.announceNextFrame(next.ts, next.scan, next.n_pts);
+        driver.process(std::move(cur.ts), cur.scan, cur.n_pts);  // (the tracker's message is handed over: the driver fills in depths)
         const auto t2 = clk::now();
         sec_synth += std::chrono::duration<double>(t1 - t0).count();
         sec_pipeline += std::chrono::duration<double>(t2 - t1).count();
         if (!quiet && (t % 100 == 0 || t == n_frames - 1)) {
             const Vector3d e = driver.poses().back().inverse().translation() - world.origin_veh[t].translation();
-            std::printf("frame %d: %zu tracks, %zu points, position error %.3f m, %d keyframes, %d solves\n", t, n_tracks, cloud.size() / 4, e.norm(),
+            std::printf("frame %d: %zu tracks, %zu points, position error %.3f m, %d keyframes, %d solves\n", t, cur.n_tracks, cur.n_pts, e.norm(),
                         driver.stats().keyframes, driver.stats().solves);
             std::fflush(stdout);
         }
     }
+    release();
     // absolute trajectory error of the dumped poses (vehicle positions in the origin frame)
     double se = 0., worst = 0.;
     for (int t = 0; t < n_frames; ++t) {
@@ -175,14 +221,16 @@ int main(int argc, char** argv) {
     std::printf("limo_stream: pipeline %.2f ms per frame -> %.1f frames/s (depth %.2f, pose-only %.2f, push %.2f, solve %.2f ms per frame; %.2f ms per solve()); input synthesis %.1f ms per frame\n",
                 1e3 * sec_pipeline / n_frames, n_frames / sec_pipeline, 1e3 * st.sec_depth / n_frames, 1e3 * st.sec_pose_only / n_frames,
                 1e3 * st.sec_push / n_frames, 1e3 * st.sec_solve / n_frames, st.solves ? 1e3 * st.sec_solve / st.solves : 0., 1e3 * sec_synth / n_frames);
-    std::printf("limo_stream: host side per frame: Keyframe object %.2f, keyframe selection %.2f, window cut + labels %.2f ms; inside the C-ABI: adjustPoseOnly %.2f of %.2f, solve %.2f of %.2f ms per frame\n",
+    std::printf("limo_stream: host side per frame: Keyframe object %.2f, keyframe selection %.2f, window cut + labels %.2f ms; inside the C-ABI: adjustPoseOnly %.2f of %.2f, solve %.2f of %.2f ms per frame; depth of %d frames started one frame ahead\n",
                 1e3 * st.sec_keyframe / n_frames, 1e3 * st.sec_select / n_frames, 1e3 * st.sec_window / n_frames, 1e3 * st.sec_abi_pose_only / n_frames,
-                1e3 * st.sec_pose_only / n_frames, 1e3 * st.sec_abi_solve / n_frames, 1e3 * st.sec_solve / n_frames);
+                1e3 * st.sec_pose_only / n_frames, 1e3 * st.sec_abi_solve / n_frames, 1e3 * st.sec_solve / n_frames, st.depth_prefetched);
+    std::printf("limo_stream: of the depth time, %.3f ms per frame is the per-track depth history\n", 1e3 * st.sec_depth_history / n_frames);
     std::printf("limo_stream: ATE rmse %.4f m (max %.4f m) over %.1f m\n", ate, worst, 0.55 * (n_frames - 1));
     if (te.rel_samples)
         std::printf("limo_stream: relative errors over 100..800 m sub-paths (KITTI devkit measure, %d samples): translation %.3f %%, rotation %.5f deg/m\n",
                     te.rel_samples, 100. * te.rel_trans, te.rel_rot * 180. / M_PI);
-    std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\nsolves_on_non_keyframes %d\n", n_frames, n_frames / sec_pipeline, ate, worst,
-                (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves, st.solves_on_non_keyframes);
+    std::printf("frames %d\nfps %.3f\nate_rmse %.6f\nate_max %.6f\ndepth_fraction %.4f\nkeyframes %d\nsolves %d\nsolves_on_non_keyframes %d\ndepth_prefetched %d\n", n_frames,
+                n_frames / sec_pipeline, ate, worst, (double)st.features_with_depth / std::max(1, st.features), st.keyframes, st.solves, st.solves_on_non_keyframes,
+                st.depth_prefetched);
     return 0;
 }

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define LIMO_ABI_VERSION 3 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms; 3: limo_ctx_coop_fallbacks */
+#define LIMO_ABI_VERSION 4 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms; 3: limo_ctx_coop_fallbacks; 4: limo_depth_estimate_begin / _end */
 
 /* Keyframe::FixationStatus, keyframe.hpp:30 */
 enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
@@ -392,6 +392,22 @@ int limo_depth_estimate(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, co
                         double f, double cx, double cy, int32_t img_w, int32_t img_h, const float* feat_uv,
                         size_t n_feat, const uint8_t* feat_is_ground, const limo_depth_params* params,
                         float* depth_out);
+
+/*
+ * The same call in two halves, so that a frame's depth assignment runs on the GPU while the host thread is busy with something
+ * else (the reference runs the depth estimator as a process of its own beside the bundle-adjustment node:
+ * demo_keyframe_bundle_adjustment_meta/launch/kitti_standalone.launch:14-23 the `tracklet_depth_node`, :55 the BA node - the two overlap there too):
+ *   limo_depth_estimate_begin  enqueues the copies and the kernels on the context's stream and returns; cloud_xyzi must stay
+ *                              valid until _end (from limo_host_alloc memory the copy is a DMA, from pageable memory the runtime
+ *                              stages it before returning); feat_uv / feat_is_ground are consumed before it returns
+ *   limo_depth_estimate_end    waits for that work and writes depth_out[n_feat] (n_feat of the _begin call)
+ * One call may be open per context: _begin with one open, or _end (or any other depth call) out of order -> LIMO_ERR_INVALID.
+ * limo_depth_estimate is exactly _begin followed by _end.
+ */
+int limo_depth_estimate_begin(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar,
+                              double f, double cx, double cy, int32_t img_w, int32_t img_h, const float* feat_uv,
+                              size_t n_feat, const uint8_t* feat_is_ground, const limo_depth_params* params);
+int limo_depth_estimate_end(limo_ctx* ctx, float* depth_out, size_t n_feat);
 
 /*
  * The same for a batch of sweeps of one sensor rig (an offline replay: the reference's demo application reads every

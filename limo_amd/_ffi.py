@@ -190,7 +190,7 @@ class DepthParams(C.Structure):  # struct limo_depth_params
     ]
 
 
-ABI_VERSION = 3  # LIMO_ABI_VERSION of include/limo_hip.h
+ABI_VERSION = 4  # LIMO_ABI_VERSION of include/limo_hip.h
 
 # every symbol include/limo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -224,6 +224,8 @@ ABI_SYMBOLS = [
     "limo_trim_quantile",
     "limo_depth_default_params",
     "limo_depth_estimate",
+    "limo_depth_estimate_begin",
+    "limo_depth_estimate_end",
     "limo_depth_estimate_batch",
     "limo_depth_last_ground_plane",
     "limo_depth_set_timing",
@@ -316,6 +318,8 @@ def load():
         C.POINTER(DepthParams),
         c_float_p,
     ]
+    lib.limo_depth_estimate_begin.argtypes = lib.limo_depth_estimate.argtypes[:-1]
+    lib.limo_depth_estimate_end.argtypes = [vp, c_float_p, C.c_size_t]
     lib.limo_host_alloc.argtypes = [C.c_size_t]
     lib.limo_host_alloc.restype = C.c_void_p
     lib.limo_host_free.argtypes = [C.c_void_p]

@@ -230,6 +230,28 @@ def depth_estimate(ctx, frame, params=None, use_ground_labels=True):
     return out
 
 
+def depth_estimate_begin(ctx, frame, params=None, use_ground_labels=True):
+    """limo_depth_estimate_begin: the frame's depth assignment is enqueued on the context's stream; returns the handle
+    depth_estimate_end wants (it keeps the cloud alive until then)."""
+    p = params if params is not None else depth_default_params()
+    cloud = np.ascontiguousarray(frame["cloud"], np.float32)
+    uv = np.ascontiguousarray(frame["uv"], np.float32)
+    T = np.ascontiguousarray(frame["T_cam_lidar"], np.float64)
+    g = np.ascontiguousarray(frame["is_ground"], np.uint8) if use_ground_labels else None
+    rc = ctx.lib.limo_depth_estimate_begin(
+        ctx.ptr, cloud.ctypes.data_as(_ffi.c_float_p), cloud.shape[0], T.ctypes.data_as(_ffi.c_double_p), frame["f"], frame["cx"], frame["cy"],
+        frame["w"], frame["h"], uv.ctypes.data_as(_ffi.c_float_p), uv.shape[0], None if g is None else g.ctypes.data_as(_ffi.c_uint8_p), C.byref(p))
+    _check(rc, ctx.ptr, "limo_depth_estimate_begin")
+    return (cloud, uv.shape[0])
+
+
+def depth_estimate_end(ctx, handle):
+    """limo_depth_estimate_end: float32 depth per feature of the frame given to depth_estimate_begin."""
+    out = np.zeros(handle[1], np.float32)
+    _check(ctx.lib.limo_depth_estimate_end(ctx.ptr, out.ctypes.data_as(_ffi.c_float_p), handle[1]), ctx.ptr, "limo_depth_estimate_end")
+    return out
+
+
 def depth_kernel_ms(ctx):
     """limo_depth_last_kernel_ms (after limo_depth_set_timing(ctx, 1)): dict of device milliseconds of the last launch group."""
     ms = np.zeros(4)

@@ -847,6 +847,9 @@ struct DepthWs {
     int cur = 0;                     // zone of the next call
     int last_frames = 0;             // frames of the last launch group (limo_depth_last_ground_plane)
     uint32_t last_ground_mask = 0;
+    bool last_timed = false;         // the last enqueued group recorded its events
+    bool open = false;               // a limo_depth_estimate_begin whose _end has not been called
+    size_t open_feat = 0;            // its n_feat
     bool timing = false;             // limo_depth_set_timing: HIP events around the kernels of a launch group
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // before k_project | k_ransac.. | k_features | copy back | end
     double last_ms[4] = {0, 0, 0, 0};  // k_project, ground-plane kernels, k_features, all kernels
@@ -959,14 +962,19 @@ void quat_to_R(const double* q, double* R) {
     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// One launch group: 1..kMaxBatch frames.
-int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const double* T_cam_lidar, double f, double cx, double cy,
+// One launch group: 1..kMaxBatch frames.  enqueue_group puts the copies and the kernels on the context's stream, finish_group
+// waits for them and reports what the kernels flagged; run_group = both + the depths into the caller's arrays.
+int enqueue_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const double* T_cam_lidar, double f, double cx, double cy,
               int32_t img_w, int32_t img_h, const limo_depth_params& p, bool device_ptrs) {
     if (!ctx->depth_ws) {
         ctx->depth_ws = new DepthWs();
         ctx->depth_ws_free = depth_ws_free;
     }
     DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    if (W.open) {
+        ctx->err = "limo_depth_estimate: a limo_depth_estimate_begin is open on this context (limo_depth_estimate_end first)";
+        return LIMO_ERR_INVALID;
+    }
     hipStream_t s = ctx->stream;
     const int cells_x = (img_w + kCell - 1) / kCell, cells_y = (img_h + kCell - 1) / kCell;
     const size_t cells = (size_t)cells_x * cells_y;
@@ -1077,8 +1085,13 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
         if (!device_ptrs) HIP_TRY(ctx, hipMemcpyAsync(W.h_out, W.out, sizeof(float) * Q * n_frames, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (W.timing && max_feat) {
+    W.last_timed = W.timing && max_feat;
+    return LIMO_OK;
+}
+
+int finish_group(limo_ctx* ctx, DepthWs& W) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (W.last_timed) {
         float a = 0.f, b = 0.f, c = 0.f;
         (void)hipEventElapsedTime(&a, W.ev[0], W.ev[1]);
         (void)hipEventElapsedTime(&b, W.ev[1], W.ev[2]);
@@ -1093,9 +1106,17 @@ int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const
                    " (not a single sweep of a spinning scanner?)";
         return LIMO_ERR_INVALID;
     }
+    return LIMO_OK;
+}
+
+int run_group(limo_ctx* ctx, int n_frames, const limo_depth_frame* frames, const double* T_cam_lidar, double f, double cx, double cy,
+              int32_t img_w, int32_t img_h, const limo_depth_params& p, bool device_ptrs) {
+    if (int rc = enqueue_group(ctx, n_frames, frames, T_cam_lidar, f, cx, cy, img_w, img_h, p, device_ptrs)) return rc;
+    DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    if (int rc = finish_group(ctx, W)) return rc;
     if (!device_ptrs)
         for (int k = 0; k < n_frames; ++k)
-            if (frames[k].n_feat) std::memcpy(frames[k].depth_out, W.h_out + (size_t)k * Q, sizeof(float) * frames[k].n_feat);
+            if (frames[k].n_feat) std::memcpy(frames[k].depth_out, W.h_out + (size_t)k * W.cap_feat, sizeof(float) * frames[k].n_feat);
     return LIMO_OK;
 }
 
@@ -1192,6 +1213,49 @@ int limo_depth_last_ground_plane(limo_ctx* ctx, int32_t frame, double* plane4, i
     const bool ok = pl[4] != 0.0;
     for (int k = 0; k < 4; ++k) plane4[k] = ok ? pl[k] : 0.0;
     if (inliers) *inliers = ok ? (int32_t)pl[5] : 0;
+    return LIMO_OK;
+}
+
+int limo_depth_estimate_begin(limo_ctx* ctx, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar, double f, double cx,
+                              double cy, int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
+                              const limo_depth_params* params) {
+    if (!ctx || !T_cam_lidar || img_w <= 0 || img_h <= 0 || (n_pts && !cloud_xyzi) || (n_feat && !feat_uv)) return LIMO_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    limo_depth_params p;
+    if (params)
+        p = *params;
+    else
+        limo_depth_default_params(&p);
+    if (p.ransac_plane_max_iterations > kMaxHyp) p.ransac_plane_max_iterations = kMaxHyp;
+    limo_depth_frame fr;
+    fr.cloud_xyzi = cloud_xyzi;
+    fr.n_pts = n_pts;
+    fr.feat_uv = feat_uv;
+    fr.n_feat = n_feat;
+    fr.feat_is_ground = feat_is_ground;
+    fr.depth_out = nullptr;
+    if (int rc = enqueue_group(ctx, 1, &fr, T_cam_lidar, f, cx, cy, img_w, img_h, p, false)) return rc;
+    DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    W.open = true;
+    W.open_feat = n_feat;
+    return LIMO_OK;
+}
+
+int limo_depth_estimate_end(limo_ctx* ctx, float* depth_out, size_t n_feat) {
+    if (!ctx || !ctx->depth_ws) return LIMO_ERR_INVALID;
+    DepthWs& W = *static_cast<DepthWs*>(ctx->depth_ws);
+    if (!W.open) {
+        ctx->err = "limo_depth_estimate_end: no limo_depth_estimate_begin is open on this context";
+        return LIMO_ERR_INVALID;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return LIMO_ERR_NO_DEVICE;
+    W.open = false;  // (whatever happens below, the call is over)
+    if (int rc = finish_group(ctx, W)) return rc;
+    if (n_feat != W.open_feat || (n_feat && !depth_out)) {
+        ctx->err = "limo_depth_estimate_end: n_feat differs from the limo_depth_estimate_begin call";
+        return LIMO_ERR_INVALID;
+    }
+    if (n_feat) std::memcpy(depth_out, W.h_out, sizeof(float) * n_feat);
     return LIMO_OK;
 }
 

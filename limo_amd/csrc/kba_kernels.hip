@@ -1419,6 +1419,19 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
     __shared__ double red[6 * (kBlock / 64)];
     const int64_t so = wd.cam_scr_off;
     const int lb0 = wd.lblk0, lb1 = wd.lblk0 + wd.n_lblk;
+#ifdef KBA_WG_TICKS  // debug build: where the time of window 0 goes (100 MHz ticks, lane 0)
+    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = wall_clock64();
+    int n_it = 0, n_lin = 0;
+#define KBA_WTICK(i)                         \
+    do {                                     \
+        const long long n_ = wall_clock64(); \
+        tk[i] += n_ - tl;                    \
+        tl = n_;                             \
+    } while (0)
+#else
+#define KBA_WTICK(i)
+#endif
     // The window's LM state is written by lane 0 only, and only behind a barrier that every lane passes AFTER its last
     // read of the state: all lanes take the same branches.
     // run_schedule: per trimming round [solve(trim_iters, windows that trim), solve(3 trim_iters, of those the ones whose
@@ -1435,23 +1448,31 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
             lm_solve_init(st, sel, max_iter, c);
         }
         __syncthreads();
+        KBA_WTICK(0);
         const long long t0 = cap_ticks > 0 ? (long long)wall_clock64() : 0ll;
         for (;;) {
             // ---- linearize(): k_view_consts, k_lin_lm, k_cam_assemble
             if (st.active && st.need_lin) {
                 if (tid < wd.n_view) view_consts_item(bv, wd.view0 + tid);
                 __syncthreads();
+                KBA_WTICK(1);
                 for (int b = lb0; b < lb1; ++b) {
                     lin_lm_block<false>(bv, c, b);
                     __syncthreads();
                 }
+                KBA_WTICK(2);
                 if (so >= 0)
                     cam_assemble(bv, c, w, tid, kBlock, bv.cam_scratch + so);
                 else
                     cam_assemble(bv, c, w, tid, kBlock, smem);
                 __syncthreads();
+                KBA_WTICK(3);
                 if (tid == 0) lm_decide_lin(st, bv.red[w], bv.reg_cost[2 * w + 1], c);
                 __syncthreads();
+                KBA_WTICK(4);
+#ifdef KBA_WG_TICKS
+                ++n_lin;
+#endif
             }
             int active = st.active;
             if (cap_ticks > 0) {
@@ -1466,19 +1487,26 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
                 for (int b = lb0; b < lb1; ++b) lm_damp_block(bv, c, b);
                 __syncthreads();
             }
+            KBA_WTICK(5);
             if (so >= 0)
                 cam_solve(bv, c, w, tid, kBlock, bv.cam_scratch + so, &flag);
             else
                 cam_solve(bv, c, w, tid, kBlock, smem, &flag);
             __syncthreads();
+            KBA_WTICK(6);
             for (int b = lb0; b < lb1; ++b) {
                 backsub_block(bv, c, b);
                 __syncthreads();
             }
+            KBA_WTICK(7);
             reduce_step(bv, w, tid, kBlock, red, 64);
             __syncthreads();
             if (tid == 0) lm_decide_step(st, bv.red[w], c);
             __syncthreads();
+            KBA_WTICK(8);
+#ifdef KBA_WG_TICKS
+            ++n_it;
+#endif
             if (st.accept) {
                 if (tid < wd.n_kf) {
                     const int64_t i = wd.kf0 + tid;
@@ -1490,6 +1518,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
                     for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
             }
             __syncthreads();
+            KBA_WTICK(9);
         }
         if (retry && wd.do_trim) {  // trim(): k_trim_residual, k_trim_max, k_trim_select
             __syncthreads();
@@ -1499,8 +1528,14 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
             for (int l = wd.lm0 + tid; l < wd.lm0 + wd.n_lm; l += kBlock) trim_max_lane(bv, l, plane_rep, plane_dep);
             __syncthreads();
             trim_select_win(bv, c, w);
+            KBA_WTICK(10);
         }
     }
+#ifdef KBA_WG_TICKS
+    if (w == 0 && tid == 0)
+        printf("[wg ticks] %d obs, %d landmark blocks, %d iterations, %d linearisations: init %lld | view consts %lld | lin %lld | assemble %lld | decide-lin %lld | damp %lld | cam solve %lld | backsub %lld | reduce+decide %lld | accept %lld | trim %lld (x10 ns)\n",
+               (int)wd.n_obs, lb1 - lb0, n_it, n_lin, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[8], tk[9], tk[10]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ one window, one launch, G workgroups

@@ -268,9 +268,18 @@ void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
         for (size_t i = 0; i < ids.size(); ++i)
             if (ok[i]) landmarks_[ids[i]] = std::make_shared<Landmark>(Vector3d(pos.data() + 3 * i), use_depth[i] != 0);
     }
+    // (measurements and active ids are both in id order: every insertion gets the place of the one before it as its hint)
     SortedFinder<decltype(landmarks_)> now_known(landmarks_);
-    for (const auto& m : kf.measurements_)
-        if (now_known.find(m.first) != landmarks_.cend()) active_landmark_ids_.insert(m.first);
+    auto hint = active_landmark_ids_.begin();
+    for (const auto& m : kf.measurements_) {
+        if (now_known.find(m.first) == landmarks_.cend()) continue;
+        for (int steps = 0; hint != active_landmark_ids_.end() && *hint < m.first; ++hint)
+            if (++steps > 8) {  // (far away: a search, not a walk)
+                hint = active_landmark_ids_.lower_bound(m.first);
+                break;
+            }
+        hint = active_landmark_ids_.insert(hint, m.first);
+    }
 }
 
 void BundleAdjusterKeyframes::collectRays(const Keyframe& kf, const LandmarkId& lId, std::vector<limo_ray>& rays) const {
@@ -476,6 +485,12 @@ struct Flat {
     std::map<const Camera*, int> cam_index;
     limo_ba_window w;
 
+    void reserve_landmarks(size_t n) {
+        lms.reserve(n);
+        lm_pos.reserve(3 * n);
+        lm_w.reserve(n);
+        lm_gp.reserve(n);
+    }
     int camera(const Camera& c) {
         auto it = cam_index.find(&c);
         if (it != cam_index.end()) return it->second;
@@ -589,6 +604,8 @@ std::string BundleAdjusterKeyframes::solve() {
     Flat F;
     for (const auto& id : active_keyframe_ids_) F.add_keyframe(*keyframes_.at(id));
     std::vector<std::pair<LandmarkId, int>> lm_index;  // (selected ids come in id order: sorted as built)
+    F.reserve_landmarks(selected_landmark_ids_.size());
+    lm_index.reserve(selected_landmark_ids_.size());
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
         auto it = known.find(id);
@@ -631,10 +648,16 @@ std::string BundleAdjusterKeyframes::solve() {
 }
 
 std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
+    using clk = std::chrono::steady_clock;
+    static const bool shim_trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;
+    const auto t_p0 = clk::now();
     selected_landmark_ids_ = landmark_selector_->getLastSelection();  // :828
+    const auto t_p1 = clk::now();
     Flat F;
     F.add_keyframe(kf);
     std::vector<std::pair<LandmarkId, int>> lm_index;  // (selected ids come in id order: sorted as built)
+    F.reserve_landmarks(selected_landmark_ids_.size());
+    lm_index.reserve(selected_landmark_ids_.size());
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& id : selected_landmark_ids_) {
         auto it = known.find(id);
@@ -677,12 +700,20 @@ std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
     o.max_solver_time_sec = solver_time_sec;
     limo_ba_report rep;
     limo_ctx* ctx = context();
+    const auto t_p2 = clk::now();
     const int rc = limo_ba_adjust_pose_only(ctx, &F.w, prior.speed_weight > 0.0 ? &prior : nullptr, &o, &rep);
+    const auto t_p3 = clk::now();
     if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_ba_adjust_pose_only: ") + limo_last_error(ctx));
     F.write_back(false);
     last_report_ = {rep.termination, rep.num_solves, rep.iterations_total, rep.n_trimmed_landmarks, rep.n_depth_blocks,
                     rep.n_repr_blocks, rep.n_gp_blocks, rep.initial_cost, rep.final_cost, rep.time_sec};
-    return report_string(rep, "adjustPoseOnly");
+    std::string summary = report_string(rep, "adjustPoseOnly");
+    if (shim_trace) {
+        auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[shim] adjustPoseOnly: %d landmarks, %d observations: selection copy %.0f us, flatten + prior %.0f us, limo_ba_adjust_pose_only %.0f us, write-back + summary %.0f us\n",
+                     F.w.n_lm, F.w.n_obs, us(t_p0, t_p1), us(t_p1, t_p2), us(t_p2, t_p3), us(t_p3, clk::now()));
+    }
+    return summary;
 }
 
 }  // namespace keyframe_bundle_adjustment

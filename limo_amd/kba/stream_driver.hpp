@@ -67,11 +67,11 @@ struct StreamParams {
 class StreamDriver {
 public:
     struct Stats {
-        int frames = 0, keyframes = 0, solves = 0, solves_on_non_keyframes = 0, features = 0, features_with_depth = 0;
+        int frames = 0, keyframes = 0, solves = 0, solves_on_non_keyframes = 0, features = 0, features_with_depth = 0, depth_prefetched = 0;
         double sec_depth = 0., sec_pose_only = 0., sec_push = 0., sec_solve = 0., sec_total = 0.;
         // host-side bookkeeping of a frame: the Keyframe object of the frame (measurement maps of its tracks), keyframe
         // selection, window cut + labels; and of sec_pose_only / sec_solve the share spent inside the C-ABI calls
-        double sec_keyframe = 0., sec_select = 0., sec_window = 0., sec_abi_pose_only = 0., sec_abi_solve = 0.;
+        double sec_keyframe = 0., sec_select = 0., sec_window = 0., sec_abi_pose_only = 0., sec_abi_solve = 0., sec_depth_history = 0.;
     };
 
     StreamDriver(const StreamParams& p, Camera::Ptr camera, const EigenPose& T_camera_lidar) : p_(p), camera_(camera), T_cam_lidar_(T_camera_lidar) {
@@ -101,10 +101,48 @@ public:
         limo_depth_default_params(&depth_params_);
     }
     ~StreamDriver() {
+        cancelPrefetch();
         if (ctx_) limo_ctx_destroy(ctx_);
     }
     StreamDriver(const StreamDriver&) = delete;
     StreamDriver& operator=(const StreamDriver&) = delete;
+
+    // Start the depth assignment of a frame that process() will be given LATER (normally the next one): copies and kernels go onto
+    // the stream of this driver's own context and run while the host thread and the bundle adjuster's context work on the current
+    // frame - the reference's depth estimator is a process of its own beside the BA node (kitti_standalone.launch:14-23, :55).
+    // `cloud_xyzi` must stay valid until that process() call (page-locked memory from limo_host_alloc makes the copy a DMA).
+    // process() recognises the frame by its stamp and feature count; a prefetch that is not picked up is dropped.  Results are
+    // those of the unprefetched call, bit for bit.
+    void prefetchDepth(const Tracklets& tracklets, const float* cloud_xyzi, size_t n_pts) {
+        if (!p_.assign_depth || !cloud_xyzi || !n_pts || tracklets.tracks.empty() || tracklets.stamps.empty()) return;
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        closeOpenDepthCall();
+        stageFeatures(tracklets);
+        const Pose T = convert(T_cam_lidar_);
+        const int rc = limo_depth_estimate_begin(ctx_, cloud_xyzi, n_pts, T.data(), camera_->focal_length, camera_->principal_point[0],
+                                                 camera_->principal_point[1], p_.image_width, p_.image_height, uv_.data(), tracklets.tracks.size(),
+                                                 ground_.data(), &depth_params_);
+        if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate_begin: ") + limo_last_error(ctx_));
+        prefetch_open_ = true;
+        prefetch_stamp_ = tracklets.stamps.front();
+        prefetch_n_ = tracklets.tracks.size();
+        stats_.sec_depth += std::chrono::duration<double>(clk::now() - t0).count();
+    }
+
+    // The same, deferred: the NEXT process() call starts this frame's depth assignment as soon as it has collected its own (one
+    // assignment is open per context at a time, so that is the earliest moment).  Both arguments must stay valid until then.
+    void announceNextFrame(const Tracklets& tracklets, const float* cloud_xyzi, size_t n_pts) {
+        next_tracklets_ = &tracklets;
+        next_cloud_ = cloud_xyzi;
+        next_n_pts_ = n_pts;
+    }
+
+    // Drop what prefetchDepth / announceNextFrame started (the sweep buffer is about to go away).
+    void cancelPrefetch() {
+        next_tracklets_ = nullptr;
+        closeOpenDepthCall();
+    }
 
     // One frame.  `tracklets`: the tracker's message - stamps[0] = this frame, every track's feature_points[0] = its point
     // in this frame (newest first).  Depths the caller already knows stay; the others (d < 0) are filled from the sweep:
@@ -119,6 +157,11 @@ public:
         const TimestampNSec stamp = tracklets.stamps.front();
         assignDepth(tracklets, cloud_xyzi, n_pts);
         stats_.sec_depth += std::chrono::duration<double>(clk::now() - t_begin).count();
+        if (next_tracklets_) {  // announceNextFrame
+            const Tracklets* next = next_tracklets_;
+            next_tracklets_ = nullptr;
+            prefetchDepth(*next, next_cloud_, next_n_pts_);
+        }
         Plane ground_plane;
         ground_plane.distance = p_.height_over_ground;
         EigenPose pose = EigenPose::Identity();
@@ -251,52 +294,82 @@ private:
         return m * last_pose_;
     }
 
+    // pixel coordinates and ground flags of the newest point of every track, as limo_depth_estimate wants them
+    void stageFeatures(const Tracklets& ts) {
+        const size_t n = ts.tracks.size();
+        uv_.resize(2 * n);
+        ground_.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            uv_[2 * i] = ts.tracks[i].feature_points[0].u;
+            uv_[2 * i + 1] = ts.tracks[i].feature_points[0].v;
+            ground_[i] = 0;
+            for (int l : p_.ground_labels) ground_[i] |= ts.tracks[i].label == l;
+        }
+    }
+
+    void closeOpenDepthCall() {  // a prefetch nobody will pick up: its limo_depth_estimate_end, results dropped
+        if (!prefetch_open_) return;
+        prefetch_open_ = false;
+        std::vector<float> sink(prefetch_n_);
+        (void)limo_depth_estimate_end(ctx_, sink.data(), prefetch_n_);
+    }
+
     // FeaturePoint::d of the tracks: newest point from the sweep (limo_depth_estimate), history from earlier frames.
     void assignDepth(Tracklets& ts, const float* cloud, size_t n_pts) {
         const size_t n = ts.tracks.size();
         stats_.features += (int)n;
         if (p_.assign_depth && cloud && n_pts && n) {
-            uv_.resize(2 * n);
-            ground_.resize(n);
             depth_.assign(n, -1.f);
-            for (size_t i = 0; i < n; ++i) {
-                uv_[2 * i] = ts.tracks[i].feature_points[0].u;
-                uv_[2 * i + 1] = ts.tracks[i].feature_points[0].v;
-                ground_[i] = 0;
-                for (int l : p_.ground_labels) ground_[i] |= ts.tracks[i].label == l;
+            if (prefetch_open_ && prefetch_stamp_ == ts.stamps.front() && prefetch_n_ == n) {  // started by prefetchDepth
+                prefetch_open_ = false;
+                const int rc = limo_depth_estimate_end(ctx_, depth_.data(), n);
+                if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate_end: ") + limo_last_error(ctx_));
+                ++stats_.depth_prefetched;
+            } else {
+                closeOpenDepthCall();
+                stageFeatures(ts);
+                const Pose T = convert(T_cam_lidar_);
+                const int rc = limo_depth_estimate(ctx_, cloud, n_pts, T.data(), camera_->focal_length, camera_->principal_point[0],
+                                                   camera_->principal_point[1], p_.image_width, p_.image_height, uv_.data(), n, ground_.data(),
+                                                   &depth_params_, depth_.data());
+                if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate: ") + limo_last_error(ctx_));
             }
-            const Pose T = convert(T_cam_lidar_);
-            const int rc = limo_depth_estimate(ctx_, cloud, n_pts, T.data(), camera_->focal_length, camera_->principal_point[0],
-                                               camera_->principal_point[1], p_.image_width, p_.image_height, uv_.data(), n, ground_.data(),
-                                               &depth_params_, depth_.data());
-            if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate: ") + limo_last_error(ctx_));
             for (size_t i = 0; i < n; ++i)
                 if (ts.tracks[i].feature_points[0].d < 0.f) ts.tracks[i].feature_points[0].d = depth_[i];
         }
         // remember this frame's depth per track, fill the history points from the memory (ring of the last frames)
+        const auto t_hist = std::chrono::steady_clock::now();
         const TimestampNSec stamp = ts.stamps.front();
         for (auto& tr : ts.tracks) {
-            auto& h = history_[tr.id];
-            h.emplace_back(stamp, tr.feature_points[0].d);
-            if (h.size() > 16) h.erase(h.begin());
+            History& h = history_[tr.id];
+            h.stamp[h.head] = stamp;
+            h.d[h.head] = tr.feature_points[0].d;
+            h.head = (h.head + 1) & (History::kDepth - 1);
+            h.n = std::min<int>(History::kDepth, h.n + 1);
             for (size_t k = 1; k < tr.feature_points.size() && k < ts.stamps.size(); ++k) {
                 if (tr.feature_points[k].d >= 0.f) continue;
-                // (a track seen in consecutive frames has the entry of stamps[k] k places from the end: looked at first; stamps are
-                // unique inside a history, so the scan below finds the same entry or none)
-                if (k < h.size() && h[h.size() - 1 - k].first == ts.stamps[k]) {
-                    tr.feature_points[k].d = h[h.size() - 1 - k].second;
-                    continue;
+                // (a track seen in consecutive frames has the entry of stamps[k] k places behind the newest: looked at first; stamps
+                // are unique inside a history, so the scan below finds the same entry or none)
+                if ((int)k < h.n) {
+                    const int e = (h.head - 1 - (int)k) & (History::kDepth - 1);
+                    if (h.stamp[e] == ts.stamps[k]) {
+                        tr.feature_points[k].d = h.d[e];
+                        continue;
+                    }
                 }
-                for (const auto& e : h)
-                    if (e.first == ts.stamps[k]) tr.feature_points[k].d = e.second;
+                for (int j = 0; j < h.n; ++j) {
+                    const int e = (h.head - 1 - j) & (History::kDepth - 1);
+                    if (h.stamp[e] == ts.stamps[k]) tr.feature_points[k].d = h.d[e];
+                }
             }
             stats_.features_with_depth += tr.feature_points[0].d > 0.f;
         }
+        stats_.sec_depth_history += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_hist).count();
         if (++frames_since_gc_ >= 64) {  // forget tracks that ended
             frames_since_gc_ = 0;
             const TimestampNSec oldest = ts.stamps.back();
             for (auto it = history_.begin(); it != history_.end();)
-                it = (it->second.empty() || it->second.back().first < oldest) ? history_.erase(it) : std::next(it);
+                it = it->second.stamp[(it->second.head - 1) & (History::kDepth - 1)] < oldest ? history_.erase(it) : std::next(it);
         }
     }
 
@@ -307,10 +380,22 @@ private:
     KeyframeSelector selector_;
     limo_ctx* ctx_ = nullptr;
     limo_depth_params depth_params_;
-    std::unordered_map<unsigned long, std::vector<std::pair<TimestampNSec, float>>> history_;
+    struct History {  // the depths this driver assigned to a track in the last frames it was seen in (ring, newest at head - 1)
+        static constexpr int kDepth = 16;
+        TimestampNSec stamp[kDepth];
+        float d[kDepth];
+        int head = 0, n = 0;
+    };
+    std::unordered_map<unsigned long, History> history_;
     int frames_since_gc_ = 0;
     std::vector<float> uv_, depth_;
     std::vector<uint8_t> ground_;
+    bool prefetch_open_ = false;  // prefetchDepth: a limo_depth_estimate_begin whose frame process() has not seen yet
+    TimestampNSec prefetch_stamp_ = 0;
+    size_t prefetch_n_ = 0;
+    const Tracklets* next_tracklets_ = nullptr;  // announceNextFrame
+    const float* next_cloud_ = nullptr;
+    size_t next_n_pts_ = 0;
     std::vector<EigenPose> poses_;
     EigenPose last_pose_ = EigenPose::Identity(), last_motion_ = EigenPose::Identity();
     bool have_last_ = false, have_motion_ = false;

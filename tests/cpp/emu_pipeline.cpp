@@ -5,6 +5,7 @@
 // lanes and workgroup reductions.  It exists so that the host logic and the kernel arithmetic can be unit-tested
 // against the oracle in the CPU-only test tier (`pytest -m "not gpu"`).  It is NOT part of the product: it is
 // built only into tests/cpp/_build/libkba_emu.so and nothing under limo_amd/ links or loads it.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -700,6 +701,25 @@ int limo_depth_estimate(limo_ctx*, const float* cloud_xyzi, size_t n_pts, const 
                         int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
                         const limo_depth_params* params, float* depth_out) {
     return oracle_depth_estimate(cloud_xyzi, n_pts, T_cam_lidar, f, cx, cy, img_w, img_h, feat_uv, n_feat, feat_is_ground, params, depth_out);
+}
+// the two-halves form of the call (limo_hip.h): these CPU backends do the work in _begin and hand it over in _end
+static std::vector<float> g_depth_pending;
+static bool g_depth_open = false;
+int limo_depth_estimate_begin(limo_ctx*, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar, double f, double cx, double cy,
+                              int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
+                              const limo_depth_params* params) {
+    if (g_depth_open) return LIMO_ERR_INVALID;
+    g_depth_pending.assign(n_feat, -1.f);
+    const int rc = oracle_depth_estimate(cloud_xyzi, n_pts, T_cam_lidar, f, cx, cy, img_w, img_h, feat_uv, n_feat, feat_is_ground, params, g_depth_pending.data());
+    g_depth_open = rc == LIMO_OK;
+    return rc;
+}
+int limo_depth_estimate_end(limo_ctx*, float* depth_out, size_t n_feat) {
+    if (!g_depth_open) return LIMO_ERR_INVALID;
+    g_depth_open = false;
+    if (n_feat != g_depth_pending.size() || (n_feat && !depth_out)) return LIMO_ERR_INVALID;
+    std::copy(g_depth_pending.begin(), g_depth_pending.end(), depth_out);
+    return LIMO_OK;
 }
 #endif
 }

@@ -9,9 +9,11 @@
 // (robust_solving.cpp:140-248).  A drive through it is the config-5 oracle (call order mono_lidar.cpp:186-260).
 //
 // Built only into tests/cpp/_build/libkba_oracle_abi.so by tests/emu_ffi.py.  NEVER linked into the product.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/limo_hip.h"
 
@@ -63,5 +65,24 @@ int limo_depth_estimate(limo_ctx*, const float* cloud_xyzi, size_t n_pts, const 
                         int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
                         const limo_depth_params* params, float* depth_out) {
     return oracle_depth_estimate(cloud_xyzi, n_pts, T_cam_lidar, f, cx, cy, img_w, img_h, feat_uv, n_feat, feat_is_ground, params, depth_out);
+}
+// the two-halves form of the call (limo_hip.h): these CPU backends do the work in _begin and hand it over in _end
+static std::vector<float> g_depth_pending;
+static bool g_depth_open = false;
+int limo_depth_estimate_begin(limo_ctx*, const float* cloud_xyzi, size_t n_pts, const double* T_cam_lidar, double f, double cx, double cy,
+                              int32_t img_w, int32_t img_h, const float* feat_uv, size_t n_feat, const uint8_t* feat_is_ground,
+                              const limo_depth_params* params) {
+    if (g_depth_open) return LIMO_ERR_INVALID;
+    g_depth_pending.assign(n_feat, -1.f);
+    const int rc = oracle_depth_estimate(cloud_xyzi, n_pts, T_cam_lidar, f, cx, cy, img_w, img_h, feat_uv, n_feat, feat_is_ground, params, g_depth_pending.data());
+    g_depth_open = rc == LIMO_OK;
+    return rc;
+}
+int limo_depth_estimate_end(limo_ctx*, float* depth_out, size_t n_feat) {
+    if (!g_depth_open) return LIMO_ERR_INVALID;
+    g_depth_open = false;
+    if (n_feat != g_depth_pending.size() || (n_feat && !depth_out)) return LIMO_ERR_INVALID;
+    std::copy(g_depth_pending.begin(), g_depth_pending.end(), depth_out);
+    return LIMO_OK;
 }
 }

@@ -177,6 +177,42 @@ def test_gpu_depth_batch_equals_single_calls(ctx, oracle):
     assert np.array_equal(ba.depth_estimate(ctx, frames[0], use_ground_labels=False), ba.depth_estimate_batch(ctx, frames[:1], use_ground_labels=False)[0])
 
 
+@pytest.mark.gpu
+def test_gpu_depth_in_two_halves(ctx, oracle):
+    """limo_depth_estimate_begin / _end (the stream driver's prefetch of the next frame): the bits of the one-piece call, also with a
+    bundle-adjustment solve of another context running between the halves and with the sweep in page-locked memory; calls out of
+    order are refused and leave the context usable."""
+    from limo_amd import _ffi, ba, default_options, synth
+
+    frames = [synth_lidar.make_frame(s) for s in (21, 22)]
+    want = [ba.depth_estimate(ctx, fr) for fr in frames]
+    compare(want[0], oracle.depth_estimate(frames[0]))
+    other = ba.Context(0)
+    for k, fr in enumerate(frames):
+        if k == 1:
+            pinned = dict(fr)
+            pinned["cloud"] = ba.host_array(fr["cloud"].shape, np.float32)
+            pinned["cloud"][:] = fr["cloud"]
+            fr = pinned
+        h = ba.depth_estimate_begin(ctx, fr)
+        rep = other.solve(synth.make_window(5, n_kf=5, n_lm=300), default_options())
+        assert rep["termination"] in (0, 1)
+        assert np.array_equal(ba.depth_estimate_end(ctx, h), want[k])
+    # out of order
+    out = np.zeros(4, np.float32)
+    assert ctx.lib.limo_depth_estimate_end(ctx.ptr, out.ctypes.data_as(_ffi.c_float_p), 4) == _ffi.LIMO_ERR_INVALID
+    h = ba.depth_estimate_begin(ctx, frames[0])
+    with pytest.raises(RuntimeError):
+        ba.depth_estimate_begin(ctx, frames[1])
+    with pytest.raises(RuntimeError):
+        ba.depth_estimate(ctx, frames[1])
+    assert np.array_equal(ba.depth_estimate_end(ctx, h), want[0])
+    h = ba.depth_estimate_begin(ctx, frames[0])
+    wrong = np.zeros(h[1] + 1, np.float32)
+    assert ctx.lib.limo_depth_estimate_end(ctx.ptr, wrong.ctypes.data_as(_ffi.c_float_p), h[1] + 1) == _ffi.LIMO_ERR_INVALID
+    assert np.array_equal(ba.depth_estimate(ctx, frames[1]), want[1])  # (the refused _end closed the call)
+
+
 def cluttered_band_frame(seed, ground_share=0.2, n=60000):
     """A sweep whose z band is mostly clutter: the ground carries only `ground_share` of the band returns, so the adaptive
     RANSAC bound stays above 64 hypotheses and the second count launch (k_ransac<rest>) has to run."""

@@ -82,7 +82,7 @@ def run_limo_stream(exe, frames, az, poses_path=None, extra=()):
     print(r.stdout[-1500:])
     print(r.stderr[-800:])
     assert r.returncode == 0
-    return {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("frames", "fps", "ate_rmse", "ate_max", "depth_fraction", "keyframes", "solves", "solves_on_non_keyframes")}
+    return {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("frames", "fps", "ate_rmse", "ate_max", "depth_fraction", "keyframes", "solves", "solves_on_non_keyframes", "depth_prefetched")}
 
 
 def test_limo_stream_with_emulated_backend(tmp_path):
@@ -115,6 +115,12 @@ def test_limo_stream_with_emulated_backend(tmp_path):
     assert want.shape == got.shape and np.abs(want - got).max() <= 1e-9, np.abs(want - got).max()
     first = np.array(rows[0], float).reshape(3, 4)
     assert np.allclose(first, np.eye(4)[:3], atol=1e-12)        # the first frame is the origin
+    # the driver started the depth assignment of every frame but the first one frame ahead (StreamDriver::announceNextFrame ->
+    # limo_depth_estimate_begin / _end); assigned inside each frame's own process() call instead, the rows are the same bytes
+    assert out["depth_prefetched"] == 39
+    serial = str(tmp_path / "poses_serial.txt")
+    assert run_limo_stream(exe, 40, 2000, serial, extra=["--no-prefetch"])["depth_prefetched"] == 0
+    assert open(serial).read() == open(poses).read()
     no_depth = run_limo_stream(exe, 40, 2000, extra=["--no-depth"])
     assert no_depth["depth_fraction"] == 0.0 and no_depth["ate_rmse"] > out["ate_rmse"]  # monocular: scale drifts without LiDAR
     # the node's own prior when it has no tf: five-point direction + the last keyframes' speed (mono_lidar.cpp:157-186,
@@ -150,7 +156,9 @@ def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
     pg, pe = str(tmp_path / "gpu.txt"), str(tmp_path / "emu.txt")
     og = run_limo_stream(gpu, 80, 2000, pg)
     oe = run_limo_stream(emu, 80, 2000, pe)
-    assert og["ate_rmse"] < 0.05 and og["depth_fraction"] > 0.35
+    assert og["ate_rmse"] < 0.05 and og["depth_fraction"] > 0.35 and og["depth_prefetched"] == 79
+    ps = str(tmp_path / "gpu_serial.txt")  # depth assigned inside each frame's own process() call: the same bytes
+    assert run_limo_stream(gpu, 80, 2000, ps, extra=["--no-prefetch"])["depth_prefetched"] == 0 and open(ps).read() == open(pg).read()
     assert og["depth_fraction"] == oe["depth_fraction"]  # the depth assignment is bit-exact against its oracle (test_depth.py)
     a = np.array([l.split() for l in open(pg).read().splitlines() if l.strip()], float)
     b = np.array([l.split() for l in open(pe).read().splitlines() if l.strip()], float)
