@@ -6,14 +6,15 @@
 // drive is synthesised by synth_world.hpp) and of the node's callback (limo_amd/kba/stream_driver.hpp).
 //
 //   limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--poses out.txt] [--gt-poses gt.txt]
-//               [--dump-velodyne DIR] [--velodyne DIR] [--no-depth] [--no-prefetch] [--quiet]
+//               [--dump-velodyne DIR] [--velodyne DIR] [--no-depth] [--depth-ahead thread|stream|none] [--quiet]
 // --dump-velodyne writes every synthetic sweep as a KITTI velodyne scan (DIR/NNNNNN.bin); --velodyne replays scans from
 // such a directory instead of ray-casting them (the scans of a real KITTI sequence have the same format; the tracked
 // features of a real sequence come from the feature tracker, which is outside this path).
 // The sweeps are received into page-locked buffers (limo_host_alloc) and the input runs one frame ahead of the pipeline: the driver
-// starts the depth assignment of frame t+1 as soon as it has collected that of frame t (StreamDriver::announceNextFrame), so it runs
-// on the GPU under the pose refinement and the solve of frame t - the reference's depth estimator is a process of its own beside the
-// BA node.  --no-prefetch assigns every frame's depth inside its own process() call; the pose rows are the same, bit for bit.
+// assigns the depths of frame t+1 while the pose refinement and the solve of frame t run (StreamDriver::announceNextFrame) - the
+// reference's depth estimator is a process of its own beside the BA node.  --depth-ahead thread (default): a thread of the driver does
+// it; stream: the calling thread starts it on the driver's own HIP stream and collects it at the next frame (limo_depth_estimate_begin
+// / _end); none (= --no-prefetch): every frame's depths are assigned inside its own process() call.  Same pose rows, bit for bit.
 // Prints one summary line per run and `key value` lines for scripts: fps of the pipeline (input synthesis excluded and
 // reported separately), ATE against the ground truth, share of features that received a LiDAR depth.
 #include <chrono>
@@ -34,7 +35,8 @@ int main(int argc, char** argv) {
     int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
     uint64_t seed = 7;
     std::string poses_path, gt_path, dump_dir, replay_dir;
-    bool use_depth = true, quiet = false, five_point_prior = false, prefetch = true;
+    bool use_depth = true, quiet = false, five_point_prior = false;
+    StreamParams::DepthAhead depth_ahead = StreamParams::DepthAhead::Thread;
     double min_flow = -1., time_between_keyframes = -1.;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
@@ -50,11 +52,19 @@ int main(int argc, char** argv) {
         else if (arg("--dump-velodyne")) dump_dir = argv[++i];
         else if (arg("--velodyne")) replay_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--no-depth")) use_depth = false;
-        else if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
+        else if (!std::strcmp(argv[i], "--no-prefetch")) depth_ahead = StreamParams::DepthAhead::None;
+        else if (arg("--depth-ahead")) {
+            const std::string m = argv[++i];
+            if (m != "thread" && m != "stream" && m != "none") {
+                std::fprintf(stderr, "limo_stream: --depth-ahead thread|stream|none\n");
+                return 2;
+            }
+            depth_ahead = m == "thread" ? StreamParams::DepthAhead::Thread : m == "stream" ? StreamParams::DepthAhead::Stream : StreamParams::DepthAhead::None;
+        }
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else if (!std::strcmp(argv[i], "--five-point-prior")) five_point_prior = true;  // the node's prior without tf (mono_lidar.cpp:157-186)
         else {
-            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--no-prefetch] [--five-point-prior] [--quiet]\n");
+            std::fprintf(stderr, "usage: limo_stream [--frames N] [--features N] [--az N] [--seed S] [--window K] [--min-flow px] [--time-between-keyframes sec] [--poses file] [--gt-poses file] [--dump-velodyne dir] [--velodyne dir] [--no-depth] [--depth-ahead thread|stream|none] [--five-point-prior] [--quiet]\n");
             return 2;
         }
     }
@@ -65,6 +75,7 @@ int main(int argc, char** argv) {
     StreamParams sp;
     sp.max_size_optimization_window = window;
     sp.assign_depth = use_depth;
+    sp.depth_ahead = depth_ahead;
     if (min_flow >= 0.) sp.min_median_flow = min_flow;
     if (time_between_keyframes > 0.) sp.time_between_keyframes_sec = time_between_keyframes;
     if (five_point_prior) sp.motion_prior = StreamParams::MotionPrior::FivePoint;
@@ -175,8 +186,9 @@ int main(int argc, char** argv) {
             return 1;
         }
         const auto t1 = clk::now();
-        if (prefetch && t + 1 < n_frames) driver.announceNextFrame(next.ts, next.scan, next.n_pts);
+        if (t + 1 < n_frames) driver.announceNextFrame(next.ts, next.scan, next.n_pts);
         driver.process(std::move(cur.ts), cur.scan, cur.n_pts);  // (the tracker's message is handed over: the driver fills in depths)
+        driver.waitForDepthAhead();  // (the depth thread's work on frame t+1 belongs to this timed region, not to the synthesis below)
         const auto t2 = clk::now();
         sec_synth += std::chrono::duration<double>(t1 - t0).count();
         sec_pipeline += std::chrono::duration<double>(t2 - t1).count();
@@ -221,10 +233,12 @@ int main(int argc, char** argv) {
     std::printf("limo_stream: pipeline %.2f ms per frame -> %.1f frames/s (depth %.2f, pose-only %.2f, push %.2f, solve %.2f ms per frame; %.2f ms per solve()); input synthesis %.1f ms per frame\n",
                 1e3 * sec_pipeline / n_frames, n_frames / sec_pipeline, 1e3 * st.sec_depth / n_frames, 1e3 * st.sec_pose_only / n_frames,
                 1e3 * st.sec_push / n_frames, 1e3 * st.sec_solve / n_frames, st.solves ? 1e3 * st.sec_solve / st.solves : 0., 1e3 * sec_synth / n_frames);
-    std::printf("limo_stream: host side per frame: Keyframe object %.2f, keyframe selection %.2f, window cut + labels %.2f ms; inside the C-ABI: adjustPoseOnly %.2f of %.2f, solve %.2f of %.2f ms per frame; depth of %d frames started one frame ahead\n",
+    std::printf("limo_stream: host side per frame: Keyframe object %.2f, keyframe selection %.2f, window cut + labels %.2f ms; inside the C-ABI: adjustPoseOnly %.2f of %.2f, solve %.2f of %.2f ms per frame\n",
                 1e3 * st.sec_keyframe / n_frames, 1e3 * st.sec_select / n_frames, 1e3 * st.sec_window / n_frames, 1e3 * st.sec_abi_pose_only / n_frames,
-                1e3 * st.sec_pose_only / n_frames, 1e3 * st.sec_abi_solve / n_frames, 1e3 * st.sec_solve / n_frames, st.depth_prefetched);
-    std::printf("limo_stream: of the depth time, %.3f ms per frame is the per-track depth history\n", 1e3 * st.sec_depth_history / n_frames);
+                1e3 * st.sec_pose_only / n_frames, 1e3 * st.sec_abi_solve / n_frames, 1e3 * st.sec_solve / n_frames);
+    std::printf("limo_stream: depth assignment one frame ahead (%s) for %d frames: %.2f ms per frame on the depth thread; per-track depth history %.3f ms per frame\n",
+                depth_ahead == StreamParams::DepthAhead::Thread ? "thread" : depth_ahead == StreamParams::DepthAhead::Stream ? "stream" : "none", st.depth_prefetched,
+                1e3 * st.sec_depth_thread / n_frames, 1e3 * st.sec_depth_history / n_frames);
     std::printf("limo_stream: ATE rmse %.4f m (max %.4f m) over %.1f m\n", ate, worst, 0.55 * (n_frames - 1));
     if (te.rel_samples)
         std::printf("limo_stream: relative errors over 100..800 m sub-paths (KITTI devkit measure, %d samples): translation %.3f %%, rotation %.5f deg/m\n",

@@ -17,11 +17,14 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <ostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -60,6 +63,18 @@ struct StreamParams {
     int add_depth_landmarks_newest = 0;                                // the node has this rule commented out (:412-416)
     // depth assignment
     bool assign_depth = true;
+    // How the depth assignment of a frame announced with announceNextFrame runs ahead of the frame before it (the reference's depth
+    // estimator is a process of its own beside the BA node, kitti_standalone.launch:14-23, :55: it works on frame t+1 while the
+    // bundle adjuster works on frame t):
+    //   Thread  a thread of this driver - the "depth node" - does all of it (limo_depth_estimate on the driver's own context, the
+    //           per-track depth history, the depth of every point of the tracker's message as one array the calling thread copies
+    //           into the message when it takes the frame) while the calling thread runs frame t
+    //   Stream  the calling thread starts it (limo_depth_estimate_begin: copies and kernels on the driver's own stream) and collects
+    //           it at the start of the next process() call (limo_depth_estimate_end): no second thread, only the GPU time is hidden
+    //   None    announceNextFrame is ignored
+    // The results are the same bits in all three.
+    enum class DepthAhead { None, Stream, Thread };
+    DepthAhead depth_ahead = DepthAhead::Thread;
     int image_width = 1241, image_height = 376;
     std::vector<int> ground_labels{6, 7, 8, 9, 10};  // cityscapes labels treated as ground (labels_["ground"])
 };
@@ -72,6 +87,7 @@ public:
         // host-side bookkeeping of a frame: the Keyframe object of the frame (measurement maps of its tracks), keyframe
         // selection, window cut + labels; and of sec_pose_only / sec_solve the share spent inside the C-ABI calls
         double sec_keyframe = 0., sec_select = 0., sec_window = 0., sec_abi_pose_only = 0., sec_abi_solve = 0., sec_depth_history = 0.;
+        double sec_depth_thread = 0.;  // time the depth thread worked (beside the calling thread: not part of sec_total)
     };
 
     StreamDriver(const StreamParams& p, Camera::Ptr camera, const EigenPose& T_camera_lidar) : p_(p), camera_(camera), T_cam_lidar_(T_camera_lidar) {
@@ -101,7 +117,18 @@ public:
         limo_depth_default_params(&depth_params_);
     }
     ~StreamDriver() {
-        cancelPrefetch();
+        try {
+            cancelPrefetch();
+        } catch (...) {  // (an error of a depth job nobody picked up)
+        }
+        if (worker_.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(job_mutex_);
+                job_state_ = JobState::Exit;
+            }
+            job_cv_.notify_all();
+            worker_.join();
+        }
         if (ctx_) limo_ctx_destroy(ctx_);
     }
     StreamDriver(const StreamDriver&) = delete;
@@ -130,17 +157,25 @@ public:
         stats_.sec_depth += std::chrono::duration<double>(clk::now() - t0).count();
     }
 
-    // The same, deferred: the NEXT process() call starts this frame's depth assignment as soon as it has collected its own (one
-    // assignment is open per context at a time, so that is the earliest moment).  Both arguments must stay valid until then.
+    // The frame after the one the NEXT process() call is given: that call starts its depth assignment (StreamParams::depth_ahead)
+    // as soon as it has finished its own - the depths of a track's older points come from the frames before, so the frames'
+    // assignments run in order.  `tracklets` is the very object that will be handed to process() afterwards (an rvalue of it):
+    // the depth thread reads it; it and the sweep must stay valid and untouched until then.
     void announceNextFrame(const Tracklets& tracklets, const float* cloud_xyzi, size_t n_pts) {
         next_tracklets_ = &tracklets;
         next_cloud_ = cloud_xyzi;
         next_n_pts_ = n_pts;
     }
 
+    // Thread mode: returns when the depth thread has finished the frame it was given (a caller that times process() calls puts the
+    // thread's work inside the timed region with it; process() waits by itself otherwise).
+    void waitForDepthAhead() { waitForDepthThread(); }
+
     // Drop what prefetchDepth / announceNextFrame started (the sweep buffer is about to go away).
     void cancelPrefetch() {
         next_tracklets_ = nullptr;
+        waitForDepthThread();
+        ahead_done_ = nullptr;
         closeOpenDepthCall();
     }
 
@@ -150,17 +185,32 @@ public:
     // from what this driver assigned to the same track in earlier frames.  external_prior: keyframe <- origin pose of the
     // frame if the caller has one (the node's tf prior), else constant velocity.
     // Returns the frame's pose estimate (keyframe <- origin).
-    EigenPose process(Tracklets tracklets, const float* cloud_xyzi, size_t n_pts, const EigenPose* external_prior = nullptr) {
+    EigenPose process(const Tracklets& message, const float* cloud_xyzi, size_t n_pts, const EigenPose* external_prior = nullptr) {
+        return process(Tracklets(message), cloud_xyzi, n_pts, external_prior);
+    }
+    EigenPose process(Tracklets&& message, const float* cloud_xyzi, size_t n_pts, const EigenPose* external_prior = nullptr) {
         using clk = std::chrono::steady_clock;
         const auto t_begin = clk::now();
+        waitForDepthThread();  // (it may be writing into `message`)
+        const bool depth_done = ahead_done_ == &message;
+        ahead_done_ = nullptr;
+        Tracklets tracklets(std::move(message));
         if (tracklets.stamps.empty()) return last_pose_;  // (:98-104)
         const TimestampNSec stamp = tracklets.stamps.front();
-        assignDepth(tracklets, cloud_xyzi, n_pts);
+        if (depth_done) {  // computed by the depth thread: into the message
+            applyDepths(tracklets, point_d_);
+            ++stats_.depth_prefetched;
+        } else {
+            assignDepth(tracklets, cloud_xyzi, n_pts);
+        }
         stats_.sec_depth += std::chrono::duration<double>(clk::now() - t_begin).count();
         if (next_tracklets_) {  // announceNextFrame
             const Tracklets* next = next_tracklets_;
             next_tracklets_ = nullptr;
-            prefetchDepth(*next, next_cloud_, next_n_pts_);
+            if (p_.depth_ahead == StreamParams::DepthAhead::Stream)
+                prefetchDepth(*next, next_cloud_, next_n_pts_);
+            else if (p_.depth_ahead == StreamParams::DepthAhead::Thread)
+                startDepthThreadJob(next, next_cloud_, next_n_pts_);
         }
         Plane ground_plane;
         ground_plane.distance = p_.height_over_ground;
@@ -307,6 +357,62 @@ private:
         }
     }
 
+    // ---- the depth thread (StreamParams::DepthAhead::Thread): one job at a time = assignDepth of the announced frame
+    enum class JobState { Idle, Pending, Running, Exit };
+    void startDepthThreadJob(const Tracklets* ts, const float* cloud, size_t n_pts) {
+        if (!worker_.joinable()) worker_ = std::thread([this] { depthThreadMain(); });
+        {
+            std::lock_guard<std::mutex> lk(job_mutex_);
+            job_ts_ = ts;
+            job_cloud_ = cloud;
+            job_n_pts_ = n_pts;
+            job_error_ = nullptr;
+            job_state_ = JobState::Pending;
+        }
+        job_cv_.notify_all();
+    }
+    // returns when no job is pending or running; a job that has finished leaves its frame in ahead_done_ (its error is rethrown here)
+    void waitForDepthThread() {
+        if (!worker_.joinable()) return;
+        std::unique_lock<std::mutex> lk(job_mutex_);
+        job_cv_.wait(lk, [this] { return job_state_ == JobState::Idle; });
+        if (job_ts_) {
+            ahead_done_ = job_ts_;
+            job_ts_ = nullptr;
+        }
+        if (job_error_) {
+            std::exception_ptr e = job_error_;
+            job_error_ = nullptr;
+            ahead_done_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    void depthThreadMain() {
+        std::unique_lock<std::mutex> lk(job_mutex_);
+        for (;;) {
+            job_cv_.wait(lk, [this] { return job_state_ == JobState::Pending || job_state_ == JobState::Exit; });
+            if (job_state_ == JobState::Exit) return;
+            job_state_ = JobState::Running;
+            const Tracklets* ts = job_ts_;
+            const float* cloud = job_cloud_;
+            const size_t n_pts = job_n_pts_;
+            lk.unlock();
+            std::exception_ptr err;
+            const auto t0 = std::chrono::steady_clock::now();
+            try {
+                if (!ts->stamps.empty()) computeDepths(*ts, cloud, n_pts, point_d_);
+            } catch (...) {
+                err = std::current_exception();
+            }
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            lk.lock();
+            stats_.sec_depth_thread += sec;
+            job_error_ = err;
+            if (job_state_ != JobState::Exit) job_state_ = JobState::Idle;
+            job_cv_.notify_all();
+        }
+    }
+
     void closeOpenDepthCall() {  // a prefetch nobody will pick up: its limo_depth_estimate_end, results dropped
         if (!prefetch_open_) return;
         prefetch_open_ = false;
@@ -316,9 +422,18 @@ private:
 
     // FeaturePoint::d of the tracks: newest point from the sweep (limo_depth_estimate), history from earlier frames.
     void assignDepth(Tracklets& ts, const float* cloud, size_t n_pts) {
+        computeDepths(ts, cloud, n_pts, point_d_);
+        applyDepths(ts, point_d_);
+    }
+    // ... in two steps: computeDepths reads the message and writes the depth of EVERY point of every track, in message order, into
+    // `out`; applyDepths copies them into the message.  (The depth thread does the first step only: what it hands over is one
+    // contiguous array - had it written into the message, the calling thread would later fetch every track's points from the
+    // other core's cache, which cost as much as the thread saved.)
+    void computeDepths(const Tracklets& ts, const float* cloud, size_t n_pts, std::vector<float>& out) {
         const size_t n = ts.tracks.size();
         stats_.features += (int)n;
-        if (p_.assign_depth && cloud && n_pts && n) {
+        const bool from_sweep = p_.assign_depth && cloud && n_pts && n;
+        if (from_sweep) {
             depth_.assign(n, -1.f);
             if (prefetch_open_ && prefetch_stamp_ == ts.stamps.front() && prefetch_n_ == n) {  // started by prefetchDepth
                 prefetch_open_ = false;
@@ -334,35 +449,39 @@ private:
                                                    &depth_params_, depth_.data());
                 if (rc != LIMO_OK) throw std::runtime_error(std::string("limo_depth_estimate: ") + limo_last_error(ctx_));
             }
-            for (size_t i = 0; i < n; ++i)
-                if (ts.tracks[i].feature_points[0].d < 0.f) ts.tracks[i].feature_points[0].d = depth_[i];
         }
         // remember this frame's depth per track, fill the history points from the memory (ring of the last frames)
         const auto t_hist = std::chrono::steady_clock::now();
         const TimestampNSec stamp = ts.stamps.front();
-        for (auto& tr : ts.tracks) {
+        out.clear();
+        for (size_t i = 0; i < n; ++i) {
+            const Tracklet& tr = ts.tracks[i];
+            if (tr.feature_points.empty()) continue;
+            const float d0 = (from_sweep && tr.feature_points[0].d < 0.f) ? depth_[i] : tr.feature_points[0].d;  // (a depth the caller knows stays)
+            out.push_back(d0);
             History& h = history_[tr.id];
             h.stamp[h.head] = stamp;
-            h.d[h.head] = tr.feature_points[0].d;
+            h.d[h.head] = d0;
             h.head = (h.head + 1) & (History::kDepth - 1);
             h.n = std::min<int>(History::kDepth, h.n + 1);
-            for (size_t k = 1; k < tr.feature_points.size() && k < ts.stamps.size(); ++k) {
-                if (tr.feature_points[k].d >= 0.f) continue;
-                // (a track seen in consecutive frames has the entry of stamps[k] k places behind the newest: looked at first; stamps
-                // are unique inside a history, so the scan below finds the same entry or none)
-                if ((int)k < h.n) {
+            for (size_t k = 1; k < tr.feature_points.size(); ++k) {
+                float dk = tr.feature_points[k].d;
+                if (dk < 0.f && k < ts.stamps.size()) {
+                    // (a track seen in consecutive frames has the entry of stamps[k] k places behind the newest: looked at first; stamps
+                    // are unique inside a history, so the scan finds the same entry or none)
                     const int e = (h.head - 1 - (int)k) & (History::kDepth - 1);
-                    if (h.stamp[e] == ts.stamps[k]) {
-                        tr.feature_points[k].d = h.d[e];
-                        continue;
+                    if ((int)k < h.n && h.stamp[e] == ts.stamps[k]) {
+                        dk = h.d[e];
+                    } else {
+                        for (int j = 0; j < h.n; ++j) {
+                            const int e2 = (h.head - 1 - j) & (History::kDepth - 1);
+                            if (h.stamp[e2] == ts.stamps[k]) dk = h.d[e2];
+                        }
                     }
                 }
-                for (int j = 0; j < h.n; ++j) {
-                    const int e = (h.head - 1 - j) & (History::kDepth - 1);
-                    if (h.stamp[e] == ts.stamps[k]) tr.feature_points[k].d = h.d[e];
-                }
+                out.push_back(dk);
             }
-            stats_.features_with_depth += tr.feature_points[0].d > 0.f;
+            stats_.features_with_depth += d0 > 0.f;
         }
         stats_.sec_depth_history += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_hist).count();
         if (++frames_since_gc_ >= 64) {  // forget tracks that ended
@@ -371,6 +490,11 @@ private:
             for (auto it = history_.begin(); it != history_.end();)
                 it = it->second.stamp[(it->second.head - 1) & (History::kDepth - 1)] < oldest ? history_.erase(it) : std::next(it);
         }
+    }
+    static void applyDepths(Tracklets& ts, const std::vector<float>& d) {
+        size_t j = 0;
+        for (auto& tr : ts.tracks)
+            for (auto& fp : tr.feature_points) fp.d = d[j++];
     }
 
     StreamParams p_;
@@ -388,11 +512,20 @@ private:
     };
     std::unordered_map<unsigned long, History> history_;
     int frames_since_gc_ = 0;
-    std::vector<float> uv_, depth_;
+    std::vector<float> uv_, depth_, point_d_;
     std::vector<uint8_t> ground_;
     bool prefetch_open_ = false;  // prefetchDepth: a limo_depth_estimate_begin whose frame process() has not seen yet
     TimestampNSec prefetch_stamp_ = 0;
     size_t prefetch_n_ = 0;
+    std::thread worker_;  // the depth thread and its one job slot
+    std::mutex job_mutex_;
+    std::condition_variable job_cv_;
+    JobState job_state_ = JobState::Idle;
+    const Tracklets* job_ts_ = nullptr;
+    const float* job_cloud_ = nullptr;
+    size_t job_n_pts_ = 0;
+    std::exception_ptr job_error_;
+    const Tracklets* ahead_done_ = nullptr;  // the message whose depths the depth thread has already assigned
     const Tracklets* next_tracklets_ = nullptr;  // announceNextFrame
     const float* next_cloud_ = nullptr;
     size_t next_n_pts_ = 0;

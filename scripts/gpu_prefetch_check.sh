@@ -6,8 +6,8 @@ timeout 600 python -m pytest tests/test_depth.py -q -m gpu -k "two_halves or bat
 timeout 600 python -m pytest tests/test_kba_shim.py -q -m gpu -k "emulated_drive" 2>&1 | tail -3
 FRAMES=${1:-4541}
 app=$(python -c "import sys; sys.path.insert(0,'tests'); import emu_ffi; print(emu_ffi.build_stream_app(gpu=True))")
-for mode in "" "--no-prefetch" ""; do
-  echo "== limo_stream $mode"
-  timeout 900 $app --frames $FRAMES --az 2000 $mode --poses gpurun_out/poses_prefetch${mode:+_off}.txt 2>&1 | grep -E "^limo_stream: (pipeline|host)|^fps|^depth_prefetched"
+for mode in thread stream none thread; do
+  echo "== limo_stream --depth-ahead $mode"
+  timeout 900 $app --frames $FRAMES --az 2000 --depth-ahead $mode --poses gpurun_out/poses_ahead_$mode.txt 2>&1 | grep -E "^limo_stream: (pipeline|host|depth)|^fps"
 done | tee gpurun_out/prefetch_ab.log
-md5sum gpurun_out/poses_prefetch.txt gpurun_out/poses_prefetch_off.txt | tee -a gpurun_out/prefetch_ab.log
+md5sum gpurun_out/poses_ahead_*.txt | tee -a gpurun_out/prefetch_ab.log

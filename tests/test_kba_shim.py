@@ -115,12 +115,14 @@ def test_limo_stream_with_emulated_backend(tmp_path):
     assert want.shape == got.shape and np.abs(want - got).max() <= 1e-9, np.abs(want - got).max()
     first = np.array(rows[0], float).reshape(3, 4)
     assert np.allclose(first, np.eye(4)[:3], atol=1e-12)        # the first frame is the origin
-    # the driver started the depth assignment of every frame but the first one frame ahead (StreamDriver::announceNextFrame ->
-    # limo_depth_estimate_begin / _end); assigned inside each frame's own process() call instead, the rows are the same bytes
-    assert out["depth_prefetched"] == 39
-    serial = str(tmp_path / "poses_serial.txt")
-    assert run_limo_stream(exe, 40, 2000, serial, extra=["--no-prefetch"])["depth_prefetched"] == 0
-    assert open(serial).read() == open(poses).read()
+    # the driver assigned the depths of every frame but the first one frame ahead (StreamDriver::announceNextFrame: on its depth
+    # thread; --depth-ahead stream: limo_depth_estimate_begin / _end on the calling thread); assigned inside each frame's own
+    # process() call instead (none), the rows are the same bytes
+    assert out["depth_prefetched"] == 39  # (default: the driver's depth thread)
+    for mode, n_ahead in (("stream", 39), ("none", 0)):
+        other = str(tmp_path / ("poses_%s.txt" % mode))
+        assert run_limo_stream(exe, 40, 2000, other, extra=["--depth-ahead", mode])["depth_prefetched"] == n_ahead
+        assert open(other).read() == open(poses).read()
     no_depth = run_limo_stream(exe, 40, 2000, extra=["--no-depth"])
     assert no_depth["depth_fraction"] == 0.0 and no_depth["ate_rmse"] > out["ate_rmse"]  # monocular: scale drifts without LiDAR
     # the node's own prior when it has no tf: five-point direction + the last keyframes' speed (mono_lidar.cpp:157-186,
@@ -157,8 +159,9 @@ def test_limo_stream_on_gpu_matches_the_emulated_drive(tmp_path):
     og = run_limo_stream(gpu, 80, 2000, pg)
     oe = run_limo_stream(emu, 80, 2000, pe)
     assert og["ate_rmse"] < 0.05 and og["depth_fraction"] > 0.35 and og["depth_prefetched"] == 79
-    ps = str(tmp_path / "gpu_serial.txt")  # depth assigned inside each frame's own process() call: the same bytes
-    assert run_limo_stream(gpu, 80, 2000, ps, extra=["--no-prefetch"])["depth_prefetched"] == 0 and open(ps).read() == open(pg).read()
+    for mode, n_ahead in (("stream", 79), ("none", 0)):  # the depth thread (default), begin / _end on the calling thread, no look-ahead: the same bytes
+        ps = str(tmp_path / ("gpu_%s.txt" % mode))
+        assert run_limo_stream(gpu, 80, 2000, ps, extra=["--depth-ahead", mode])["depth_prefetched"] == n_ahead and open(ps).read() == open(pg).read()
     assert og["depth_fraction"] == oe["depth_fraction"]  # the depth assignment is bit-exact against its oracle (test_depth.py)
     a = np.array([l.split() for l in open(pg).read().splitlines() if l.strip()], float)
     b = np.array([l.split() for l in open(pe).read().splitlines() if l.strip()], float)
