@@ -641,8 +641,9 @@ std::string BundleAdjusterKeyframes::solve() {
                     rep.n_repr_blocks, rep.n_gp_blocks, rep.initial_cost, rep.final_cost, rep.time_sec};
     if (shim_trace) {
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        std::fprintf(stderr, "[shim] solve: %zu active landmarks, %zu selected: active maps %.0f us, selection %.0f us, flatten %.0f us, limo_ba_solve %.0f us, write-back %.0f us\n",
-                     active_landmark_ids_.size(), selected_landmark_ids_.size(), us(t_s0, t_s0b), us(t_s0b, t_s1), us(t_s1, t_s2), us(t_s2, t_s3), us(t_s3, clk::now()));
+        std::fprintf(stderr, "[shim] solve: %zu active landmarks, %zu selected, %d LM iterations in %d solves: active maps %.0f us, selection %.0f us, flatten %.0f us, limo_ba_solve %.0f us, write-back %.0f us\n",
+                     active_landmark_ids_.size(), selected_landmark_ids_.size(), rep.iterations_total, rep.num_solves, us(t_s0, t_s0b), us(t_s0b, t_s1), us(t_s1, t_s2),
+                     us(t_s2, t_s3), us(t_s3, clk::now()));
     }
     return report_string(rep, "solve");
 }
