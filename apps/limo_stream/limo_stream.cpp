@@ -32,7 +32,7 @@
 using namespace keyframe_bundle_adjustment;
 
 int main(int argc, char** argv) {
-    int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5;
+    int n_frames = 200, n_feat = 1500, n_az = 2000, window = 5, misannounce_every = 0;
     uint64_t seed = 7;
     std::string poses_path, gt_path, dump_dir, replay_dir;
     bool use_depth = true, quiet = false, five_point_prior = false;
@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
         else if (arg("--az")) n_az = std::atoi(argv[++i]);
         else if (arg("--seed")) seed = std::strtoull(argv[++i], nullptr, 10);
         else if (arg("--window")) window = std::atoi(argv[++i]);
+        else if (arg("--misannounce-every")) misannounce_every = std::atoi(argv[++i]);  // (testing aid, see the frame loop)
         else if (arg("--min-flow")) min_flow = std::atof(argv[++i]);
         else if (arg("--time-between-keyframes")) time_between_keyframes = std::atof(argv[++i]);
         else if (arg("--poses")) poses_path = argv[++i];
@@ -177,6 +178,7 @@ int main(int argc, char** argv) {
         }
         sec_synth += std::chrono::duration<double>(clk::now() - t0).count();
     }
+    Tracklets stale;
     for (int t = 0; t < n_frames; ++t) {
         Frame& cur = frames[t & 1];
         Frame& next = frames[(t + 1) & 1];
@@ -186,7 +188,13 @@ int main(int argc, char** argv) {
             return 1;
         }
         const auto t1 = clk::now();
-        if (t + 1 < n_frames) driver.announceNextFrame(next.ts, next.scan, next.n_pts);
+        // --misannounce-every N (testing aid): every N-th frame the driver is told that the CURRENT frame comes next - what it prepares
+        // then does not belong to the frame it gets, must be dropped, and the pose rows must not change
+        if (misannounce_every > 0 && t % misannounce_every == misannounce_every - 1) {
+            stale = cur.ts;
+            driver.announceNextFrame(stale, cur.scan, cur.n_pts);
+        } else if (t + 1 < n_frames)
+            driver.announceNextFrame(next.ts, next.scan, next.n_pts);
         driver.process(std::move(cur.ts), cur.scan, cur.n_pts);  // (the tracker's message is handed over: the driver fills in depths)
         driver.waitForDepthAhead();  // (the depth thread's work on frame t+1 belongs to this timed region, not to the synthesis below)
         const auto t2 = clk::now();

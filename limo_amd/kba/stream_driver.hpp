@@ -175,7 +175,7 @@ public:
     void cancelPrefetch() {
         next_tracklets_ = nullptr;
         waitForDepthThread();
-        ahead_done_ = nullptr;
+        ahead_valid_ = false;
         closeOpenDepthCall();
     }
 
@@ -192,10 +192,14 @@ public:
         using clk = std::chrono::steady_clock;
         const auto t_begin = clk::now();
         waitForDepthThread();  // (it may be writing into `message`)
-        const bool depth_done = ahead_done_ == &message;
-        ahead_done_ = nullptr;
         Tracklets tracklets(std::move(message));
         if (tracklets.stamps.empty()) return last_pose_;  // (:98-104)
+        // what the depth thread prepared belongs to this message iff stamp, track count and point count agree (a copy of the announced
+        // message is as good as the object itself; anything else is assigned here and the prepared depths are dropped)
+        size_t n_points = 0;
+        for (const auto& tr : tracklets.tracks) n_points += tr.feature_points.size();
+        const bool depth_done = ahead_valid_ && ahead_stamp_ == tracklets.stamps.front() && ahead_tracks_ == tracklets.tracks.size() && point_d_.size() == n_points;
+        ahead_valid_ = false;
         const TimestampNSec stamp = tracklets.stamps.front();
         if (depth_done) {  // computed by the depth thread: into the message
             applyDepths(tracklets, point_d_);
@@ -371,19 +375,21 @@ private:
         }
         job_cv_.notify_all();
     }
-    // returns when no job is pending or running; a job that has finished leaves its frame in ahead_done_ (its error is rethrown here)
+    // returns when no job is pending or running; a job that has finished leaves its frame's identity in ahead_* (its error is rethrown here)
     void waitForDepthThread() {
         if (!worker_.joinable()) return;
         std::unique_lock<std::mutex> lk(job_mutex_);
         job_cv_.wait(lk, [this] { return job_state_ == JobState::Idle; });
         if (job_ts_) {
-            ahead_done_ = job_ts_;
+            ahead_valid_ = !job_ts_->stamps.empty();
+            ahead_stamp_ = ahead_valid_ ? job_ts_->stamps.front() : 0;
+            ahead_tracks_ = job_ts_->tracks.size();
             job_ts_ = nullptr;
         }
         if (job_error_) {
             std::exception_ptr e = job_error_;
             job_error_ = nullptr;
-            ahead_done_ = nullptr;
+            ahead_valid_ = false;
             std::rethrow_exception(e);
         }
     }
@@ -525,7 +531,9 @@ private:
     const float* job_cloud_ = nullptr;
     size_t job_n_pts_ = 0;
     std::exception_ptr job_error_;
-    const Tracklets* ahead_done_ = nullptr;  // the message whose depths the depth thread has already assigned
+    bool ahead_valid_ = false;  // point_d_ holds the depths the depth thread computed for the message (ahead_stamp_, ahead_tracks_)
+    TimestampNSec ahead_stamp_ = 0;
+    size_t ahead_tracks_ = 0;
     const Tracklets* next_tracklets_ = nullptr;  // announceNextFrame
     const float* next_cloud_ = nullptr;
     size_t next_n_pts_ = 0;

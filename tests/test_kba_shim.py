@@ -123,6 +123,12 @@ def test_limo_stream_with_emulated_backend(tmp_path):
         other = str(tmp_path / ("poses_%s.txt" % mode))
         assert run_limo_stream(exe, 40, 2000, other, extra=["--depth-ahead", mode])["depth_prefetched"] == n_ahead
         assert open(other).read() == open(poses).read()
+    # a frame announced that is NOT the one process() gets next (every third call announces the current frame again): what was
+    # prepared is recognised as foreign (stamp / counts), dropped, the frame's depths are assigned in its own call - same bytes
+    for mode in ("thread", "stream"):
+        other = str(tmp_path / ("poses_mis_%s.txt" % mode))
+        mis = run_limo_stream(exe, 40, 2000, other, extra=["--depth-ahead", mode, "--misannounce-every", "3"])
+        assert 0 < mis["depth_prefetched"] < 39 and open(other).read() == open(poses).read()
     no_depth = run_limo_stream(exe, 40, 2000, extra=["--no-depth"])
     assert no_depth["depth_fraction"] == 0.0 and no_depth["ate_rmse"] > out["ate_rmse"]  # monocular: scale drifts without LiDAR
     # the node's own prior when it has no tf: five-point direction + the last keyframes' speed (mono_lidar.cpp:157-186,
