@@ -84,7 +84,7 @@ def collect(passes, timeout, workload=None, per_pass=90.0):
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         for i, grp in enumerate(groups):
             left = min(per_pass, t_end - time.time())
-            if left < 20:
+            if left < 3:
                 failed.append("pass %d (%s): out of time" % (i, " ".join(grp)))
                 continue
             cmd = [rocprof, "--pmc"] + grp + ["--kernel-trace", "-d", os.path.join(tmp, "p%d" % i), "-o", "p", "--"] + workload

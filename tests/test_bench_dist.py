@@ -105,7 +105,7 @@ def test_counter_collection_skips_a_pass_that_hangs(tmp_path, monkeypatch):
     spec = importlib.util.spec_from_file_location("pmc_collect", os.path.join(root, "scripts", "pmc_collect.py"))
     pmc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pmc)
-    out, err = pmc.collect(["hbm", "valu"], 120.0, workload=["true"], per_pass=21.0)
+    out, err = pmc.collect(["hbm", "valu"], 60.0, workload=["true"], per_pass=5.0)
     assert out is not None, err
     lin = out["kernels"]["k_lin_lm<3>"]
     assert lin["hbm_MB"] == (2 * 1000.0 + 500.0) * 1024 / 1e6 and abs(lin["hbm_bytes_per_observation"] - lin["hbm_MB"] * 1e6 / 10000) < 1e-9
@@ -120,6 +120,6 @@ def test_counter_collection_skips_a_pass_that_hangs(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "PMC_FILE", str(pmc_file))
     roof = {"_lin_obs": 2.0e7, "_lin_s": 0.7e-3 * 250, "launches": 250, "algorithmic_bytes_per_launch": 1.9e9}
     schur = {}
-    bench.fill_traffic(roof, schur, measure=True, timeout=75.0)
+    bench.fill_traffic(roof, schur, measure=True, timeout=15.0)
     assert roof["traffic_bytes_per_observation"] == lin["hbm_bytes_per_observation"] and "measured in this run" in roof["traffic_source"]
     assert roof["limited_by"]["valu_busy"] == 0.77 and "stored profile" in roof["traffic_source"] and "timed out" in roof["traffic_measurement_partial"]
