@@ -27,6 +27,9 @@ struct limo_ctx {
     std::map<size_t, std::vector<void*>> pool, host_pool;  // device blocks / pinned host blocks
     void* staging = nullptr;                // pinned host staging buffer of small uploads
     size_t staging_cap = 0;
+    void* staging_big = nullptr;            // pinned host buffer the results of a LARGE batch come back through (grow-only, <= kBigStageMax)
+    size_t staging_big_cap = 0;
+    static constexpr size_t kBigStageMax = 512u << 20;
 
     // Larger blocks (the arena of a 1024-window batch is ~1.5 GB) are kept too, in 64 MB classes, one per class and at most
     // kPoolLargeBytes altogether: hipMalloc / hipFree of blocks that size synchronise the DEVICE, so a caller that streams
@@ -93,5 +96,8 @@ struct limo_ctx {
         if (staging) (void)hipHostFree(staging);
         staging = nullptr;
         staging_cap = 0;
+        if (staging_big) (void)hipHostFree(staging_big);
+        staging_big = nullptr;
+        staging_big_cap = 0;
     }
 };

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kba_kernels.hip"
@@ -1325,12 +1327,31 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
         const char* lo = reinterpret_cast<const char*>(b->bv.st);
         const char* hi = reinterpret_cast<const char*>(b->bv.lm) + sizeof(double) * 3 * (size_t)P.TL;
         auto inside = [&](const void* q) { return reinterpret_cast<const char*>(q) >= lo && reinterpret_cast<const char*>(q) < hi; };
-        const bool one_span = hi > lo && (size_t)(hi - lo) <= ctx->staging_cap && ctx->staging && inside(b->bv.pose) && inside(b->bv.pdir) &&
-                              inside(b->bv.pdist) && (P.TL == 0 || inside(b->bv.lm));
-        if (one_span) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->staging, lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+        // A LARGE batch takes the same single copy through a pinned buffer the context keeps for it (grow-only, up to kBigStageMax):
+        // five copies into fresh pageable vectors were staged by the runtime and paid their page faults - 6 of the 10 ms a
+        // 1024-window download took.
+        const bool neighbours = hi > lo && inside(b->bv.pose) && inside(b->bv.pdir) && inside(b->bv.pdist) && (P.TL == 0 || inside(b->bv.lm));
+        const size_t span = neighbours ? (size_t)(hi - lo) : 0;
+        void* hbuf = nullptr;
+        if (neighbours && span <= ctx->staging_cap && ctx->staging) {
+            hbuf = ctx->staging;
+        } else if (neighbours && span <= limo_ctx::kBigStageMax) {
+            if (ctx->staging_big_cap < span) {
+                if (ctx->staging_big) (void)hipHostFree(ctx->staging_big);
+                ctx->staging_big = nullptr;
+                ctx->staging_big_cap = 0;
+                const size_t cap = std::min(limo_ctx::kBigStageMax, span + span / 4);
+                if (hipHostMalloc(&ctx->staging_big, cap) == hipSuccess)
+                    ctx->staging_big_cap = cap;
+                else
+                    (void)hipGetLastError();  // (no pinned memory to be had: the pageable path below)
+            }
+            if (ctx->staging_big_cap >= span) hbuf = ctx->staging_big;
+        }
+        if (hbuf) {
+            HIP_TRY(ctx, hipMemcpyAsync(hbuf, lo, span, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            const char* h = static_cast<const char*>(ctx->staging);
+            const char* h = static_cast<const char*>(hbuf);
             auto at = [&](const void* q) { return h + (reinterpret_cast<const char*>(q) - lo); };
             st = reinterpret_cast<const WinState*>(at(b->bv.st));
             pose = reinterpret_cast<const double*>(at(b->bv.pose));
@@ -1356,14 +1377,17 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
             st = st_v.data();
         }
     }
-    for (int w = 0; w < P.n_win; ++w) {
-        const WinDesc& d = P.win[w];
-        if (windows_out) {
-            limo_ba_window& W = windows_out[w];
-            if (W.n_kf != d.n_kf || W.n_lm != d.n_lm) {
+    if (windows_out)
+        for (int w = 0; w < P.n_win; ++w)
+            if (windows_out[w].n_kf != P.win[w].n_kf || windows_out[w].n_lm != P.win[w].n_lm) {
                 ctx->err = "download: window shape differs from create()";
                 return LIMO_ERR_INVALID;
             }
+    // windows are independent (every window writes its own arrays): host threads share them when the batch is large
+    auto one_window = [&](int w) {
+        const WinDesc& d = P.win[w];
+        if (windows_out) {
+            limo_ba_window& W = windows_out[w];
             std::memcpy(W.kf_pose, pose + 7 * (size_t)d.kf0, sizeof(double) * 7 * d.n_kf);
             std::memcpy(W.kf_plane_dir, pdir + 3 * (size_t)d.kf0, sizeof(double) * 3 * d.n_kf);
             std::memcpy(W.kf_plane_dist, pdist + d.kf0, sizeof(double) * d.n_kf);
@@ -1388,6 +1412,20 @@ int limo_ba_batch_download(limo_ba_batch* b, limo_ba_window* windows_out, limo_b
             r.final_cost = s.solve_final_cost;
             r.time_sec = b->last_solve_sec;
         }
+    };
+    unsigned nt = std::min({std::thread::hardware_concurrency(), 32u, (unsigned)(P.n_win / 32)});
+    if (const char* e = std::getenv("KBA_PACK_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+    if (nt <= 1) {
+        for (int w = 0; w < P.n_win; ++w) one_window(w);
+    } else {
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&] {
+                for (int w0 = next.fetch_add(8); w0 < P.n_win; w0 = next.fetch_add(8))
+                    for (int w = w0; w < std::min(w0 + 8, (int)P.n_win); ++w) one_window(w);
+            });
+        for (auto& th : pool) th.join();
     }
     return LIMO_OK;
 }
