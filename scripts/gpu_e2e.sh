@@ -1,12 +1,5 @@
 #!/bin/bash
 # end_to_end of the bench (pack + upload + solve + download of 1024 host windows) a few times, with the pack / create trace.
-cat > /tmp/e2e.py <<'PY'
-import os, sys, json, time
-sys.path.insert(0, os.getcwd())
-import bench
-from limo_amd import ba, default_options
-base = bench.make_windows(1024) if hasattr(bench, "make_windows") else None
-PY
 KBA_PACK_TRACE=1 python - <<'PY' 2>&1 | grep -E "\[kba\]|e2e" | tail -30
 import os, sys, time
 sys.path.insert(0, os.getcwd())
