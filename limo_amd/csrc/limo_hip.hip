@@ -1017,7 +1017,20 @@ struct limo_ba_batch : Executor {
         cp.plane_dep = d_plane_dep;
         cp.red = d_coop_red;
         void* args[] = {(void*)&bv, (void*)&c, (void*)&cp};
-        static const bool plain_launch = std::getenv("KBA_COOP_PLAIN_LAUNCH") != nullptr;  // (timing aid: no co-residency guarantee)
+        // A PLAIN launch by default, with the co-residency of the grid checked here against the occupancy the runtime reports
+        // (the workgroups of other kernels on the device all finish, so every workgroup of this grid gets its CU; a barrier that
+        // waits too long is recovered, coop_sync).  hipLaunchCooperativeKernel gives the same guarantee from the runtime, but
+        // after the first such launch of a process every LATER solve that uses several streams ran 30-50 % slower (a 2048-window
+        // batch 91 -> 118-137 ms, scripts/gpu_groups_sequence.py; with plain launches 91 ms) - KBA_COOP_PLAIN_LAUNCH=0 takes that API.
+        static const bool plain_launch = !(std::getenv("KBA_COOP_PLAIN_LAUNCH") && std::atoi(std::getenv("KBA_COOP_PLAIN_LAUNCH")) == 0);
+        if (plain_launch) {
+            int per_cu = 0, n_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_solve_coop, kBlock, (size_t)lds) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || per_cu * n_cu < coop_grid) {
+                (void)hipGetLastError();
+                return false;  // (not all workgroups resident at once: the launch sequence)
+            }
+        }
         const hipError_t e = plain_launch ? hipLaunchKernel((const void*)k_solve_coop, dim3(coop_grid), dim3(kBlock), args, lds, ctx->stream)
                                           : hipLaunchCooperativeKernel((const void*)k_solve_coop, dim3(coop_grid), dim3(kBlock), args, lds, ctx->stream);
         if (e != hipSuccess) {
