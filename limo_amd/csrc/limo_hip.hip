@@ -1044,7 +1044,9 @@ struct limo_ba_batch : Executor {
     // The host only enqueues; it learns that all windows are done from a pinned word the scheduler writes, two rounds
     // late (so the streams never drain inside a solve).
     int solve_streaming() {
-        int n_groups = P.n_win >= 2048 ? 2 : 1;
+        // two slot groups from 512 windows on (A/B at 256 .. 1536 windows: 5-9 % on the re-solve at every size; the FIRST solve of a batch
+        // pays the second group's streams and events, which a one-shot batch of 256 windows does not earn back: 44 vs 36 ms)
+        int n_groups = P.n_win >= 512 ? 2 : 1;
         if (const char* e = std::getenv("KBA_GROUPS")) n_groups = std::max(1, std::min(4, std::atoi(e)));
         if (stream_setup(n_groups) != LIMO_OK) return LIMO_ERR_RUNTIME;
         set_span(P.n_win);
