@@ -205,11 +205,6 @@ void BundleAdjusterKeyframes::set_solver_time(double s) {
 
 // ------------------------------------------------------------------------------------------ push / landmark creation
 namespace {
-bool containsDepth(const Keyframe& kf, const LandmarkId lId) {
-    for (const auto& cam_meas : kf.measurements_.at(lId))
-        if (cam_meas.second.d >= 0) return true;
-    return false;
-}
 limo_ray make_ray(const Camera& cam, const Keyframe& kf, const Measurement& m) {
     limo_ray r;
     const Pose pc = convert(cam.getEigenPose() * kf.getEigenPose());  // camera <- origin
@@ -244,15 +239,62 @@ void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
     std::vector<int32_t> off{0};
     std::vector<limo_ray> rays;
     std::vector<uint8_t> use_depth;
+    // The rays of one (keyframe, camera) share pose and intrinsics: that part is formed once per view here, not once per ray (the
+    // same statements on the same operands as make_ray - collectRays(..) below, which calculateLandmark still uses - so the same
+    // bits); the new ids come in ascending order, so every active keyframe's measurements are walked by a finder of their own
+    // instead of two tree searches per (landmark, keyframe).
+    struct View {
+        const Keyframe* kf;
+        CameraId cam;
+        limo_ray base;
+    };
+    auto views_of = [](const Keyframe& k, std::vector<View>& out) {
+        for (const auto& id_cam : k.cameras_) {
+            Measurement none;
+            none.u = none.v = 0.f;
+            none.d = -1.f;
+            out.push_back({&k, id_cam.first, make_ray(*id_cam.second, k, none)});
+        }
+    };
+    auto ray_of = [](const View& v, const Measurement& m) {
+        limo_ray r = v.base;
+        r.u = m.u;
+        r.v = m.v;
+        r.d = m.d;
+        return r;
+    };
+    std::vector<View> own_views, active_views;
+    views_of(kf, own_views);
+    using MeasFinder = SortedFinder<decltype(kf.measurements_)>;
+    std::vector<MeasFinder> finders;  // one per active keyframe, in the order of active_views' keyframes
+    std::vector<std::pair<size_t, size_t>> views_of_kf;  // [first, last) of active_views
+    for (const auto& id : active_keyframe_ids_) {
+        const Keyframe& k = *keyframes_.at(id);
+        const size_t first = active_views.size();
+        views_of(k, active_views);
+        views_of_kf.push_back({first, active_views.size()});
+        finders.emplace_back(k.measurements_);
+    }
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& m : kf.measurements_) {
         if (known.find(m.first) != landmarks_.cend()) continue;
-        const bool has_depth = containsDepth(kf, m.first);
+        bool has_depth = false;  // containsDepth(kf, id)
+        for (const auto& cam_meas : m.second) has_depth = has_depth || cam_meas.second.d >= 0;
         const size_t before = rays.size();
-        if (has_depth) {
-            collectRays(kf, m.first, rays);
-        } else {
-            collectRays(m.first, rays);
+        if (has_depth) {  // collectRays(kf, id): this keyframe's views of the landmark
+            for (const auto& cam_meas : m.second)
+                for (const View& v : own_views)
+                    if (v.cam == cam_meas.first) rays.push_back(ray_of(v, cam_meas.second));
+        } else {  // collectRays(id): every active keyframe / camera that sees the landmark (getMeasurementsAndPoses, :125-159)
+            for (size_t k = 0; k < finders.size(); ++k) {
+                const Keyframe& ak = *active_views[views_of_kf[k].first].kf;
+                const auto it = finders[k].find(m.first);
+                if (it == ak.measurements_.cend()) continue;
+                for (size_t vi = views_of_kf[k].first; vi < views_of_kf[k].second; ++vi) {
+                    const auto im = it->second.find(active_views[vi].cam);
+                    if (im != it->second.cend()) rays.push_back(ray_of(active_views[vi], im->second));
+                }
+            }
             if (rays.size() - before < 2) {  // not enough views to triangulate (:363-365)
                 rays.resize(before);
                 continue;

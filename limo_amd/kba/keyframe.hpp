@@ -2,6 +2,7 @@
 // keyframe_bundle_adjustment/include/keyframe_bundle_adjustment/keyframe.hpp:27-196 and src/keyframe.cpp.
 #pragma once
 #include <algorithm>
+#include <iterator>
 
 #include "definitions.hpp"
 
@@ -37,8 +38,14 @@ public:
     // alive yet.  (A stamp that is not listed gives column == stamps.size(), like std::distance to end() in the reference.)
     void assignMeasurements(const Tracklets& tracklets, const CameraId& cam_id) {
         const size_t col = stampColumn(tracklets.stamps);
-        for (const Tracklet& t : tracklets.tracks)
-            if (col < t.feature_points.size()) measurements_[t.id][cam_id] = t.feature_points[col];
+        for (const Tracklet& t : tracklets.tracks) {
+            if (col >= t.feature_points.size()) continue;
+            // (a tracker hands its tracks over in id order more often than not: an id above everything stored goes to the end of the
+            // map without a search; any other id takes the search operator[] would have made)
+            auto it = (measurements_.empty() || std::prev(measurements_.end())->first < t.id) ? measurements_.emplace_hint(measurements_.end(), t.id, std::map<CameraId, Measurement>())
+                                                                                              : measurements_.try_emplace(t.id).first;
+            it->second[cam_id] = t.feature_points[col];
+        }
     }
     // The same for a rig (src/keyframe.cpp:43-59): no per-camera copies of the tracklets - one pass, the column is found
     // once.  An id that `landmark_lookup` does not know throws std::out_of_range, as the reference's .at() does.
