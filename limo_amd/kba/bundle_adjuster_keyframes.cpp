@@ -367,7 +367,17 @@ bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d&
 // ------------------------------------------------------------------------------------------ labels
 void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_weight) {
     // (the three label sets are looked up once, not per track: a std::string key per lookup was a third of this function)
-    const std::set<int>&outlier_labels = labels_["outliers"], &shrubbery_labels = labels_["shrubbery"], &ground_labels = labels_["ground"];
+    // (... and turned into tables over the label value once per call: three std::set searches per track were half of what was left)
+    struct LabelSet {
+        const std::set<int>& s;
+        std::vector<char> table;  // labels 0 .. 255; anything else is looked up in the set
+        explicit LabelSet(const std::set<int>& set) : s(set), table(256, 0) {
+            for (int l : s)
+                if (l >= 0 && l < 256) table[l] = 1;
+        }
+        bool count(int l) const { return (l >= 0 && l < 256) ? table[l] != 0 : s.count(l) > 0; }
+    };
+    const LabelSet outlier_labels(labels_["outliers"]), shrubbery_labels(labels_["shrubbery"]), ground_labels(labels_["ground"]);
     std::set<LandmarkId> outlier_ids;
     for (const auto& id : landmark_selector_->getOutliers())
         if (active_landmark_ids_.count(id)) outlier_ids.insert(id);
@@ -383,7 +393,7 @@ void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_
         auto it = known.find(track.id);
         if (it == landmarks_.cend()) continue;
         if (shrubbery_labels.count(track.label)) it->second->weight = shrubbery_weight;
-        it->second->is_ground_plane = ground_labels.count(track.label) > 0;
+        it->second->is_ground_plane = ground_labels.count(track.label);
     }
 }
 
@@ -567,14 +577,22 @@ struct Flat {
         v.reserve(room);
         d.reserve(room);
         auto it = lm_index.cbegin();              // (measurements and index are both sorted by landmark id: one merge pass)
+        bool have_cam = false;                    // (camera id -> index of the flattened camera table, looked up when the id changes:
+        CameraId last_cam{};                      //  two map searches per observation were most of this function on a mono rig)
+        int last_cam_index = -1;
         for (const auto& m : kf.measurements_) {  // addKeyframeToProblem, :569-576
             while (it != lm_index.cend() && it->first < m.first) ++it;
             if (it == lm_index.cend()) break;
             if (it->first != m.first) continue;
             for (const auto& cam_meas : m.second) {
+                if (!have_cam || !(cam_meas.first == last_cam)) {
+                    last_cam_index = camera(*kf.cameras_.at(cam_meas.first));
+                    last_cam = cam_meas.first;
+                    have_cam = true;
+                }
                 obs_kf.push_back(k);
                 obs_lm.push_back(it->second);
-                obs_cam.push_back(camera(*kf.cameras_.at(cam_meas.first)));
+                obs_cam.push_back(last_cam_index);
                 u.push_back(cam_meas.second.u);
                 v.push_back(cam_meas.second.v);
                 d.push_back(cam_meas.second.d);
