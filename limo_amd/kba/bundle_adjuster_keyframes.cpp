@@ -459,10 +459,11 @@ const std::vector<LandmarkId>& BundleAdjusterKeyframes::measuredIds(const Keyfra
     std::vector<LandmarkId>& v = measured_ids_[kf.timestamp_];
     const auto& ms = kf.measurements_;
     const bool looks_right = v.size() == ms.size() && (v.empty() || (v.front() == ms.cbegin()->first && v.back() == ms.crbegin()->first));
-    if (!looks_right) {
+    if (!looks_right) {  // from the keyframe's measurement table (one row per (landmark, camera), ids ascending): each id once
         v.clear();
         v.reserve(ms.size());
-        for (const auto& m : ms) v.push_back(m.first);
+        for (const auto& row : kf.measurementTable())
+            if (v.empty() || v.back() != row.id) v.push_back(row.id);
     }
     return v;
 }
@@ -576,27 +577,28 @@ struct Flat {
         u.reserve(room);
         v.reserve(room);
         d.reserve(room);
-        auto it = lm_index.cbegin();              // (measurements and index are both sorted by landmark id: one merge pass)
-        bool have_cam = false;                    // (camera id -> index of the flattened camera table, looked up when the id changes:
-        CameraId last_cam{};                      //  two map searches per observation were most of this function on a mono rig)
+        // (the keyframe's measurement table and the index are both sorted by landmark id: one merge pass over two arrays; the map
+        // node of a measurement is only touched when its landmark is in the window)
+        const auto& rows = kf.measurementTable();
+        auto it = lm_index.cbegin();
+        bool have_cam = false;  // (camera id -> index of the flattened camera table, looked up when the id changes)
+        CameraId last_cam{};
         int last_cam_index = -1;
-        for (const auto& m : kf.measurements_) {  // addKeyframeToProblem, :569-576
-            while (it != lm_index.cend() && it->first < m.first) ++it;
+        for (const auto& row : rows) {  // addKeyframeToProblem, :569-576
+            while (it != lm_index.cend() && it->first < row.id) ++it;
             if (it == lm_index.cend()) break;
-            if (it->first != m.first) continue;
-            for (const auto& cam_meas : m.second) {
-                if (!have_cam || !(cam_meas.first == last_cam)) {
-                    last_cam_index = camera(*kf.cameras_.at(cam_meas.first));
-                    last_cam = cam_meas.first;
-                    have_cam = true;
-                }
-                obs_kf.push_back(k);
-                obs_lm.push_back(it->second);
-                obs_cam.push_back(last_cam_index);
-                u.push_back(cam_meas.second.u);
-                v.push_back(cam_meas.second.v);
-                d.push_back(cam_meas.second.d);
+            if (it->first != row.id) continue;
+            if (!have_cam || !(row.cam == last_cam)) {
+                last_cam_index = camera(*kf.cameras_.at(row.cam));
+                last_cam = row.cam;
+                have_cam = true;
             }
+            obs_kf.push_back(k);
+            obs_lm.push_back(it->second);
+            obs_cam.push_back(last_cam_index);
+            u.push_back(row.m->u);
+            v.push_back(row.m->v);
+            d.push_back(row.m->d);
         }
     }
     void finish() {

@@ -100,6 +100,30 @@ public:
     EigenPose getEigenPose() const { return convert(pose_); }
     std::shared_ptr<Pose> getPosePtr() const { return std::make_shared<Pose>(pose_); }
 
+    // measurements_ as ONE array in the order the map iterates it (landmark id, then camera id), each row with a pointer to the
+    // Measurement inside the map: what the selector's schemes, the window cut and the flattening merge against sorted landmark lists
+    // instead of walking the map node by node (not in the reference; its std::map stays the interface and the owner of the values - a
+    // value changed in place is seen through the pointer).  Built on first use and again whenever the map no longer looks like the
+    // one it was built from (number of landmarks, first and last id); a copy of a keyframe builds its own.  Not for concurrent callers.
+    struct MeasurementRef {
+        LandmarkId id;
+        CameraId cam;
+        const Measurement* m;
+    };
+    const std::vector<MeasurementRef>& measurementTable() const {
+        std::vector<MeasurementRef>& rows = table_.rows;
+        const bool looks_right = table_.n_landmarks == measurements_.size() &&
+                                 (measurements_.empty() || (!rows.empty() && rows.front().id == measurements_.cbegin()->first && rows.back().id == measurements_.crbegin()->first));
+        if (!looks_right) {
+            rows.clear();
+            rows.reserve(measurements_.size());
+            for (const auto& lm : measurements_)
+                for (const auto& cm : lm.second) rows.push_back({lm.first, cm.first, &cm.second});
+            table_.n_landmarks = measurements_.size();
+        }
+        return rows;
+    }
+
 private:
     void setup(TimestampNSec stamp, std::map<CameraId, Camera::Ptr> rig, const EigenPose& p, FixationStatus fix, const Plane& plane) {
         timestamp_ = stamp;
@@ -114,6 +138,21 @@ private:
         while (col < stamps.size() && stamps[col] != timestamp_) ++col;
         return col;
     }
+
+    struct TableCache {  // (copying a keyframe does not copy the table: its pointers lead into the source's map)
+        std::vector<MeasurementRef> rows;
+        size_t n_landmarks = static_cast<size_t>(-1);
+        TableCache() = default;
+        TableCache(const TableCache&) {}
+        TableCache& operator=(const TableCache&) {
+            rows.clear();
+            n_landmarks = static_cast<size_t>(-1);
+            return *this;
+        }
+        TableCache(TableCache&&) = default;  // (a moved map keeps its nodes where they are)
+        TableCache& operator=(TableCache&&) = default;
+    };
+    mutable TableCache table_;
 
 public:
     TimestampNSec timestamp_{0};

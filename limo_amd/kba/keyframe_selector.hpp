@@ -60,22 +60,19 @@ public:
         const Keyframe::Ptr& last = newest(last_frames);
         double sum = 0.;
         size_t n = 0;
-        // (both measurement maps are in landmark-id order: one merge pass instead of two tree searches per measurement; the terms are
-        // added in the order of the statement it replaces - the new frame's landmarks, their cameras)
-        auto il = last->measurements_.cbegin();
-        const auto el = last->measurements_.cend();
-        for (const auto& m : new_frame->measurements_) {
-            while (il != el && il->first < m.first) ++il;
-            if (il == el) break;
-            if (m.first < il->first) continue;
-            for (const auto& cam_meas : m.second) {
-                const auto io = il->second.find(cam_meas.first);
-                if (io == il->second.cend()) continue;
-                const Measurement& o = io->second;
-                const double du = double(cam_meas.second.u) - double(o.u), dv = double(cam_meas.second.v) - double(o.v);
-                sum += std::sqrt(du * du + dv * dv);
-                ++n;
-            }
+        // (both keyframes' measurement tables are in (landmark id, camera id) order: one merge pass over two arrays instead of two tree
+        // searches per measurement; the terms are added in the order of the statement it replaces - the new frame's landmarks, their cameras)
+        const auto& rn = new_frame->measurementTable();
+        const auto& rl = last->measurementTable();
+        size_t il = 0;
+        for (const auto& row : rn) {
+            while (il < rl.size() && (rl[il].id < row.id || (rl[il].id == row.id && rl[il].cam < row.cam))) ++il;
+            if (il == rl.size()) break;
+            if (rl[il].id != row.id || rl[il].cam != row.cam) continue;
+            const Measurement& o = *rl[il].m;
+            const double du = double(row.m->u) - double(o.u), dv = double(row.m->v) - double(o.v);
+            sum += std::sqrt(du * du + dv * dv);
+            ++n;
         }
         const double mean = sum / static_cast<double>(n);  // n == 0 -> NaN -> not usable, as in the reference
         return mean * mean > min_median_flow_squared_;

@@ -109,32 +109,27 @@ inline std::vector<std::pair<LandmarkId, double>> calcFlowSorted(const std::vect
     std::vector<unsigned char> n_cams(n, 0);
     bool overflow = false;
     for (const auto& kf : kfs) {
-        auto im = kf->measurements_.cbegin();
-        const auto end = kf->measurements_.cend();
-        for (size_t i = 0; i < n && im != end; ++i) {
+        const auto& rows = kf->measurementTable();  // (landmark id, camera id) ascending: merged with the ids, no map node is visited for an id that is not asked for
+        size_t im = 0;
+        for (size_t i = 0; i < n && im < rows.size(); ++i) {
             const LandmarkId id = ids_sorted[i];
-            int steps = 0;
-            while (im != end && im->first < id) {
-                ++im;
-                if (++steps > 24) {  // far ahead: one descent instead of a long walk
-                    im = kf->measurements_.lower_bound(id);
-                    break;
-                }
-            }
-            if (im == end) break;
-            if (im->first != id) continue;
-            for (const auto& cm : im->second) {
-                if (!kf->cameras_.count(cm.first)) continue;
+            if (rows[im].id < id)  // (far ahead most of the time: the near field is a small part of a keyframe's landmarks)
+                im = std::lower_bound(rows.begin() + im, rows.end(), id, [](const Keyframe::MeasurementRef& r, LandmarkId v) { return r.id < v; }) - rows.begin();
+            if (im == rows.size()) break;
+            for (; im < rows.size() && rows[im].id == id; ++im) {
+                const CameraId cam = rows[im].cam;
+                const Measurement& meas = *rows[im].m;
+                if (!kf->cameras_.count(cam)) continue;
                 PerCam* pc = nullptr;
                 for (int c = 0; c < n_cams[i]; ++c)
-                    if (cams[i * kCams + c].cam == cm.first) pc = &cams[i * kCams + c];
+                    if (cams[i * kCams + c].cam == cam) pc = &cams[i * kCams + c];
                 if (pc) {
-                    const double du = double(pc->last.u) - double(cm.second.u), dv = double(pc->last.v) - double(cm.second.v);
+                    const double du = double(pc->last.u) - double(meas.u), dv = double(pc->last.v) - double(meas.v);
                     pc->sum += std::sqrt(du * du + dv * dv);
                     pc->cnt += 1;
-                    pc->last = cm.second;
+                    pc->last = meas;
                 } else if (n_cams[i] < kCams) {
-                    cams[i * kCams + n_cams[i]++] = {cm.first, cm.second, 0., 0};
+                    cams[i * kCams + n_cams[i]++] = {cam, meas, 0., 0};
                 } else {
                     overflow = true;
                 }
@@ -209,11 +204,18 @@ inline std::vector<LandmarkId> chooseMiddleLmIds(size_t max_num, const std::vect
 inline std::vector<LandmarkId> chooseFarLmIds(size_t max_num, const std::vector<LandmarkId>& far_ids,
                                               const std::map<KeyframeId, Keyframe::ConstPtr>& keyframes) {
     std::vector<std::pair<unsigned, LandmarkId>> keyed;
-    for (const auto& id : far_ids) {
-        unsigned n = 0;
-        for (const auto& kf : keyframes)
-            if (kf.second->hasMeasurement(id)) n += 1;
-        keyed.push_back({n, id});
+    keyed.reserve(far_ids.size());
+    for (const auto& id : far_ids) keyed.push_back({0u, id});
+    // Keyframe::hasMeasurement(id) - some camera of the keyframe's rig measured it - per (id, keyframe), as a binary search in the
+    // keyframe's measurement table (contiguous) instead of a descent through its map
+    for (const auto& kf : keyframes) {
+        const auto& rows = kf.second->measurementTable();
+        for (auto& k : keyed) {
+            auto it = std::lower_bound(rows.begin(), rows.end(), k.second, [](const Keyframe::MeasurementRef& r, LandmarkId id) { return r.id < id; });
+            bool seen = false;
+            for (; it != rows.end() && it->id == k.second && !seen; ++it) seen = kf.second->cameras_.count(it->cam) != 0;
+            k.first += seen ? 1u : 0u;
+        }
     }
     std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
     keyed.resize(std::min(max_num, keyed.size()));
@@ -421,29 +423,18 @@ public:
             std::vector<std::pair<LandmarkId, double>> keyed;
             const EigenPose T = kf.getEigenPose();
             // the landmarks that qualify (a fifth of them with the ground-plane predicate), then their measurements in this
-            // keyframe - both in id order: the position in measurements_ moves forward with a short walk or a fresh search
-            auto im = kf.measurements_.cbegin();
-            bool first = true;
+            // keyframe - both in id order: a merge with the keyframe's measurement table (binary search ahead when the next id is far)
+            const auto& rows = kf.measurementTable();
+            size_t im = 0;
             for (const auto& lm_it : qualifies[cfg]) {
                 const auto& lm = *lm_it;
-                if (first) {
-                    im = kf.measurements_.lower_bound(lm.first);
-                    first = false;
-                } else {
-                    int steps = 0;
-                    while (im != kf.measurements_.cend() && im->first < lm.first) {
-                        ++im;
-                        if (++steps > 16) {
-                            im = kf.measurements_.lower_bound(lm.first);
-                            break;
-                        }
-                    }
-                }
-                if (im == kf.measurements_.cend()) break;
-                if (im->first != lm.first) continue;
+                if (im < rows.size() && rows[im].id < lm.first)
+                    im = std::lower_bound(rows.begin() + im, rows.end(), lm.first, [](const Keyframe::MeasurementRef& r, LandmarkId v) { return r.id < v; }) - rows.begin();
+                if (im == rows.size()) break;
+                if (rows[im].id != lm.first) continue;
                 const Vector3d local = T * Vector3d(lm.second->pos.data());
                 double worst = -std::numeric_limits<double>::max();  // largest key over the cameras that see it
-                for (const auto& cam_meas : im->second) worst = std::max(worst, (double)std::get<3>(el)(cam_meas.second, local));
+                for (; im < rows.size() && rows[im].id == lm.first; ++im) worst = std::max(worst, (double)std::get<3>(el)(*rows[im].m, local));
                 keyed.push_back({lm.first, worst});
             }
             std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) {

@@ -95,22 +95,21 @@ public:
             const EigenPose T = kf.getEigenPose();
             std::map<CameraId, EigenPose> cam_T;
             for (const auto& c : kf.cameras_) cam_T[c.first] = c.second->getEigenPose();
+            const auto& rows = kf.measurementTable();  // (id, camera) rows in id order: the merge touches no map node
             auto il = landmarks.cbegin();
-            auto im = kf.measurements_.cbegin();
-            size_t i = 0;
-            while (il != landmarks.cend() && im != kf.measurements_.cend()) {
-                if (il->first < im->first) {
+            size_t im = 0, i = 0;
+            while (il != landmarks.cend() && im < rows.size()) {
+                if (il->first < rows[im].id) {
                     ++il;
                     ++i;
-                } else if (im->first < il->first) {
+                } else if (rows[im].id < il->first) {
                     ++im;
                 } else {
                     const Vector3d p_vehicle = T * Vector3d(il->second->pos.data());
-                    for (const auto& cam_meas : im->second)
-                        if ((cam_T.at(cam_meas.first) * p_vehicle).z() < 0.) bad[i] = 1;
+                    for (; im < rows.size() && rows[im].id == il->first; ++im)
+                        if ((cam_T.at(rows[im].cam) * p_vehicle).z() < 0.) bad[i] = 1;
                     ++il;
                     ++i;
-                    ++im;
                 }
             }
         }
