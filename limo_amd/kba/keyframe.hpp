@@ -110,6 +110,10 @@ public:
         CameraId cam;
         const Measurement* m;
     };
+    // A caller that edits measurements_ STRUCTURALLY after the keyframe was used (erases and inserts that leave the number of landmarks
+    // and both end ids as they were - the one change the check below cannot see) says so with this call; values changed in place,
+    // insertions and erasures that change the count or an end are picked up without it.
+    void measurementsChanged() const { table_.n_landmarks = static_cast<size_t>(-1); }
     const std::vector<MeasurementRef>& measurementTable() const {
         std::vector<MeasurementRef>& rows = table_.rows;
         const bool looks_right = table_.n_landmarks == measurements_.size() &&
