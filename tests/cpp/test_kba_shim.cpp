@@ -861,6 +861,54 @@ static void test_kitti_io() {
     CHECK(err.ate_max > 9. && err.ate_rmse > 3. && err.ate_rmse < err.ate_max);
 }
 
+// Keyframe::measurementTable(): the rows of measurements_ in map order with pointers INTO the map; follows insertions / erasures that
+// change the landmark count or an end id, values changed in place, copies and moves of the keyframe, and measurementsChanged().
+static void test_measurement_table() {
+    auto cam0 = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
+    auto cam1 = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
+    Tracklets ts;
+    ts.stamps = {7};
+    for (unsigned long id : {5ul, 9ul, 2ul, 40ul}) {  // (not in id order)
+        Tracklet t;
+        t.id = id;
+        t.feature_points.push_back(FeaturePoint((float)id, (float)(2 * id), id == 9 ? 3.5f : -1.f));
+        ts.tracks.push_back(t);
+    }
+    std::map<LandmarkId, CameraIds> seen{{2, {0}}, {5, {0, 1}}, {9, {1}}, {40, {0}}};
+    Keyframe kf(7, ts, std::map<CameraId, Camera::Ptr>{{0, cam0}, {1, cam1}}, seen, EigenPose::Identity());
+    auto agrees = [](const Keyframe& k) {
+        const auto& rows = k.measurementTable();
+        size_t i = 0;
+        for (const auto& lm : k.measurements_)
+            for (const auto& cm : lm.second) {
+                if (i >= rows.size() || rows[i].id != lm.first || rows[i].cam != cm.first || rows[i].m != &cm.second) return false;
+                ++i;
+            }
+        return i == rows.size();
+    };
+    CHECK(kf.measurementTable().size() == 5 && agrees(kf));
+    kf.getMeasurement(5, 1).d = 12.f;  // a value changed in place is seen through the row's pointer
+    CHECK(kf.measurementTable()[2].id == 5 && kf.measurementTable()[2].cam == 1 && kf.measurementTable()[2].m->d == 12.f);
+    kf.measurements_[41][0] = FeaturePoint(1.f, 2.f);  // a new last id
+    CHECK(kf.measurementTable().size() == 6 && agrees(kf));
+    kf.measurements_.erase(9);  // the count changes
+    CHECK(kf.measurementTable().size() == 5 && agrees(kf));
+    Keyframe copy(kf);  // a copy has its own map: its rows must point into it
+    CHECK(agrees(copy) && copy.measurementTable()[0].m != kf.measurementTable()[0].m);
+    Keyframe assigned;
+    assigned = kf;
+    CHECK(agrees(assigned));
+    Keyframe moved(std::move(copy));  // a moved map keeps its nodes
+    CHECK(agrees(moved) && moved.measurementTable().size() == 5);
+    // the one change the check cannot see by itself: same count, same ends
+    kf.measurements_.erase(5);
+    kf.measurements_[6][0] = FeaturePoint(3.f, 4.f);
+    kf.measurementsChanged();
+    CHECK(kf.measurementTable().size() == 4 && agrees(kf));
+    Keyframe empty;
+    CHECK(empty.measurementTable().empty());
+}
+
 int main(int argc, char** argv) {
     struct T {
         const char* name;
@@ -873,6 +921,7 @@ int main(int argc, char** argv) {
                  {"LandmarkSelector.base", test_landmark_selector_base},
                  {"LandmarkSelector.voxel", test_landmark_selector_voxel},
                  {"LandmarkSelector.schemes_equal_plain_statements", test_selector_schemes_equal_their_plain_statements},
+                 {"Keyframe.measurementTable", test_measurement_table},
                  {"FivePoint.motion_prior", test_five_point_motion},
                  {"KeyFrameBundleAdjustment.solve", test_solve},
                  {"KeyFrameBundleAdjustment.solve_depth", test_solve_depth},
