@@ -61,7 +61,6 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(view_cam, TV * 16 * D, P.view_cam.data());
     KBA_BUF(view_lin, TV * kViewLin * D, nullptr);
     KBA_BUF(view_lin_c, TV * kViewLin * D, nullptr);
-    KBA_BUF(kf_dR, TK * 9 * D, nullptr);
     KBA_BUF(blk_view, NB * I, P.blk_view.data());
     KBA_BUF(blk_obs0, NB * I, P.blk_obs0.data());
     KBA_BUF(blk_n, NB * I, P.blk_n.data());

@@ -42,7 +42,12 @@ struct LinLane {
 };
 
 // Per-view constants of the current poses (one item per view, before the observations are linearised):
-//   vl[0..8] H = Rc R(q), vl[9..11] h0 = Rc t + tc (camera point = H p + h0), vl[12..20] Rc, vl[21..24] q, vl[25..27] f, cx, cy.
+//   vl[0..8] H = Rc R(q), vl[9..11] h0 = Rc t + tc (camera point = H p + h0), vl[12..20] Rc, vl[21..24] q, vl[25..27] f, cx, cy,
+//   vl[28..54] C_k = Rc B_k(q), k = 0..2 (9 each, row-major): the rotation-tangent Jacobian M(q, p) = d(R(q) p)/d(delta) of
+//   kba_math.hpp:rot_tangent_jac is LINEAR in p, M = p_0 B_0 + p_1 B_1 + p_2 B_2 with B_k = M(q, e_k), so the camera-frame
+//   Jacobian  d(camera point)/d(rotation tangent) = Rc M = sum_k p_k C_k  costs 27 multiply-adds per observation with
+//   wave-uniform operands instead of ~100 (the 3 x 4 quaternion derivative, its product with the 4 x 3 plus-Jacobian and the
+//   product with Rc) - the same polynomial in (q, p), summed in another order.
 // In k_lin_lm every lane of a wave is at the same view of the same window, so these are wave-uniform (scalar registers).
 KBA_HD void view_consts_item(const BatchView& bv, int view) {
     const double* cam = bv.view_cam + 16 * (int64_t)view;
@@ -58,12 +63,19 @@ KBA_HD void view_consts_item(const BatchView& bv, int view) {
     vl[25] = cam[0];
     vl[26] = cam[1];
     vl[27] = cam[2];
+    for (int k = 0; k < 3; ++k) {
+        const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+        double B[9];
+        rot_tangent_jac(pose, e, B);
+        mat3_mul(cam + 4, B, vl + 28 + 9 * k);
+    }
 }
 
 // Inputs of one observation as the linearisation consumes them (a GPU lane fetches them one observation ahead).
 struct LinIn {
     double p[3];  // landmark
     double w;     // landmark weight
+    double sw;    // sqrt(w): sqrt(rho') = sqrt(w) / sqrt(1 + s / a^2) for the scaled Cauchy loss
     float u, v, d;
     int live;     // landmark in the problem
 };
@@ -74,83 +86,91 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
     in.p[1] = bv.lm[3 * (int64_t)gl + 1];
     in.p[2] = bv.lm[3 * (int64_t)gl + 2];
     in.w = bv.lm_weight[gl];
+    in.sw = sqrt(in.w);
     in.u = bv.obs_u[o];
     in.v = bv.obs_v[o];
     in.d = bv.obs_d[o];
 }
 
 // One observation at the CURRENT parameters: residual r (3, loss-corrected), the four scalars c4 = (au, xn, yn, sd) of
-// the factored Jacobian (kba_math.hpp:ft_build) and the camera-side sums U += Jp^T Jp, g += Jp^T r with
-// Jp = Ft [M | I], Ft = c^T Rc.  Same arithmetic as obs_residual_jacobian (kba_math.hpp) with the per-view products
-// taken from vl (view_consts_item) and without the landmark-side Jacobian, which nobody reads here.
+// the factored Jacobian (kba_math.hpp:ft_build) and the camera-side sums U = Jp^T Jp, g = Jp^T r with
+// Jp = Ft [M | I], Ft = c^T Rc (ASSIGNED to out, not added).  The arithmetic of obs_residual_jacobian (kba_math.hpp), laid
+// out for the instruction stream of a gfx950 lane (profiles/r05_lin_lm_instruction_diet.txt: 626 -> ~390 instructions per
+// pair):
+//   * every multiply-add takes at most ONE operand from the view's constants vl (wave-uniform: scalar registers, of which an
+//     instruction reads one);
+//   * the pose Jacobian's rotation block comes from the view's C_k (view_consts_item): Rc M(q, p) = sum_k p_k C_k;
+//   * 1 / z and sqrt(rho') through rcp_nr / rsqrt_nr: sqrt(w / (1 + s c)) = sqrt(w) rsqrt(1 + s c), one seed + one
+//     refinement instead of a division followed by a square root;
+//   * the cost value (two logarithms) only where the LM loop reads it (want_cost: the first linearisation of a solve).
 // BRANCH-FREE on purpose: a landmark that is out of the problem (!in.live) or a failing functor (|z| < 0.01, returns
-// false when in.live) contributes zeros through a final mask - on the GPU the four passes of a lane are then one
+// false when in.live) contributes zeros through a final mask - on the GPU the passes of a lane are then one
 // straight-line stream and the compiler can keep the loads of the next pass in flight across the stores of this one
 // (with divergent branches around them it drained the memory queue every pass).
 // CAM = false: the view's keyframe has no free pose block (WinDesc::n_view_fixed0): its camera-side sums would be masked out of
 // the camera system anyway, so the pose Jacobian and U / g are not formed (a third of the arithmetic of a pair).  The cost, the
 // residual and the planes are the same statements either way.
-template <bool CAM = true>
-KBA_HD bool lin_obs(const double* vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4,
-                    LinLane& out) {
-    const double* H = vl;
-    const double* Rc = vl + 12;
+// VP: pointer to the view's constants - plain memory, or the constant address space (scalar loads) in k_lin_lm.
+template <bool CAM = true, class VP = const double*>
+KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, LinLane& out) {
     const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
-    const double z0 = H[0] * p0 + H[1] * p1 + H[2] * p2 + vl[9];
-    const double z1 = H[3] * p0 + H[4] * p1 + H[5] * p2 + vl[10];
-    const double z2r = H[6] * p0 + H[7] * p1 + H[8] * p2 + vl[11];
+    const double z0 = vl[0] * p0 + vl[1] * p1 + vl[2] * p2 + vl[9];
+    const double z1 = vl[3] * p0 + vl[4] * p1 + vl[5] * p2 + vl[10];
+    const double z2r = vl[6] * p0 + vl[7] * p1 + vl[8] * p2 + vl[11];
     const bool z_ok = fabs(z2r) >= 0.01;
     const bool ok = in.live != 0 && z_ok;
     const double z2 = z_ok ? z2r : 1.0;  // keeps the arithmetic finite; masked below
-    const double f = vl[25];
-    const double iz = 1.0 / z2;
+    const double iz = rcp_nr(z2);
     const double xn = z0 * iz, yn = z1 * iz;
-    const double ru = f * xn + vl[26] - static_cast<double>(in.u);
-    const double rv = f * yn + vl[27] - static_cast<double>(in.v);
+    const double ru = vl[25] * xn + (vl[26] - static_cast<double>(in.u));
+    const double rv = vl[25] * yn + (vl[27] - static_cast<double>(in.v));
     const bool has_d = in.d > 0.0f;
     const double rd = has_d ? z2 - static_cast<double>(in.d) : 0.0;
     const double s_uv = ru * ru + rv * rv, s_d = rd * rd;
-    double su, sd, cost = 0.0;
-    if (want_cost) {  // (uniform over a workgroup)
-        double rho[3];
-        loss_cauchy(c.a_rep, in.w, s_uv, rho);
-        su = sqrt(rho[1]);
-        cost = 0.5 * rho[0];
-        loss_cauchy(c.a_dep, in.w, s_d, rho);
-        sd = sqrt(rho[1]);
-        cost += has_d ? 0.5 * rho[0] : 0.0;
-    } else {
-        su = sqrt(loss_cauchy_d1(c.a_rep, in.w, s_uv));
-        sd = sqrt(loss_cauchy_d1(c.a_dep, in.w, s_d));
+    // ScaledLoss(CauchyLoss(a), w): rho' = w / (1 + s / a^2)   (a sum beyond 1e300 - a residual of 1e150 - is clamped: the
+    // seed of the inverse square root stays a number)
+    const double sum_uv = fmin(1.0 + s_uv * (1.0 / (c.a_rep * c.a_rep)), 1e300);
+    const double sum_d = fmin(1.0 + s_d * (1.0 / (c.a_dep * c.a_dep)), 1e300);
+    double su = in.sw * rsqrt_nr(sum_uv);
+    double sd = in.sw * rsqrt_nr(sum_d);
+    double cost = 0.0;
+    if (want_cost) {  // (uniform over a workgroup)  1/2 rho(s) = 1/2 w a^2 log(1 + s / a^2)
+        cost = 0.5 * (in.w * ((c.a_rep * c.a_rep) * log(sum_uv)));
+        cost += has_d ? 0.5 * (in.w * ((c.a_dep * c.a_dep) * log(sum_d))) : 0.0;
     }
     su = ok ? su : 0.0;
     sd = ok && has_d ? sd : 0.0;
-    out.cost += ok ? cost : 0.0;
+    out.cost = ok ? cost : 0.0;
     const double r0 = su * ru, r1 = su * rv, r2 = sd * rd;
     r3[0] = r0;
     r3[1] = r1;
     r3[2] = r2;
-    const double au = su * (f * iz);
+    const double au = su * (vl[25] * iz);
     c4[0] = au;
     c4[1] = ok ? xn : 0.0;
     c4[2] = ok ? yn : 0.0;
     c4[3] = sd;
     if (!CAM) return z_ok || in.live == 0;
-    double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft]
+    const double a1 = au * xn, a2 = au * yn;
+    double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = sum_k p_k C_k
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        J[3 + j] = au * (Rc[0 + j] - xn * Rc[6 + j]);
-        J[9 + j] = au * (Rc[3 + j] - yn * Rc[6 + j]);
-        J[15 + j] = sd * Rc[6 + j];
+        const double g0 = vl[28 + j] * p0 + vl[37 + j] * p1 + vl[46 + j] * p2;
+        const double g1 = vl[31 + j] * p0 + vl[40 + j] * p1 + vl[49 + j] * p2;
+        const double g2 = vl[34 + j] * p0 + vl[43 + j] * p1 + vl[52 + j] * p2;
+        J[0 + j] = au * g0 - a1 * g2;
+        J[6 + j] = au * g1 - a2 * g2;
+        J[12 + j] = sd * g2;
+        J[3 + j] = au * vl[12 + j] - a1 * vl[18 + j];
+        J[9 + j] = au * vl[15 + j] - a2 * vl[18 + j];
+        J[15 + j] = sd * vl[18 + j];
     }
-    double M[9];
-    rot_tangent_jac(vl + 21, in.p, M);
-    for (int row = 0; row < 3; ++row)
-        for (int j = 0; j < 3; ++j)
-            J[row * 6 + j] = J[row * 6 + 3] * M[j] + J[row * 6 + 4] * M[3 + j] + J[row * 6 + 5] * M[6 + j];
     int k = 0;
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
-        for (int bb = a; bb < 6; ++bb) out.U[k++] += J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
-        out.g[a] += J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
+#pragma unroll
+        for (int bb = a; bb < 6; ++bb) out.U[k++] = J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
+        out.g[a] = J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
     }
     return z_ok || in.live == 0;
 }
@@ -165,7 +185,8 @@ struct LmAcc {
     double V[6], g[3];
 };
 KBA_HD int lm_damp_store(const BatchView& bv, const SolveConsts& c, double radius, int gl, const double* s, const double* V, const double* g);
-KBA_HD void lin_lm_accum(const double* vl, const double* r3, const double* c4, LmAcc& a) {
+template <class VP>
+KBA_HD void lin_lm_accum(VP vl, const double* r3, const double* c4, LmAcc& a) {
     double E[9];
     ft_build(c4, vl, E);  // E = c^T H, H = Rc R(q) of the view (view_consts_item)
     for (int row = 0; row < 3; ++row) {
@@ -312,9 +333,10 @@ KBA_HD void gp_lane(const BatchView& bv, int g, bool candidate, double* cost_out
 KBA_HD int lm_damp_store(const BatchView& bv, const SolveConsts& c, double radius, int gl, const double* s, const double* V, const double* g) {
     double A[6] = {s[0] * s[0] * V[0], s[0] * s[1] * V[1], s[0] * s[2] * V[2],
                    s[1] * s[1] * V[3], s[1] * s[2] * V[4], s[2] * s[2] * V[5]};
-    A[0] += fmin(fmax(A[0], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-    A[3] += fmin(fmax(A[3], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
-    A[5] += fmin(fmax(A[5], c.min_lm_diagonal), c.max_lm_diagonal) / radius;
+    const double ir = rcp_nr(radius);  // (one reciprocal instead of three divisions; radius > 0)
+    A[0] += fmin(fmax(A[0], c.min_lm_diagonal), c.max_lm_diagonal) * ir;
+    A[3] += fmin(fmax(A[3], c.min_lm_diagonal), c.max_lm_diagonal) * ir;
+    A[5] += fmin(fmax(A[5], c.min_lm_diagonal), c.max_lm_diagonal) * ir;
     double Li[6];
     int fail = 0;
     if (!chol3_inv(A, Li)) {
@@ -353,6 +375,8 @@ KBA_HD int lm_damp_lane(const BatchView& bv, const SolveConsts& c, int w, int gl
 //   (local index);  vkl[j] = local keyframe of view j.
 // Pose part of one observation:  Y[a*3 + c'] += sc[a] (F^T E)[a][c] Bt[c'][c]   for the six pose slots, with
 // F^T E = [M^T G ; G],  G = Ft^T Ft R  (F = Ft [M | I], E = Ft R).
+// ASSIGN: Y receives the block (the lean kernel: one view per keyframe) instead of accumulating it.
+template <bool ASSIGN = false>
 KBA_HD void schur_pose_block(const double* Ft, const double* R, const double* M, const double* lmk, const double* sc6,
                              double* Y) {
     // A = Ft^T Ft (symmetric)
@@ -369,26 +393,27 @@ KBA_HD void schur_pose_block(const double* Ft, const double* R, const double* M,
         G[3 + j] = a01 * R[j] + a11 * R[3 + j] + a12 * R[6 + j];
         G[6 + j] = a02 * R[j] + a12 * R[3 + j] + a22 * R[6 + j];
     }
-    // landmark-side factor  B[c][c'] = Bt[c'][c]
+    // landmark-side factor first:  GB[i][c'] = sum_c G[i][c] Bt[c'][c]  (Bt lower triangular) - then the translation slots'
+    // rows are the rows of GB and the rotation slots' rows are M^T GB: 18 + 27 multiply-adds instead of 27 + 36
     const double b00 = lmk[0], b01 = lmk[1], b02 = lmk[3];
     const double b11 = lmk[2], b12 = lmk[4];
     const double b22 = lmk[5];
+    double GB[9];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        double w0, w1, w2;
-        if (a < 3) {  // rotation slots: row a of M^T G
-            w0 = M[a] * G[0] + M[3 + a] * G[3] + M[6 + a] * G[6];
-            w1 = M[a] * G[1] + M[3 + a] * G[4] + M[6 + a] * G[7];
-            w2 = M[a] * G[2] + M[3 + a] * G[5] + M[6 + a] * G[8];
-        } else {
-            w0 = G[(a - 3) * 3];
-            w1 = G[(a - 3) * 3 + 1];
-            w2 = G[(a - 3) * 3 + 2];
+    for (int i = 0; i < 3; ++i) {
+        GB[i * 3 + 0] = G[i * 3] * b00;
+        GB[i * 3 + 1] = G[i * 3] * b01 + G[i * 3 + 1] * b11;
+        GB[i * 3 + 2] = G[i * 3] * b02 + G[i * 3 + 1] * b12 + G[i * 3 + 2] * b22;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const double yr = sc6[a] * (M[a] * GB[cc] + M[3 + a] * GB[3 + cc] + M[6 + a] * GB[6 + cc]);
+            const double yt = sc6[3 + a] * GB[a * 3 + cc];
+            Y[a * 3 + cc] = ASSIGN ? yr : Y[a * 3 + cc] + yr;
+            Y[(3 + a) * 3 + cc] = ASSIGN ? yt : Y[(3 + a) * 3 + cc] + yt;
         }
-        const double sca = sc6[a];
-        Y[a * 3 + 0] += sca * (w0 * b00);
-        Y[a * 3 + 1] += sca * (w0 * b01 + w1 * b11);
-        Y[a * 3 + 2] += sca * (w0 * b02 + w1 * b12 + w2 * b22);
     }
 }
 
@@ -498,6 +523,20 @@ KBA_HD int schur_col(int i, int nfq) {
 }
 
 // ======================================================================================= back-substitution
+// Product of factors >= 1 kept as mantissa x 2^exponent: sum_j log(f_j) = log(prod_j f_j) costs ONE logarithm per landmark
+// and loss instead of one per observation (an fp64 logarithm is ~45 instructions on gfx950; the candidate cost of an
+// observation is 1/2 w a^2 log(1 + s / a^2), twice).  The mantissa of n factors stays above 2^-n (n <= kMaxViews).
+struct LogProd {
+    double m;
+    int e;
+};
+KBA_HD void logprod_mul(LogProd& a, double x) {
+    int ex;
+    a.m *= frexp(x, &ex);
+    a.e += ex;
+}
+KBA_HD double logprod_log(const LogProd& a) { return log(a.m) + static_cast<double>(a.e) * 0.69314718055994530942; }
+
 // y_l = (V'+D^2)^-1 (g' - W'^T y_c);  delta_l = -S_l y_l;  candidate = lm + delta_l;  then the cost of the landmark's
 // observations AT THE CANDIDATE (Evaluator cost-only pass): the lane holds the candidate landmark, the candidate
 // poses' per-view constants are in view_lin_c (k_cam_solve), so the measurements (12 B per observation through the slot
@@ -525,7 +564,7 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
     const int n_view = wd.n_view;
     if (state == 1) {
         double a[3] = {0, 0, 0};
-        // (the leading views of keyframes without a free pose block have delta_c = 0 and dR = 0: their terms of `a` are exact
+        // (the leading views of keyframes without a free pose block have a zero camera step: their terms of `a` are exact
         // zeros - the loop starts behind them and their planes are never loaded)
         const int j0 = wd.n_view_fixed0;
         int s_cur = j0 < n_view ? slot[(int64_t)j0 * bv.SL] : -1;
@@ -545,20 +584,20 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
                 const int64_t o = s_cur >= 0 ? s_cur : 0;
                 for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
             }
-            const int gk = bv.view_kf[wd.view0 + j];
-            const double* dc = bv.delta_c + (int64_t)gk * kCamSlots;
-            const double* dR = bv.kf_dR + 9 * (int64_t)gk;
-            const double* vl = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);  // H = Rc R at [0..8], Rc at [12..20]
-            // F dc = Ft (dR x + d_trans);  E^T (F dc) with E = c^T H
-            double Ft[9], E[9], m[3], q[3];
-            ft_build(c4, vl + 12, Ft);
-            ft_build(c4, vl, E);
-            mat3_vec(dR, x, m);
-            m[0] += dc[3];
-            m[1] += dc[4];
-            m[2] += dc[5];
-            mat3_vec(Ft, m, q);
-            for (int cc = 0; cc < 3; ++cc) a[cc] += E[cc] * q[0] + E[3 + cc] * q[1] + E[6 + cc] * q[2];
+            // E^T (F dc) of the pair, with F dc = c^T Rc (dR x + d_trans) = c^T (K x + k0) and E = c^T H: the view's
+            // K = Rc dR, k0 = Rc d_trans (cam_solve) and H (view_consts_item) are wave-uniform, c^T is spanned by the four
+            // scalars (kba_math.hpp:ft_build) - no 3 x 3 Ft / E per observation
+            const double* vs = bv.view_lin_c + (int64_t)kViewLin * (wd.view0 + j) + 28;  // K (9) | k0 (3)
+            const double* H = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);
+            const double w0 = vs[0] * x[0] + vs[1] * x[1] + vs[2] * x[2] + vs[9];
+            const double w1 = vs[3] * x[0] + vs[4] * x[1] + vs[5] * x[2] + vs[10];
+            const double w2 = vs[6] * x[0] + vs[7] * x[1] + vs[8] * x[2] + vs[11];
+            const double v0 = c4[0] * (c4[0] * (w0 - c4[1] * w2));  // au q_u
+            const double v1 = c4[0] * (c4[0] * (w1 - c4[2] * w2));  // au q_v
+            const double v2 = c4[3] * (c4[3] * w2) - c4[1] * v0 - c4[2] * v1;
+            a[0] += H[0] * v0 + H[3] * v1 + H[6] * v2;
+            a[1] += H[1] * v0 + H[4] * v1 + H[7] * v2;
+            a[2] += H[2] * v0 + H[5] * v1 + H[8] * v2;
         }
         const int gg = bv.lm_gp[gl];
         if (gg >= 0) {
@@ -594,9 +633,11 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
         part[4] = xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2];
     }
     // ---- cost of this landmark's observations at (candidate poses, candidate point); state 2 = constant landmark of a
-    //      motion-only problem: its point is the candidate
+    //      motion-only problem: its point is the candidate.  1/2 rho = 1/2 w a^2 log(1 + s / a^2) per block: the factors
+    //      1 + s / a^2 of the landmark's blocks are multiplied up per loss (LogProd), two logarithms per LANDMARK.
     const double lw = bv.lm_weight[gl];
-    double cost = 0.0;
+    const double c_rep = 1.0 / (c.a_rep * c.a_rep), c_dep = 1.0 / (c.a_dep * c.a_dep);
+    LogProd lp_rep = {1.0, 0}, lp_dep = {1.0, 0};
     int fail = 0;
     {
         int s_cur = slot[0];
@@ -626,18 +667,18 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
             const bool z_ok = fabs(z2r) >= 0.01;
             if (have && !z_ok) fail = 1;
             const double z2 = z_ok ? z2r : 1.0;  // keeps the arithmetic finite; masked below
-            const double ru = vc[25] * (z0 / z2) + vc[26] - static_cast<double>(u);
-            const double rv = vc[25] * (z1 / z2) + vc[27] - static_cast<double>(v);
-            double rho[3];
-            loss_cauchy(c.a_rep, lw, ru * ru + rv * rv, rho);
-            double pair = 0.5 * rho[0];
+            const double iz = rcp_nr(z2);
+            const double ru = vc[25] * (z0 * iz) + (vc[26] - static_cast<double>(u));
+            const double rv = vc[25] * (z1 * iz) + (vc[27] - static_cast<double>(v));
             const double rd = z2 - static_cast<double>(d);
-            loss_cauchy(c.a_dep, lw, rd * rd, rho);
-            pair += d > 0.0f ? 0.5 * rho[0] : 0.0;
-            cost += have && z_ok ? pair : 0.0;
+            const bool on = have && z_ok;
+            const double f_rep = fmin(1.0 + (ru * ru + rv * rv) * c_rep, 1e300);
+            const double f_dep = fmin(1.0 + (rd * rd) * c_dep, 1e300);
+            logprod_mul(lp_rep, on ? f_rep : 1.0);
+            logprod_mul(lp_dep, on && d > 0.0f ? f_dep : 1.0);
         }
     }
-    part[6] = cost;
+    part[6] = 0.5 * (lw * ((c.a_rep * c.a_rep) * logprod_log(lp_rep))) + 0.5 * (lw * ((c.a_dep * c.a_dep) * logprod_log(lp_dep)));
     part[7] = fail ? 1.0 : 0.0;
     double* o = bv.lm_c + 3 * (int64_t)gl;
     o[0] = xc[0];
@@ -1513,11 +1554,6 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             for (int i = 0; i < 7; ++i) pc[i] = x[i];
         }
         for (int i = 0; i < 7; ++i) xc[i] = pc[i];
-        {   // what the landmark-side kernels need of the proposed camera step: dR of this keyframe (back-substitution:
-            // F_pose delta = Ft (dR p + delta_t), kba_math.hpp:quat_dR)
-            const double zero3[3] = {0.0, 0.0, 0.0};
-            quat_dR(x, cm[k * kCamSlots] ? d : zero3, bv.kf_dR + 9 * (int64_t)gk);
-        }
         const double* n = bv.pdir + 3 * (int64_t)gk;
         double* ncand = bv.pdir_c + 3 * (int64_t)gk;
         if (cm[k * kCamSlots + 6]) {
@@ -1561,6 +1597,17 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         vl[25] = cam[0];
         vl[26] = cam[1];
         vl[27] = cam[2];
+        {   // what the back-substitution needs of the proposed camera step, per view: F_pose delta of an observation is
+            // c^T Rc (dR p + delta_t) with dR = derivative of R(q) along the rotation step (kba_math.hpp:quat_dR):
+            // K = Rc dR (9) and k0 = Rc delta_t (3); zeros for a keyframe whose pose block is not free
+            const bool fr = cm[k * kCamSlots] != 0;
+            const double* dk = dl + k * kCamSlots;
+            const double dz[6] = {fr ? dk[0] : 0.0, fr ? dk[1] : 0.0, fr ? dk[2] : 0.0, fr ? dk[3] : 0.0, fr ? dk[4] : 0.0, fr ? dk[5] : 0.0};
+            double dR[9];
+            quat_dR(x, dz, dR);
+            mat3_mul(cam + 4, dR, vl + 28);
+            mat3_vec(cam + 4, dz + 3, vl + 37);
+        }
     }
     KBA_TICK(12);
     // three sums at once (red holds 3*nt doubles)

@@ -23,6 +23,9 @@
 
 #define KBA_SYNC() __syncthreads()
 #include "kba_items.hpp"
+#ifndef KBA_ABLATE  // (profiling builds only: scripts/gpu_lin_ablate.sh compiles variants of k_lin_lm with pieces left out)
+#define KBA_ABLATE 0
+#endif
 
 namespace kba {
 
@@ -385,6 +388,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     in.p[1] = bv.lm[3 * (int64_t)gl + 1];
     in.p[2] = bv.lm[3 * (int64_t)gl + 2];
     in.w = bv.lm_weight[gl];
+    in.sw = sqrt(in.w);
     const int32_t* slot = bv.lm_slot + gl;
     typename ViewPtr<KVIEW>::type vc = (typename ViewPtr<KVIEW>::type)(bv.view_lin + (int64_t)kViewLin * wd.view0);
     double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
@@ -413,9 +417,9 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     //      straight-line body (a uniform branch inside it cost more than the skipped third of the arithmetic gave back).
     const int j_cam0 = wd.n_view_fixed0;
     for (int j = 0; j < j_cam0; ++j) {
-        double vl[28];
-#pragma unroll
-        for (int i = 0; i < 28; ++i) vl[i] = vc[(int64_t)j * kViewLin + i];
+        // (the constants are read where they are used - scalar loads the compiler places next to their instructions; a local
+        // copy of all 55 would not fit the scalar register file)
+        typename ViewPtr<KVIEW>::type vl = vc + (int64_t)j * kViewLin;
         const int s = s_cur;
         in.u = u_n;
         in.v = v_n;
@@ -431,8 +435,6 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         const bool have = state != 0 && s >= 0;
         in.live = have;
         LinLane l;
-        l.cost = 0.0;
-        l.fail = 0;
         double r3[3], c4[4];
         if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
         {
@@ -445,9 +447,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         if (lane < kLinPartial) lv_lds[(j * kLinWaves + wave) * kLinPartial + lane] = lane == 0 ? tot : 0.0;
     }
     for (int j = j_cam0; j < n_view; ++j) {
-        double vl[28];
-#pragma unroll
-        for (int i = 0; i < 28; ++i) vl[i] = vc[(int64_t)j * kViewLin + i];
+        typename ViewPtr<KVIEW>::type vl = vc + (int64_t)j * kViewLin;
         const int s = s_cur;
         in.u = u_n;
         in.v = v_n;
@@ -463,22 +463,48 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         const bool have = state != 0 && s >= 0;
         in.live = have;
         LinLane l;
-        l.cost = 0.0;
-        l.fail = 0;
-#pragma unroll
-        for (int i = 0; i < 21; ++i) l.U[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) l.g[i] = 0.0;
         double r3[3], c4[4];
+#if KBA_ABLATE == 64 || KBA_ABLATE == 69
+        if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) l.U[i] = r3[i % 3] * c4[i % 4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) l.g[i] = r3[i % 3];
+#elif KBA_ABLATE == 67
+        r3[0] = in.u; r3[1] = in.v; r3[2] = in.d;
+        c4[0] = in.p[0] * vl[0]; c4[1] = in.p[1]; c4[2] = in.p[2]; c4[3] = in.w;
+        l.cost = c4[0];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) l.U[i] = r3[i % 3] * c4[i % 4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) l.g[i] = r3[i % 3];
+#else
         if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
+#endif
         {   // the four scalars of the factored Jacobian are what the Schur / back-substitution kernels read; the residual
             // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
             // (limo_ba_evaluate has its own kernel), so it is not stored: 32 instead of 56 B written per pair
             const int64_t o = have ? s : dump;
+#if KBA_ABLATE == 61 || KBA_ABLATE == 69
+            if (c.pad == 12345)
+#endif
+#if KBA_ABLATE == 65
+            {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                v2d* q = reinterpret_cast<v2d*>(bv.obs_c);
+                q[o] = (v2d){c4[0], c4[1]};
+                q[bv.SO + o] = (v2d){c4[2], c4[3]};
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
+#endif
         }
+#if KBA_ABLATE == 68 || KBA_ABLATE == 67
+        acc.V[0] += r3[0] * c4[0]; acc.V[1] += r3[1] * c4[1]; acc.g[0] += r3[2] * c4[2]; acc.g[1] += c4[3];
+#else
         lin_lm_accum(vl, r3, c4, acc);  // zeros where the pair does not exist
+#endif
         double vals[kLinPartial];
         vals[0] = l.cost;
 #pragma unroll
@@ -486,7 +512,13 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 #pragma unroll
         for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
         static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter28");
+#if KBA_ABLATE == 63 || KBA_ABLATE == 69
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < kLinPartial; ++i) tot += vals[i];
+#else
         const double tot = wave_reduce_scatter28(vals, lane);
+#endif
         if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
     }
     double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -496,7 +528,12 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         const int gg = bv.lm_gp[gl];
         if (gg >= 0) gp_lane(bv, gg, false, bv.gp_cost);
     }
+#if KBA_ABLATE == 62 || KBA_ABLATE == 69
+    if (state == 1 && c.pad == 12345) lin_lm_finish(bv, c, w, gl, acc, part);
+    part[0] = acc.V[0] + acc.V[1] + acc.V[2] + acc.V[3] + acc.V[4] + acc.V[5] + acc.g[0] + acc.g[1] + acc.g[2];
+#else
     if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
+#endif
     __shared__ double lds[8];
     const double m = wave_max(part[0]);
     const double sm = wave_sum(part[1]);
@@ -724,7 +761,8 @@ __global__ __launch_bounds__(64 * kWideWaves) void k_schur_wide(BatchView bv, co
 //     indices (slot, state, ground-plane row) are fetched two tiles ahead.
 // One wave per workgroup, no cross-wave synchronisation; `span` consecutive blocks of one class per wave.
 constexpr int kSpBatch = 4;  // k-steps whose panel reads are in flight together
-constexpr int kSpKf = 32;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots
+constexpr int kSpKf = 60;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots | B_k (27): the
+                             // rotation-tangent Jacobian is linear in the landmark, M(q, p) = sum_k p_k B_k, B_k = M(q, e_k)
 
 __host__ __device__ inline int schur_lean_ld(int ncol) { return ncol | 1; }  // odd row stride: conflict-free fill
 __host__ __device__ inline int schur_lean_lds_bytes(int ncol) {
@@ -784,6 +822,13 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             for (int i = 0; i < 4; ++i) mine[18 + i] = pose[i];
         } else if (li < 10) {
             mine[9 + li - 1] = my_view >= 0 ? bv.view_cam[16 * (int64_t)my_view + 4 + li - 1] : 0.0;
+        } else if (li < 13) {
+            const int k = li - 10;
+            const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+            double B[9];
+            rot_tangent_jac(pose, e, B);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mine[32 + 9 * k + i] = B[i];
         }
         if (li < kCamSlots) {
             const int slot = wd.cam0 + my_kl * kCamSlots + li;
@@ -875,9 +920,10 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             for (int i = 0; i < 3 * NS; ++i) Y[i] = 0.0;
             if (seen) {
                 double M[9], Ft[9];
-                rot_tangent_jac(mine + 18, p, M);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) M[i] = p[0] * mine[32 + i] + p[1] * mine[41 + i] + p[2] * mine[50 + i];
                 ft_build(c4, mine + 9, Ft);
-                schur_pose_block(Ft, mine, M, Bt, mine + 22, Y);
+                schur_pose_block<true>(Ft, mine, M, Bt, mine + 22, Y);
                 if (two_tile) {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) yt[a] += Y[a * 3 + 0] * t3[0] + Y[a * 3 + 1] * t3[1] + Y[a * 3 + 2] * t3[2];

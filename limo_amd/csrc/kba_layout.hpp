@@ -21,7 +21,7 @@ namespace kba {
 constexpr int kMaxKf = 20;        // max keyframes per window: the reference's default max_size_optimization_window
                                   // (bundle_adjuster_keyframes.hpp:129); the KITTI launch runs 12
 constexpr int kMaxViews = 64;     // max (keyframe, camera) views per window (LDS tables of the Schur kernels)
-constexpr int kViewLin = 32;      // doubles per view in BatchView::view_lin
+constexpr int kViewLin = 64;      // doubles per view in BatchView::view_lin (kba_items.hpp:view_consts_item: 55 used)
 constexpr int kCamSlots = 10;     // tangent dims per keyframe in the reduced camera system
 constexpr int kMaxNc = kMaxKf * kCamSlots;
 constexpr int kBlock = 256;       // lanes per workgroup in the scan kernels
@@ -168,9 +168,9 @@ struct BatchView {
     const int32_t* view_kf;     // [TV] global keyframe index
     const int32_t* view_win;    // [TV]
     const double* view_cam;     // [TV*16] f,cx,cy,pad, Rc[9], tc[3]
-    double* view_lin_c;         // [TV*kViewLin] the same for the CANDIDATE poses (written by k_cam_solve; H, h0, intrinsics)
-    double* kf_dR;              // [TK*9] dR = derivative of R(q) along the proposed rotation step of the keyframe (k_cam_solve):
-                                // F_pose delta_pose of an observation = Ft (dR p + delta_t), no per-observation M(q, p)
+    double* view_lin_c;         // [TV*kViewLin] for the CANDIDATE poses (k_cam_solve): H, h0, intrinsics at the same places, and at
+                                // [28..39] K = Rc dR (9), k0 = Rc delta_t (3) of the proposed camera step (back-substitution:
+                                // F_pose delta_pose of an observation = c^T (K p + k0), no per-observation M(q, p))
     double* view_lin;           // [TV*kViewLin] per-view constants of the CURRENT poses (k_view_consts): H = Rc R(q) (9),
                                 // h0 = Rc t + tc (3), Rc (9), q (4), f, cx, cy - wave-uniform operands of k_lin_lm
     const int32_t* blk_view;    // [n_blk]

@@ -30,6 +30,36 @@
 
 namespace kba {
 
+// ---------------------------------------------------------------------------------------- reciprocals on the hot path
+// 1 / x and 1 / sqrt(x) for the solve's inner loops.  On gfx950 a correctly rounded fp64 division is ~12 instructions (63
+// cycles of SIMD time at three waves, profiles/r04_micro_valu_f64_rate.txt), a square root ~18 (91 cycles): the IEEE
+// expansions carry range scaling and fix-up steps for operands these call sites never see (x is a camera depth with
+// |x| >= 0.01, a Cauchy denominator >= 1 or a positive pivot).  Here: the hardware seed (v_rcp_f64 / v_rsq_f64, ~23 bits)
+// refined to the last one or two ulps - two Newton steps for the reciprocal, one third-order step for the inverse square
+// root.  Not correctly rounded; every device path shares these, so the paths stay bit-identical among themselves, and the
+// oracle bar (1e-4 on poses and cost, 1e-9 per Jacobian entry) is ten orders of magnitude away.  Host builds (the CPU-tier
+// emulation) use the IEEE operations.
+KBA_HD double rcp_nr(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
+KBA_HD double rsqrt_nr(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);          // 1 - x y^2
+    return fma(y * e, fma(0.375, e, 0.5), y);        // y (1 + e/2 + 3 e^2/8): error^3
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------- rotation
 // R(q) p and the 3x4 derivative d(R(q)p)/dq of the polynomial form (valid for non-unit q).
 KBA_HD void quat_R(const double* q, double* R) {
@@ -160,11 +190,15 @@ struct ObsOut {
 // Every row of an observation's Jacobian is  c_row^T Rc [ M(q,p) | I ]  (pose) /  c_row^T Rc R(q)  (landmark) with
 //   c_u = au (1, 0, -xn),  c_v = au (0, 1, -yn),  c_d = sd (0, 0, 1),   au = sqrt(rho'_uv) f / z,  sd = sqrt(rho'_d).
 // Ft = c^T Rc (3x3, = the translation columns of Jp) is rebuilt from the FOUR scalars and the view's Rc.
-KBA_HD void ft_build(const double* c, const double* Rc, double* Ft) {
+// (written as  au Rc_0 - (au xn) Rc_2: every multiply-add has ONE operand from Rc, which is wave-uniform in the landmark
+// kernels - an instruction of gfx950 takes one scalar-register operand, the form au (Rc_0 - xn Rc_2) needs two and a copy)
+template <class CP>
+KBA_HD void ft_build(const double* c, CP Rc, double* Ft) {
+    const double a1 = c[0] * c[1], a2 = c[0] * c[2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        Ft[0 + j] = c[0] * (Rc[0 + j] - c[1] * Rc[6 + j]);
-        Ft[3 + j] = c[0] * (Rc[3 + j] - c[2] * Rc[6 + j]);
+        Ft[0 + j] = c[0] * Rc[0 + j] - a1 * Rc[6 + j];
+        Ft[3 + j] = c[0] * Rc[3 + j] - a2 * Rc[6 + j];
         Ft[6 + j] = c[3] * Rc[6 + j];
     }
 }
@@ -372,26 +406,27 @@ KBA_HD void unitvec_plus(const double* x, const double* delta, double* out) {
 // ---------------------------------------------------------------------------------------- 3x3 SPD
 // A (sym, 6 unique: a00 a01 a02 a11 a12 a22) = L L^T ; returns false if not positive definite.
 // Linv (lower-triangular inverse, 6: l00 l10 l11 l20 l21 l22).
+// Straight-line: the three pivots go through rsqrt_nr (what the factor's INVERSE needs is 1 / sqrt(pivot) - no square root
+// followed by a division), a non-positive pivot is replaced by 1 and reported at the end.
 KBA_HD bool chol3_inv(const double* A, double* Li) {
     const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
-    if (!(a00 > 0.0)) return false;
-    const double l00 = sqrt(a00);
-    const double l10 = a01 / l00, l20 = a02 / l00;
+    const bool ok0 = a00 > 0.0;
+    const double i00 = rsqrt_nr(ok0 ? a00 : 1.0);
+    const double l10 = a01 * i00, l20 = a02 * i00;
     const double d1 = a11 - l10 * l10;
-    if (!(d1 > 0.0)) return false;
-    const double l11 = sqrt(d1);
-    const double l21 = (a12 - l20 * l10) / l11;
+    const bool ok1 = d1 > 0.0;
+    const double i11 = rsqrt_nr(ok1 ? d1 : 1.0);
+    const double l21 = (a12 - l20 * l10) * i11;
     const double d2 = a22 - l20 * l20 - l21 * l21;
-    if (!(d2 > 0.0)) return false;
-    const double l22 = sqrt(d2);
-    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const bool ok2 = d2 > 0.0;
+    const double i22 = rsqrt_nr(ok2 ? d2 : 1.0);
     Li[0] = i00;
     Li[1] = -l10 * i00 * i11;
     Li[2] = i11;
     Li[3] = -(l20 * i00 + l21 * Li[1]) * i22;
     Li[4] = -l21 * i11 * i22;
     Li[5] = i22;
-    return true;
+    return ok0 && ok1 && ok2;
 }
 
 }  // namespace kba
