@@ -83,7 +83,7 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(gp_cost, TG * D, nullptr);
     KBA_BUF(gp_cost_c, TG * D, nullptr);
     KBA_BUF(obs_r, (size_t)(P.evaluate_only ? P.SO * 3 : 1) * D, nullptr);  // residual planes: limo_ba_evaluate only
-    KBA_BUF(obs_c, (size_t)(P.evaluate_only ? 1 : P.SO * 4) * D, nullptr);
+    KBA_BUF(obs_c, (size_t)(P.evaluate_only ? 1 : P.SO * 2) * D, nullptr);
     KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
     KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
     KBA_BUF(lv_part, (size_t)(P.lvpart_total > 0 ? P.lvpart_total : 1) * D, nullptr);
@@ -92,7 +92,6 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(lm_g, (size_t)P.SL * 3 * D, nullptr);
     KBA_BUF(lm_scale, (size_t)P.SL * 3 * D, nullptr);
     KBA_BUF(lm_Li, (size_t)P.SL * 6 * D, nullptr);
-    KBA_BUF(lm_t, (size_t)P.SL * 3 * D, nullptr);
     KBA_BUF(lblk_part, NL * 8 * D, nullptr);
     KBA_BUF(Hcc, (size_t)(P.hcc_total > 0 ? P.hcc_total : 1) * D, nullptr);
     KBA_BUF(gc, TK * kCamSlots * D, nullptr);

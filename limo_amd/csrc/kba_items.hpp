@@ -114,14 +114,9 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 template <bool CAM = true, class VP = const double*>
 KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, LinLane& out) {
     const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
-    const double z0 = vl[0] * p0 + vl[1] * p1 + vl[2] * p2 + vl[9];
-    const double z1 = vl[3] * p0 + vl[4] * p1 + vl[5] * p2 + vl[10];
-    const double z2r = vl[6] * p0 + vl[7] * p1 + vl[8] * p2 + vl[11];
-    const bool z_ok = fabs(z2r) >= 0.01;
+    double xn, yn, iz, z2;  // (z2 = 1 inside the failure band: keeps the arithmetic finite; masked below)
+    const bool z_ok = view_xy(vl, in.p, &xn, &yn, &iz, &z2);
     const bool ok = in.live != 0 && z_ok;
-    const double z2 = z_ok ? z2r : 1.0;  // keeps the arithmetic finite; masked below
-    const double iz = rcp_nr(z2);
-    const double xn = z0 * iz, yn = z1 * iz;
     const double ru = vl[25] * xn + (vl[26] - static_cast<double>(in.u));
     const double rv = vl[25] * yn + (vl[27] - static_cast<double>(in.v));
     const bool has_d = in.d > 0.0f;
@@ -146,9 +141,9 @@ KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost
     r3[1] = r1;
     r3[2] = r2;
     const double au = su * (vl[25] * iz);
-    c4[0] = au;
-    c4[1] = ok ? xn : 0.0;
-    c4[2] = ok ? yn : 0.0;
+    c4[0] = au;  // (au and sd are what is stored per observation; xn, yn are rebuilt by the consumers: view_xy)
+    c4[1] = xn;
+    c4[2] = yn;
     c4[3] = sd;
     if (!CAM) return z_ok || in.live == 0;
     const double a1 = au * xn, a2 = au * yn;
@@ -266,7 +261,8 @@ KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl,
         } else {
             if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, cam[j])) fail = 1;
         }
-        for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + s] = c4[i];  // (the residual stays in the lane: nobody reads it back)
+        bv.obs_c[s] = c4[0];  // (au, sd: the residual stays in the lane, xn / yn are rebuilt from the landmark: view_xy)
+        bv.obs_c[bv.SO + s] = c4[3];
         lin_lm_accum(vl, r3, c4, acc);
     }
     if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
@@ -345,10 +341,14 @@ KBA_HD int lm_damp_store(const BatchView& bv, const SolveConsts& c, double radiu
     }
     const double Bt[6] = {Li[0] * s[0], Li[1] * s[0], Li[2] * s[1], Li[3] * s[0], Li[4] * s[1], Li[5] * s[2]};
     for (int i = 0; i < 6; ++i) bv.lm_Li[i * bv.SL + gl] = Bt[i];
-    bv.lm_t[0 * bv.SL + gl] = Bt[0] * g[0];
-    bv.lm_t[1 * bv.SL + gl] = Bt[1] * g[0] + Bt[2] * g[1];
-    bv.lm_t[2 * bv.SL + gl] = Bt[3] * g[0] + Bt[4] * g[1] + Bt[5] * g[2];
+    (void)g;  // t = L^-1 S g = Bt g is formed by its readers from Bt and g (lm_t_of): 24 B per landmark less to write and read
     return fail;
+}
+// t = L^-1 S g of a landmark from its stored Bt and g (the rhs column of the Schur tile, the back-substitution)
+KBA_HD void lm_t_of(const double* Bt, const double* g, double* t) {
+    t[0] = Bt[0] * g[0];
+    t[1] = Bt[1] * g[0] + Bt[2] * g[1];
+    t[2] = Bt[3] * g[0] + Bt[4] * g[1] + Bt[5] * g[2];
 }
 // Stand-alone pass: only after a REJECTED step (new radius, same linearisation) - after a linearisation the landmark pass
 // (lin_lm_finish) has damped with the radius of the coming step already.
@@ -452,8 +452,9 @@ KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int
                 have = true;
             }
             double Ft[9], c4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + s];
+            c4[0] = bv.obs_c[s];
+            c4[3] = bv.obs_c[bv.SO + s];
+            view_xy(bv.view_lin + (int64_t)kViewLin * (wd.view0 + j), bv.lm + 3 * (int64_t)gl, &c4[1], &c4[2]);
             ft_build(c4, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4, Ft);
             schur_pose_block(Ft, R, M, lmk, sc + row0, Y);
         }
@@ -569,26 +570,30 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
         const int j0 = wd.n_view_fixed0;
         int s_cur = j0 < n_view ? slot[(int64_t)j0 * bv.SL] : -1;
         int s_nxt = j0 + 1 < n_view ? slot[(int64_t)(j0 + 1) * bv.SL] : -1;
-        double c4n[4];
+        double aun, sdn;
         {
             const int64_t o = s_cur >= 0 ? s_cur : 0;
-            for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
+            aun = bv.obs_c[o];
+            sdn = bv.obs_c[bv.SO + o];
         }
         for (int j = j0; j < n_view; ++j) {
             const bool have = s_cur >= 0;
             double c4[4];
-            for (int i = 0; i < 4; ++i) c4[i] = have ? c4n[i] : 0.0;
+            c4[0] = have ? aun : 0.0;
+            c4[3] = have ? sdn : 0.0;
             s_cur = s_nxt;
             s_nxt = j + 2 < n_view ? slot[(int64_t)(j + 2) * bv.SL] : -1;
             {
                 const int64_t o = s_cur >= 0 ? s_cur : 0;
-                for (int i = 0; i < 4; ++i) c4n[i] = bv.obs_c[i * bv.SO + o];
+                aun = bv.obs_c[o];
+                sdn = bv.obs_c[bv.SO + o];
             }
             // E^T (F dc) of the pair, with F dc = c^T Rc (dR x + d_trans) = c^T (K x + k0) and E = c^T H: the view's
             // K = Rc dR, k0 = Rc d_trans (cam_solve) and H (view_consts_item) are wave-uniform, c^T is spanned by the four
             // scalars (kba_math.hpp:ft_build) - no 3 x 3 Ft / E per observation
             const double* vs = bv.view_lin_c + (int64_t)kViewLin * (wd.view0 + j) + 28;  // K (9) | k0 (3)
             const double* H = bv.view_lin + (int64_t)kViewLin * (wd.view0 + j);
+            view_xy(H, x, &c4[1], &c4[2]);  // xn, yn of the pair as the linearisation had them
             const double w0 = vs[0] * x[0] + vs[1] * x[1] + vs[2] * x[2] + vs[9];
             const double w1 = vs[3] * x[0] + vs[4] * x[1] + vs[5] * x[2] + vs[10];
             const double w2 = vs[6] * x[0] + vs[7] * x[1] + vs[8] * x[2] + vs[11];
@@ -609,9 +614,9 @@ KBA_HD void backsub_lane(const BatchView& bv, const SolveConsts& c, int w, int g
         }
         double Bt[6], t[3], V[6], g[3];
         for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];  // L^-1 S (lm_damp_lane)
-        for (int i = 0; i < 3; ++i) t[i] = bv.lm_t[i * bv.SL + gl];
         for (int i = 0; i < 6; ++i) V[i] = bv.lm_V[i * bv.SL + gl];
         for (int i = 0; i < 3; ++i) g[i] = bv.lm_g[i * bv.SL + gl];
+        lm_t_of(Bt, g, t);
         // W'^T y_c = -S_l a  (a built from the UNSCALED camera step delta_c = -S_c y_c):  t' = t + L^-1 S a
         const double t0 = t[0] + Bt[0] * a[0];
         const double t1 = t[1] + Bt[1] * a[0] + Bt[2] * a[1];

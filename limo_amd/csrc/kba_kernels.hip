@@ -439,8 +439,8 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
         {
             const int64_t o = have ? s : dump;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
+            bv.obs_c[o] = c4[0];
+            bv.obs_c[bv.SO + o] = c4[3];
         }
         lin_lm_accum(vl, r3, c4, acc);
         const double tot = wave_sum_all(l.cost);
@@ -481,24 +481,17 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 #else
         if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
 #endif
-        {   // the four scalars of the factored Jacobian are what the Schur / back-substitution kernels read; the residual
+        {   // of the four scalars of the factored Jacobian the Schur / back-substitution kernels read au and sd (16 B per pair) and
+            // rebuild xn, yn from the landmark and the view (kba_math.hpp:view_xy: the same statements as here); the residual
             // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
-            // (limo_ba_evaluate has its own kernel), so it is not stored: 32 instead of 56 B written per pair
             const int64_t o = have ? s : dump;
 #if KBA_ABLATE == 61 || KBA_ABLATE == 69
             if (c.pad == 12345)
 #endif
-#if KBA_ABLATE == 65
             {
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                v2d* q = reinterpret_cast<v2d*>(bv.obs_c);
-                q[o] = (v2d){c4[0], c4[1]};
-                q[bv.SO + o] = (v2d){c4[2], c4[3]};
+                bv.obs_c[o] = c4[0];
+                bv.obs_c[bv.SO + o] = c4[3];
             }
-#else
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv.obs_c[i * bv.SO + o] = c4[i];
-#endif
         }
 #if KBA_ABLATE == 68 || KBA_ABLATE == 67
         acc.V[0] += r3[0] * c4[0]; acc.V[1] += r3[1] * c4[1]; acc.g[0] += r3[2] * c4[2]; acc.g[1] += c4[3];
@@ -692,8 +685,13 @@ __global__ __launch_bounds__(64 * kWideWaves) void k_schur_wide(BatchView bv, co
         double lmk[6];
         if (live) schur_load_lm(bv, gl, lmk);
         if (t < kSchurLm) {
+            double t3[3] = {0.0, 0.0, 0.0};
+            if (live) {
+                const double g3[3] = {bv.lm_g[gl], bv.lm_g[bv.SL + gl], bv.lm_g[2 * bv.SL + gl]};
+                lm_t_of(lmk, g3, t3);
+            }
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? bv.lm_t[cc * bv.SL + gl] : 0.0;
+            for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = t3[cc];
         }
         for (int q = t >> 4; q < nfk; q += (64 * kWideWaves) >> 4) {
             const int kl = fk[q];
@@ -761,8 +759,9 @@ __global__ __launch_bounds__(64 * kWideWaves) void k_schur_wide(BatchView bv, co
 //     indices (slot, state, ground-plane row) are fetched two tiles ahead.
 // One wave per workgroup, no cross-wave synchronisation; `span` consecutive blocks of one class per wave.
 constexpr int kSpBatch = 4;  // k-steps whose panel reads are in flight together
-constexpr int kSpKf = 60;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots | B_k (27): the
-                             // rotation-tangent Jacobian is linear in the landmark, M(q, p) = sum_k p_k B_k, B_k = M(q, e_k)
+constexpr int kSpKf = 72;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots | B_k (27): the
+                             // rotation-tangent Jacobian is linear in the landmark, M(q, p) = sum_k p_k B_k, B_k = M(q, e_k) |
+                             // H (9), h0 (3) of its view (view_xy: xn, yn of an observation are rebuilt from the landmark)
 
 __host__ __device__ inline int schur_lean_ld(int ncol) { return ncol | 1; }  // odd row stride: conflict-free fill
 __host__ __device__ inline int schur_lean_lds_bytes(int ncol) {
@@ -822,6 +821,8 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             for (int i = 0; i < 4; ++i) mine[18 + i] = pose[i];
         } else if (li < 10) {
             mine[9 + li - 1] = my_view >= 0 ? bv.view_cam[16 * (int64_t)my_view + 4 + li - 1] : 0.0;
+        } else if (li == 13) {
+            for (int i = 0; i < 12; ++i) mine[59 + i] = my_view >= 0 ? bv.view_lin[(int64_t)kViewLin * my_view + i] : 0.0;
         } else if (li < 13) {
             const int k = li - 10;
             const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
@@ -876,18 +877,19 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         seen = live && slot >= 0;
         att = GP && live && gg >= 0;
         if (seen) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c4[i] = bv.obs_c[i * bv.SO + slot];
+            c4[0] = bv.obs_c[slot];
+            c4[3] = bv.obs_c[bv.SO + slot];
 #pragma unroll
             for (int i = 0; i < 3; ++i) p[i] = bv.lm[3 * (int64_t)gl + i];
         }
-        if (seen || att) {
+        const bool want_t = live && (kq == 0 || two_tile);  // this lane supplies (its share of) the rhs column: t = Bt g
+        if (seen || att || want_t) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) Bt[i] = bv.lm_Li[i * bv.SL + gl];
         }
-        if (live && (kq == 0 || two_tile)) {
+        if (want_t) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) t3[i] = bv.lm_t[i * bv.SL + gl];
+            for (int i = 0; i < 3; ++i) t3[i] = bv.lm_g[i * bv.SL + gl];  // (g here; turned into t = Bt g at the fill)
         }
         if constexpr (GP) {
             if (att) {
@@ -910,6 +912,10 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
     const int mq = li < 8 ? li : li + 8;            // two-tile path: column of lane li in the second operand {0..7, 16..23}
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         // ---- fill: this lane's 3 x NS block of Y' (zeros where the landmark has no row with the keyframe)
+        if (live && (kq == 0 || two_tile)) {
+            const double g3[3] = {t3[0], t3[1], t3[2]};
+            lm_t_of(Bt, g3, t3);
+        }
         if (kq == 0 && !two_tile) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? t3[cc] : 0.0;
@@ -922,6 +928,7 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
                 double M[9], Ft[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) M[i] = p[0] * mine[32 + i] + p[1] * mine[41 + i] + p[2] * mine[50 + i];
+                view_xy(mine + 59, p, &c4[1], &c4[2]);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block<true>(Ft, mine, M, Bt, mine + 22, Y);
                 if (two_tile) {

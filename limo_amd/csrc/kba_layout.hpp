@@ -214,14 +214,14 @@ struct BatchView {
     // of 240 B for J_pose 3x6 + J_point 3x3; the landmark-parallel kernels rebuild Ft = c^T Rc, F = Ft [M | I],
     // E = Ft R from the view / pose / landmark they hold anyway.  Evaluate-only batches (Problem::Evaluate)
     // materialise Jp / Jl in full.
-    double *obs_r, *obs_c;            // [3|4][SO]; obs_r exists in evaluate-only batches only (the solve keeps residuals in registers)
+    double *obs_r, *obs_c;            // [3|2][SO]; obs_c = (au, sd); obs_r exists in evaluate-only batches only (the solve keeps residuals in registers)
     double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
     double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
     double* lblk_linfail;       // [n_lblk] 1.0: a functor failed in this landmark workgroup (a double: it travels in the exchange arena)
     // --- landmark side
     double *lm_V, *lm_g;        // planes [6|3][SL]  (unscaled E^T E, E^T r incl. ground-plane rows)
     double *lm_scale;           // [3][SL] Jacobi scaling
-    double *lm_Li, *lm_t;       // planes [6|3][SL]  inverse Cholesky factor of (V' + D^2), t = Li g'
+    double* lm_Li;              // planes [6][SL]  Bt = L^-1 S of the damped landmark block (V' + D^2) = L L^T (lm_damp_store)
     double* lblk_part;          // [n_lblk*8]: gmax, xnorm2, mcc, step2, cand2, fail, -, -
     // --- camera side
     double *Hcc, *gc;           // per window nc*nc (hcc_off) ; [TK*10]

@@ -136,6 +136,37 @@ KBA_HD void quat_dR(const double* q, const double* delta, double* D) {
     D[8] = -4.0 * (x * dx + y * dy);
 }
 
+// ---------------------------------------------------------------------------------------- projection into a view
+// Camera-frame point z = H p + h0 of landmark p in a view with constants vl (H = Rc R(q) at [0..8], h0 = Rc t + tc at
+// [9..11]; kba_items.hpp:view_consts_item).  ONE statement sequence with explicit fused multiply-adds: the linearisation and
+// the kernels that rebuild the factored Jacobian from (au, sd) and the landmark (Schur fill, back-substitution) must get the
+// same bits for the normalised coordinates xn = z0 / z2, yn = z1 / z2 whatever code surrounds the call.
+template <class VP>
+KBA_HD void view_point(VP vl, const double* p, double* z) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double t = vl[3 * i] * p[0];
+        t = fma(vl[3 * i + 1], p[1], t);
+        t = fma(vl[3 * i + 2], p[2], t);
+        z[i] = t + vl[9 + i];
+    }
+}
+// xn, yn and 1 / z of the point; a depth inside the functor's failure band (|z| < 0.01, cost_functors_ceres.hpp:78-83) is
+// replaced by 1 - the caller's au and sd are zero there, the coordinates only have to stay finite.  Returns |z| >= 0.01.
+template <class VP>
+KBA_HD bool view_xy(VP vl, const double* p, double* xn, double* yn, double* iz_out = nullptr, double* z2_out = nullptr) {
+    double z[3];
+    view_point(vl, p, z);
+    const bool z_ok = fabs(z[2]) >= 0.01;
+    const double z2 = z_ok ? z[2] : 1.0;
+    const double iz = rcp_nr(z2);
+    *xn = z[0] * iz;
+    *yn = z[1] * iz;
+    if (iz_out) *iz_out = iz;
+    if (z2_out) *z2_out = z2;
+    return z_ok;
+}
+
 // ---------------------------------------------------------------------------------------- losses
 // rho[0..2] of ScaledLoss(CauchyLoss(a), weight) at s
 KBA_HD void loss_cauchy(double a, double weight, double s, double* rho) {

@@ -266,7 +266,12 @@ struct EmuBatch : Executor {
                             for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + schur_col(ci, nfq)] = Y[a * 3 + cc];
                         }
                     }
-                    for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + nfq] = v.lm_t[cc * v.SL + gl];
+                    {
+                        const double g3[3] = {v.lm_g[gl], v.lm_g[v.SL + gl], v.lm_g[2 * v.SL + gl]};
+                        double t3[3];
+                        lm_t_of(lmk, g3, t3);
+                        for (int cc = 0; cc < 3; ++cc) z[(size_t)cc * nfp + nfq] = t3[cc];
+                    }
                     for (int cc = 0; cc < 3; ++cc) {
                         const double* zr = z.data() + (size_t)cc * nfp;
                         for (int a = 0; a <= wd.nf; ++a) {
