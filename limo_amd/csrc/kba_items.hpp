@@ -111,8 +111,46 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // the camera system anyway, so the pose Jacobian and U / g are not formed (a third of the arithmetic of a pair).  The cost, the
 // residual and the planes are the same statements either way.
 // VP: pointer to the view's constants - plain memory, or the constant address space (scalar loads) in k_lin_lm.
+// Entry k (0..27: cost | U 21, upper triangle row-major | g 6) of the camera-side sums of a pair from its pose Jacobian J
+// (3 x 6, row-major) and residual r3 - k is a compile-time constant at every call site (unrolled loops).
+template <int K>
+KBA_HD double lin_cam_entry_t(const double* J, const double* r3, double cost) {
+    if constexpr (K == 0) {
+        return cost;
+    } else if constexpr (K >= 22) {
+        constexpr int a = K - 22;
+        return J[a] * r3[0] + J[6 + a] * r3[1] + J[12 + a] * r3[2];
+    } else {
+        constexpr int q = K - 1;  // row a of the upper triangle starts at a * 6 - a (a - 1) / 2
+        constexpr int a = q < 6 ? 0 : q < 11 ? 1 : q < 15 ? 2 : q < 18 ? 3 : q < 20 ? 4 : 5;
+        constexpr int bb = a + (q - (a * 6 - a * (a - 1) / 2));
+        return J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
+    }
+}
+// entries K0 .. K0 + N - 1 into out[0 .. N - 1]
+template <int K0, int N>
+KBA_HD void lin_cam_entries(const double* J, const double* r3, double cost, double* out) {
+    if constexpr (N > 0) {
+        out[0] = lin_cam_entry_t<K0>(J, r3, cost);
+        lin_cam_entries<K0 + 1, N - 1>(J, r3, cost, out + 1);
+    }
+}
+
+// lin_obs_core: everything of lin_obs up to the pose Jacobian J (filled when CAM); lin_obs adds the camera-side sums.
+template <bool CAM = true, class VP = const double*>
+KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J);
 template <bool CAM = true, class VP = const double*>
 KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, LinLane& out) {
+    double J[18];
+    const bool ok = lin_obs_core<CAM>(vl, c, in, want_cost, r3, c4, out.cost, J);
+    if (CAM) {
+        lin_cam_entries<1, 21>(J, r3, 0.0, out.U);
+        lin_cam_entries<22, 6>(J, r3, 0.0, out.g);
+    }
+    return ok;
+}
+template <bool CAM, class VP>
+KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J) {
     const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
     double xn, yn, iz, z2;  // (z2 = 1 inside the failure band: keeps the arithmetic finite; masked below)
     const bool z_ok = view_xy(vl, in.p, &xn, &yn, &iz, &z2);
@@ -135,7 +173,7 @@ KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost
     }
     su = ok ? su : 0.0;
     sd = ok && has_d ? sd : 0.0;
-    out.cost = ok ? cost : 0.0;
+    cost_out = ok ? cost : 0.0;
     const double r0 = su * ru, r1 = su * rv, r2 = sd * rd;
     r3[0] = r0;
     r3[1] = r1;
@@ -147,7 +185,7 @@ KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost
     c4[3] = sd;
     if (!CAM) return z_ok || in.live == 0;
     const double a1 = au * xn, a2 = au * yn;
-    double J[18];  // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = sum_k p_k C_k
+    // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = sum_k p_k C_k
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double g0 = vl[28 + j] * p0 + vl[37 + j] * p1 + vl[46 + j] * p2;
@@ -159,13 +197,6 @@ KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost
         J[3 + j] = au * vl[12 + j] - a1 * vl[18 + j];
         J[9 + j] = au * vl[15 + j] - a2 * vl[18 + j];
         J[15 + j] = sd * vl[18 + j];
-    }
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int bb = a; bb < 6; ++bb) out.U[k++] = J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
-        out.g[a] = J[a] * r0 + J[6 + a] * r1 + J[12 + a] * r2;
     }
     return z_ok || in.live == 0;
 }
@@ -197,12 +228,30 @@ KBA_HD void lin_lm_accum(VP vl, const double* r3, const double* c4, LmAcc& a) {
         a.g[2] += e2 * r3[row];
     }
 }
+// What the landmark's tail needs from memory besides its sums - fetched BEFORE the view loop (lin_lm_tail_fetch): behind the
+// loop's plane stores these loads could not be moved up by the compiler (possible aliasing), and a dependent round trip per
+// landmark at the end of a workgroup's life is a fifth of the kernel (profiles/r05_experiment_lin_lm_ablations.txt).
+struct LmTailIn {
+    int gg;             // ground-plane row of the landmark or -1
+    int compute_scale;  // this linearisation defines the Jacobi scale
+    double radius;      // trust-region radius of the coming step
+    double sc[3];       // Jacobi scale of the landmark's columns (valid unless compute_scale)
+};
+KBA_HD void lin_lm_tail_fetch(const BatchView& bv, int w, int gl, LmTailIn& t) {
+    t.gg = bv.lm_gp[gl];
+    t.compute_scale = bv.st[w].compute_scale;
+    t.radius = bv.st[w].radius;
+#if defined(KBA_ABLATE) && KBA_ABLATE >= 60 && KBA_ABLATE < 80
+    t.compute_scale = 0;  // (ablation builds: the steady-state tail - the scale is read, not computed)
+#endif
+    for (int i = 0; i < 3; ++i) t.sc[i] = t.compute_scale ? 1.0 : bv.lm_scale[i * bv.SL + gl];
+}
 // after the views: the landmark's ground-plane row, V / g / Jacobi scale to memory, damping.
-// part: [0] max|g|, [1] |x|^2, [5] 1 = the damped block is not positive definite
-KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int w, int gl, LmAcc& a, double* part) {
+// part: [0] max|g|, [1] |x|^2, [5] 1 = the damped block is not positive definite;  x = the landmark
+KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int gl, const double* x, const LmTailIn& t, LmAcc& a, double* part) {
     double* V = a.V;
     double* g = a.g;
-    const int gg = bv.lm_gp[gl];
+    const int gg = t.gg;
     if (gg >= 0) {
         const double e0 = bv.gp_E[0 * bv.SG + gg], e1 = bv.gp_E[1 * bv.SG + gg], e2 = bv.gp_E[2 * bv.SG + gg];
         const double r = bv.gp_r[gg];
@@ -219,18 +268,17 @@ KBA_HD void lin_lm_finish(const BatchView& bv, const SolveConsts& c, int w, int 
     for (int i = 0; i < 6; ++i) bv.lm_V[i * bv.SL + gl] = V[i];
     for (int i = 0; i < 3; ++i) bv.lm_g[i * bv.SL + gl] = g[i];
     double sc[3];
-    if (bv.st[w].compute_scale) {
+    if (t.compute_scale) {
         const double d[3] = {V[0], V[3], V[5]};
         for (int i = 0; i < 3; ++i) bv.lm_scale[i * bv.SL + gl] = sc[i] = c.jacobi_scaling ? 1.0 / (1.0 + sqrt(d[i])) : 1.0;
     } else {
-        for (int i = 0; i < 3; ++i) sc[i] = bv.lm_scale[i * bv.SL + gl];
+        for (int i = 0; i < 3; ++i) sc[i] = t.sc[i];
     }
     part[0] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-    const double* x = bv.lm + 3 * (int64_t)gl;
     part[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     // (V' + D^2) = L L^T for the step that follows this linearisation (the radius is final: kba_lm.hpp:lm_decide_step);
     // the stand-alone k_lm_damp only runs after rejected steps
-    part[5] = lm_damp_store(bv, c, bv.st[w].radius, gl, sc, V, g) ? 1.0 : 0.0;
+    part[5] = lm_damp_store(bv, c, t.radius, gl, sc, V, g) ? 1.0 : 0.0;
 }
 // Plain form of one landmark for the CPU emulation (k_lin_lm runs the same statements software-pipelined and
 // branch-free): cam[j] receives the camera-side sums of view j.  Returns 1 if a functor failed.
@@ -265,7 +313,11 @@ KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl,
         bv.obs_c[bv.SO + s] = c4[3];
         lin_lm_accum(vl, r3, c4, acc);
     }
-    if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
+    if (state == 1) {
+        LmTailIn t;
+        lin_lm_tail_fetch(bv, w, gl, t);
+        lin_lm_finish(bv, c, gl, bv.lm + 3 * (int64_t)gl, t, acc, part);
+    }
     return fail;
 }
 

@@ -133,6 +133,27 @@ __device__ __forceinline__ double wave_reduce_scatter28(const double* v, int lan
     const double y = halve_dpp<2>(x0, x1, b1);
     return y + dpp_mov(y, 3);
 }
+// The same for 14 values (7 + 4 + 2 + 1 + 1 + 1 = 16 exchange-adds).  k_lin_lm reduces the 28 camera-side sums of a view as two
+// halves: with all 28 (56 registers) live next to the Jacobian the kernel needed 167 registers - three waves per SIMD; in halves it
+// fits into 128 - four.  After the call the lane with rs14_index(lane) = i >= 0 holds the wave total of v[i].
+__device__ __forceinline__ int rs14_index(int lane) {
+    const int half = lane >> 5, rowp = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+    const int j = b2 ? (b3 ? 3 : 1) : (b3 ? 2 : 0);
+    if ((lane & 3) || (j == 3 && rowp)) return -1;
+    return 7 * half + (j == 3 ? 3 : j + 4 * rowp);
+}
+__device__ __forceinline__ double wave_reduce_scatter14(const double* v, int lane) {
+    double s[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s[i] = swap32_add(v[i], v[i + 7]);  // lanes < 32: values 0..6, lanes >= 32: 7..13
+    const double u0 = swap16_add(s[0], s[4]), u1 = swap16_add(s[1], s[5]), u2 = swap16_add(s[2], s[6]);  // even rows i, odd rows i + 4
+    const double u3 = swap16_add(s[3], s[3]);                                                           // both rows: 3
+    const bool b3 = lane & 8, b2 = lane & 4;
+    const double w0 = halve_dpp<0>(u0, u2, b3), w1 = halve_dpp<0>(u1, u3, b3);
+    const double x = halve_dpp<1>(w0, w1, b2);
+    const double y = x + dpp_mov(x, 2);
+    return y + dpp_mov(y, 3);
+}
 // out_global[i] = sum over the workgroup of vals[i], i < 28;  lds: 4 * 28 doubles
 __device__ __forceinline__ void block_sum28(const double* vals, double* lds, double* out_global) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,7 +396,11 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
+#if KBA_ABLATE >= 60 && KBA_ABLATE < 80
+    const bool want_cost = false;  // (ablation builds time the STEADY-STATE body on a first linearisation: no cost value, 70 = nothing left out)
+#else
     const bool want_cost = st.first != 0;  // workgroup-uniform
+#endif
     const WinDesc& wd = bv.win[w];
     const int n_view = wd.n_view;
     const int n = bv.lblk_n[b];
@@ -389,6 +414,8 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     in.p[2] = bv.lm[3 * (int64_t)gl + 2];
     in.w = bv.lm_weight[gl];
     in.sw = sqrt(in.w);
+    LmTailIn tail;  // (fetched here, in front of the view loop's stores: kba_items.hpp:LmTailIn)
+    lin_lm_tail_fetch(bv, w, gl, tail);
     const int32_t* slot = bv.lm_slot + gl;
     typename ViewPtr<KVIEW>::type vc = (typename ViewPtr<KVIEW>::type)(bv.view_lin + (int64_t)kViewLin * wd.view0);
     double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
@@ -410,7 +437,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         v_n = bv.obs_v[o];
         d_n = bv.obs_d[o];
     }
-    const int rs_idx = rs28_index(lane);
+    const int rs_idx = rs28_index(lane), rs14_idx = rs14_index(lane);
     // ---- the leading views of keyframes WITHOUT a free pose block (WinDesc::n_view_fixed0: the Pose-fixed oldest keyframe of
     //      a sliding window): same pipeline, same planes, same landmark-block terms, but no pose Jacobian, no U / g, and only the
     //      cost leaves the wave (the slice's other 27 entries are zeros).  A loop of its own: the general loop below stays one
@@ -464,7 +491,10 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         in.live = have;
         LinLane l;
         double r3[3], c4[4];
-#if KBA_ABLATE == 64 || KBA_ABLATE == 69
+#if KBA_ABLATE == 0
+        double J[18];
+        if (!lin_obs_core<true>(vl, c, in, want_cost, r3, c4, l.cost, J)) fail = 1;
+#elif KBA_ABLATE == 64 || KBA_ABLATE == 69
         if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
 #pragma unroll
         for (int i = 0; i < 21; ++i) l.U[i] = r3[i % 3] * c4[i % 4];
@@ -498,13 +528,29 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 #else
         lin_lm_accum(vl, r3, c4, acc);  // zeros where the pair does not exist
 #endif
+        static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter14 x 2");
+#if KBA_ABLATE == 0
+        // the 28 camera-side sums of the view leave the wave in two halves of 14 (register pressure: wave_reduce_scatter14)
+        {
+            double vals[14];
+            lin_cam_entries<0, 14>(J, r3, l.cost, vals);
+            const double tot = wave_reduce_scatter14(vals, lane);
+            if (rs14_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs14_idx] = tot;
+        }
+        {
+            double vals[14];
+            lin_cam_entries<14, 14>(J, r3, l.cost, vals);
+            const double tot = wave_reduce_scatter14(vals, lane);
+            if (rs14_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + 14 + rs14_idx] = tot;
+        }
+        continue;
+#endif
         double vals[kLinPartial];
         vals[0] = l.cost;
 #pragma unroll
         for (int i = 0; i < 21; ++i) vals[1 + i] = l.U[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
-        static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter28");
 #if KBA_ABLATE == 63 || KBA_ABLATE == 69
         double tot = 0.0;
 #pragma unroll
@@ -517,15 +563,12 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     // the landmark's ground-plane row (B3) is linearised by its own lane right here, before lin_lm_finish adds it to the
     // landmark block (a separate k_gp launch per linearisation did this before: one launch per iteration less)
-    if (in_block) {
-        const int gg = bv.lm_gp[gl];
-        if (gg >= 0) gp_lane(bv, gg, false, bv.gp_cost);
-    }
+    if (in_block && tail.gg >= 0) gp_lane(bv, tail.gg, false, bv.gp_cost);
 #if KBA_ABLATE == 62 || KBA_ABLATE == 69
-    if (state == 1 && c.pad == 12345) lin_lm_finish(bv, c, w, gl, acc, part);
+    if (state == 1 && c.pad == 12345) lin_lm_finish(bv, c, gl, in.p, tail, acc, part);
     part[0] = acc.V[0] + acc.V[1] + acc.V[2] + acc.V[3] + acc.V[4] + acc.V[5] + acc.g[0] + acc.g[1] + acc.g[2];
 #else
-    if (state == 1) lin_lm_finish(bv, c, w, gl, acc, part);
+    if (state == 1) lin_lm_finish(bv, c, gl, in.p, tail, acc, part);
 #endif
     __shared__ double lds[8];
     const double m = wave_max(part[0]);
@@ -876,6 +919,15 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         live = st == 1;
         seen = live && slot >= 0;
         att = GP && live && gg >= 0;
+#if KBA_ABLATE == 83
+        if (bv.n_win != -12345) {
+            c4[0] = c4[3] = 1.0 + l0;
+            p[0] = p[1] = p[2] = 2.0 + li;
+            for (int i = 0; i < 6; ++i) Bt[i] = 0.5 + i;
+            for (int i = 0; i < 3; ++i) t3[i] = 1.5;
+            return;
+        }
+#endif
         if (seen) {
             c4[0] = bv.obs_c[slot];
             c4[3] = bv.obs_c[bv.SO + slot];
@@ -907,6 +959,9 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         fetch_index(kSchurLm, n_st, n_slot, n_gg);
         fetch_data(0, st0, slot0, gg0);
     }
+#if KBA_ABLATE == 84
+    const double fk_c0 = mine[0], fk_c1 = mine[1];
+#endif
     constexpr int NS = GP ? kCamSlots : 6;  // slots of a keyframe this kernel fills
     double yt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // two-tile path: this lane's share of the rhs, slots of its keyframe
     const int mq = li < 8 ? li : li + 8;            // two-tile path: column of lane li in the second operand {0..7, 16..23}
@@ -925,12 +980,23 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
 #pragma unroll
             for (int i = 0; i < 3 * NS; ++i) Y[i] = 0.0;
             if (seen) {
+#if KBA_ABLATE == 82
+#pragma unroll
+                for (int i = 0; i < 18; ++i) Y[i] = p[i % 3] * c4[0] + Bt[i % 6];
+#else
                 double M[9], Ft[9];
+#if KBA_ABLATE == 84  // (no LDS reads of the keyframe constants: lane-local stand-ins)
+                double fake[72];
+#pragma unroll
+                for (int i = 0; i < 72; ++i) fake[i] = fk_c0 + i * fk_c1;
+                const double* mine = fake;
+#endif
 #pragma unroll
                 for (int i = 0; i < 9; ++i) M[i] = p[0] * mine[32 + i] + p[1] * mine[41 + i] + p[2] * mine[50 + i];
                 view_xy(mine + 59, p, &c4[1], &c4[2]);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block<true>(Ft, mine, M, Bt, mine + 22, Y);
+#endif
                 if (two_tile) {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) yt[a] += Y[a * 3 + 0] * t3[0] + Y[a * 3 + 1] * t3[1] + Y[a * 3 + 2] * t3[2];
@@ -976,6 +1042,9 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         schur_wave_sync<COOP>();
         // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps, upper tiles
         const double* zp = Z + kq * ld + li;
+#if KBA_ABLATE == 81
+        if (bv.n_win == -12345)
+#endif
         if (TM == 1 || Tt == 1) {  // wave-uniform
 #pragma unroll
             for (int h = 0; h < 12; h += kSpBatch) {

@@ -26,11 +26,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ws = bench.generate_windows([7000 + i for i in range(B)], 5, 2000)
 pk = "/tmp/lin_ablate_windows.pkl"
 pickle.dump(ws, open(pk, "wb"))
-NAMES = {61: "no plane stores", 62: "no landmark tail", 63: "no cross-lane reduction", 64: "no pose Jacobian / U / g", 65: "planes as 2 x 16-byte stores",
+NAMES = {70: "steady-state body, nothing left out (no cost value, scale read)", 61: "no plane stores", 62: "no landmark tail", 63: "no cross-lane reduction", 64: "no pose Jacobian / U / g", 65: "planes as 2 x 16-byte stores",
          67: "no arithmetic at all (loads, stores, reduction, tail)", 68: "no landmark block (E, V, g)", 69: "61+62+63+64 (projection, residual, loss, E, V only)"}
 variants = [("product", None)] + [("%d %s" % (int(os.path.basename(f)[12:-3]), NAMES.get(int(os.path.basename(f)[12:-3]), "")), f) for f in sorted(glob.glob(os.path.join(ROOT, "limo_amd/lib/ablate/liblimo_hip_*.so")))]
-for tag, lib in variants + [("product (again)", None)]:
-    env = dict(os.environ, KBA_GROUPS="1")  # (kernel timing by events needs one slot group)
+lib70 = os.path.join(ROOT, "limo_amd/lib/ablate/liblimo_hip_70.so")
+extra = [("70 at 4 waves / SIMD (128 registers)", lib70, {"KBA_LIN_WAVES": "4"}), ("70 at 2 waves / SIMD (LDS pad)", lib70, {"KBA_LIN_LDS_PAD": "80000"})] if os.path.exists(lib70) else []
+for tag, lib, more in [(t, l, {}) for t, l in variants] + extra + [("product (again)", None, {})]:
+    env = dict(os.environ, KBA_GROUPS="1", **more)  # (kernel timing by events needs one slot group)
     if lib:
         env["LIMO_HIP_LIB"] = lib
     subprocess.call([sys.executable, os.path.abspath(__file__), "--child", pk, tag], env=env)
