@@ -227,12 +227,12 @@ void BundleAdjusterKeyframes::push(const std::vector<Keyframe>& kfs) {
 void BundleAdjusterKeyframes::push(const Keyframe& kf) { push(Keyframe(kf)); }
 
 void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
+    Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
     const TimestampNSec stamp = kf_in.timestamp_;
     const auto stored = std::make_shared<Keyframe>(std::move(kf_in));
     keyframes_[stamp] = stored;
     const Keyframe& kf = *stored;
     active_keyframe_ids_.insert(stamp);
-    measured_ids_.erase(stamp);  // (a keyframe pushed again under the same stamp replaces the old one)
     // Every landmark this keyframe introduces is initialised in ONE device call (the reference does it one by one,
     // :289-330): depth back-projection where the keyframe measures a depth, N-view triangulation otherwise.
     std::vector<LandmarkId> ids;
@@ -366,6 +366,7 @@ bool BundleAdjusterKeyframes::calculateLandmark(const LandmarkId& lId, Vector3d&
 
 // ------------------------------------------------------------------------------------------ labels
 void BundleAdjusterKeyframes::updateLabels(const Tracklets& t, double shrubbery_weight) {
+    Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
     // (the three label sets are looked up once, not per track: a std::string key per lookup was a third of this function)
     // (... and turned into tables over the label value once per call: three std::set searches per track were half of what was left)
     struct LabelSet {
@@ -455,21 +456,12 @@ const Keyframe& BundleAdjusterKeyframes::getKeyframe(TimestampSec timestamp) con
 }
 
 // ------------------------------------------------------------------------------------------ window cut (:907-987)
-const std::vector<LandmarkId>& BundleAdjusterKeyframes::measuredIds(const Keyframe& kf) {
-    std::vector<LandmarkId>& v = measured_ids_[kf.timestamp_];
-    const auto& ms = kf.measurements_;
-    const bool looks_right = v.size() == ms.size() && (v.empty() || (v.front() == ms.cbegin()->first && v.back() == ms.crbegin()->first));
-    if (!looks_right) {  // from the keyframe's measurement table (one row per (landmark, camera), ids ascending): each id once
-        v.clear();
-        v.reserve(ms.size());
-        for (const auto& row : kf.measurementTable())
-            if (v.empty() || v.back() != row.id) v.push_back(row.id);
-    }
-    return v;
-}
+// (the ids live with the keyframe's measurement table: trusted inside one public call, or for a frozen keyframe - keyframe.hpp)
+const std::vector<LandmarkId>& BundleAdjusterKeyframes::measuredIds(const Keyframe& kf) { return kf.measuredIds(); }
 
 void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmarks, int min_size_optimization_window,
                                                   int max_size_optimization_window) {
+    Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
     auto sorted = getSortedIdsWithActiveKeyframePtrs();
     if (sorted.empty()) return;
     const Keyframe& newest = *sorted.back().second;
@@ -500,7 +492,6 @@ void BundleAdjusterKeyframes::deactivateKeyframes(int min_num_connecting_landmar
         }
         if (!cur.is_active_) {
             active_keyframe_ids_.erase(it->first);
-            measured_ids_.erase(cur.timestamp_);  // (a keyframe that left the window is not asked again)
         }
     }
     // active landmarks that some active keyframe still measures: the union of the active keyframes' id arrays (merged pairwise), then ONE
@@ -579,6 +570,7 @@ struct Flat {
         d.reserve(room);
         // (the keyframe's measurement table and the index are both sorted by landmark id: one merge pass over two arrays; the map
         // node of a measurement is only touched when its landmark is in the window)
+        Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
         const auto& rows = kf.measurementTable();
         auto it = lm_index.cbegin();
         bool have_cam = false;  // (camera id -> index of the flattened camera table, looked up when the id changes)
@@ -649,6 +641,7 @@ std::string report_string(const limo_ba_report& r, const char* what) {
 }  // namespace
 
 std::string BundleAdjusterKeyframes::solve() {
+    Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
     if (keyframes_.size() < 3) throw NotEnoughKeyframesException(keyframes_.size(), 3);
     using clk = std::chrono::steady_clock;
     static const bool shim_trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;  // where the host time of solve() goes
@@ -716,6 +709,7 @@ std::string BundleAdjusterKeyframes::solve() {
 }
 
 std::string BundleAdjusterKeyframes::adjustPoseOnly(Keyframe& kf) {
+    Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
     using clk = std::chrono::steady_clock;
     static const bool shim_trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;
     const auto t_p0 = clk::now();

@@ -95,7 +95,6 @@ private:
     // landmark ids a pushed keyframe measures, in id order (the keys of its measurements_ as one contiguous array: the window cut
     // merges them instead of walking the maps node by node); rebuilt from the map whenever it does not look like it any more
     const std::vector<LandmarkId>& measuredIds(const Keyframe& kf);
-    std::map<KeyframeId, std::vector<LandmarkId>> measured_ids_;
     limo_ctx* ctx_ = nullptr;
     double solver_time_sec;
 };

@@ -37,6 +37,7 @@ public:
     // the column of THIS keyframe's stamp is the measurement it contributes.  A track shorter than that column was not
     // alive yet.  (A stamp that is not listed gives column == stamps.size(), like std::distance to end() in the reference.)
     void assignMeasurements(const Tracklets& tracklets, const CameraId& cam_id) {
+        measurementsChanged();
         const size_t col = stampColumn(tracklets.stamps);
         for (const Tracklet& t : tracklets.tracks) {
             if (col >= t.feature_points.size()) continue;
@@ -50,6 +51,7 @@ public:
     // The same for a rig (src/keyframe.cpp:43-59): no per-camera copies of the tracklets - one pass, the column is found
     // once.  An id that `landmark_lookup` does not know throws std::out_of_range, as the reference's .at() does.
     void assignMeasurements(const Tracklets& tracklets, const std::map<LandmarkId, CameraIds>& landmark_lookup) {
+        measurementsChanged();
         const size_t col = stampColumn(tracklets.stamps);
         for (const Tracklet& t : tracklets.tracks) {
             const CameraIds& seen_by = landmark_lookup.at(t.id);
@@ -103,29 +105,52 @@ public:
     // measurements_ as ONE array in the order the map iterates it (landmark id, then camera id), each row with a pointer to the
     // Measurement inside the map: what the selector's schemes, the window cut and the flattening merge against sorted landmark lists
     // instead of walking the map node by node (not in the reference; its std::map stays the interface and the owner of the values - a
-    // value changed in place is seen through the pointer).  Built on first use and again whenever the map no longer looks like the
-    // one it was built from (number of landmarks, first and last id); a copy of a keyframe builds its own.  Not for concurrent callers.
+    // value changed in place is seen through the pointer).
+    //
+    // measurements_ is a PUBLIC member that a caller may edit between two calls into this library (the reference's interface), and no
+    // cheap test sees every such edit.  So the table is only trusted for as long as nobody outside can have touched the map:
+    //   * inside ONE call of a public entry point of this library (they open a MeasurementTableScope: the map cannot change while the
+    //     call runs - the classes are single-threaded like the reference's) the table is built on first use and reused;
+    //   * across calls only for a keyframe whose owner has promised not to edit measurements_ any more: freezeMeasurements() (the
+    //     streaming driver does for the keyframes it creates; assignMeasurements() takes the promise back);
+    //   * anywhere else it is rebuilt on every use - always right, one walk over the map.
+    // A copy of a keyframe builds its own table (the rows point into the source's map); a moved map keeps its nodes.
     struct MeasurementRef {
         LandmarkId id;
         CameraId cam;
         const Measurement* m;
     };
-    // A caller that edits measurements_ STRUCTURALLY after the keyframe was used (erases and inserts that leave the number of landmarks
-    // and both end ids as they were - the one change the check below cannot see) says so with this call; values changed in place,
-    // insertions and erasures that change the count or an end are picked up without it.
-    void measurementsChanged() const { table_.n_landmarks = static_cast<size_t>(-1); }
-    const std::vector<MeasurementRef>& measurementTable() const {
-        std::vector<MeasurementRef>& rows = table_.rows;
-        const bool looks_right = table_.n_landmarks == measurements_.size() &&
-                                 (measurements_.empty() || (!rows.empty() && rows.front().id == measurements_.cbegin()->first && rows.back().id == measurements_.crbegin()->first));
-        if (!looks_right) {
-            rows.clear();
-            rows.reserve(measurements_.size());
-            for (const auto& lm : measurements_)
-                for (const auto& cm : lm.second) rows.push_back({lm.first, cm.first, &cm.second});
-            table_.n_landmarks = measurements_.size();
+    struct MeasurementTableScope {  // opened by the public entry points; nests (the outermost call defines the epoch)
+        MeasurementTableScope() {
+            if (depth()++ == 0) ++epoch();
         }
-        return rows;
+        ~MeasurementTableScope() { --depth(); }
+        MeasurementTableScope(const MeasurementTableScope&) = delete;
+        MeasurementTableScope& operator=(const MeasurementTableScope&) = delete;
+        static unsigned long long& epoch() {
+            static thread_local unsigned long long e = 0;
+            return e;
+        }
+        static int& depth() {
+            static thread_local int d = 0;
+            return d;
+        }
+    };
+    void freezeMeasurements() const { table_.frozen = true; }
+    bool measurementsFrozen() const { return table_.frozen; }
+    // (kept for callers of the earlier interface: the next use rebuilds the table - and the promise of freezeMeasurements() is off)
+    void measurementsChanged() const {
+        table_.valid_epoch = 0;
+        table_.frozen = false;
+    }
+    const std::vector<MeasurementRef>& measurementTable() const {
+        refreshTable();
+        return table_.rows;
+    }
+    // the landmark ids of measurements_ in ascending order, each once (the keys of the map as one contiguous array)
+    const std::vector<LandmarkId>& measuredIds() const {
+        refreshTable();
+        return table_.ids;
     }
 
 private:
@@ -137,20 +162,40 @@ private:
         is_active_ = true;
         assignPose(p);
     }
+    void refreshTable() const {
+        const bool in_call = MeasurementTableScope::depth() > 0;
+        const bool trusted = table_.valid_epoch != 0 && (table_.frozen || (in_call && table_.valid_epoch == MeasurementTableScope::epoch()));
+        if (trusted) return;
+        std::vector<MeasurementRef>& rows = table_.rows;
+        rows.clear();
+        table_.ids.clear();
+        rows.reserve(measurements_.size());
+        table_.ids.reserve(measurements_.size());
+        for (const auto& lm : measurements_) {
+            table_.ids.push_back(lm.first);
+            for (const auto& cm : lm.second) rows.push_back({lm.first, cm.first, &cm.second});
+        }
+        // (outside a call the table is never trusted again; a frozen keyframe only needs "built once")
+        table_.valid_epoch = in_call ? MeasurementTableScope::epoch() : (table_.frozen ? 1 : 0);
+    }
     size_t stampColumn(const std::vector<TimestampNSec>& stamps) const {
         size_t col = 0;
         while (col < stamps.size() && stamps[col] != timestamp_) ++col;
         return col;
     }
 
-    struct TableCache {  // (copying a keyframe does not copy the table: its pointers lead into the source's map)
+    struct TableCache {  // (copying a keyframe does not copy the table: its pointers lead into the source's map; the promise does carry over)
         std::vector<MeasurementRef> rows;
-        size_t n_landmarks = static_cast<size_t>(-1);
+        std::vector<LandmarkId> ids;
+        unsigned long long valid_epoch = 0;  // epoch of the call the table was built in (frozen: any non-zero value); 0 = not built
+        bool frozen = false;
         TableCache() = default;
-        TableCache(const TableCache&) {}
-        TableCache& operator=(const TableCache&) {
+        TableCache(const TableCache& o) : frozen(o.frozen) {}
+        TableCache& operator=(const TableCache& o) {
             rows.clear();
-            n_landmarks = static_cast<size_t>(-1);
+            ids.clear();
+            valid_epoch = 0;
+            frozen = o.frozen;
             return *this;
         }
         TableCache(TableCache&&) = default;  // (a moved map keeps its nodes where they are)

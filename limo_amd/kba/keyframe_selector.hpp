@@ -62,6 +62,7 @@ public:
         size_t n = 0;
         // (both keyframes' measurement tables are in (landmark id, camera id) order: one merge pass over two arrays instead of two tree
         // searches per measurement; the terms are added in the order of the statement it replaces - the new frame's landmarks, their cameras)
+        Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
         const auto& rn = new_frame->measurementTable();
         const auto& rl = last->measurementTable();
         size_t il = 0;
@@ -137,6 +138,7 @@ public:
 
     // frames: candidates (the node passes one); buffer_selected_frames: the keyframes already in the optimisation
     Keyframes select(const Keyframes& frames, std::map<KeyframeId, Keyframe::Ptr> buffer_selected_frames) const {
+        Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
         // frames in time order; a frame accepted earlier in this call counts as a keyframe for the later ones
         std::vector<Keyframe::Ptr> ordered(frames.begin(), frames.end());
         std::sort(ordered.begin(), ordered.end(), [](const auto& a, const auto& b) { return a->timestamp_ < b->timestamp_; });

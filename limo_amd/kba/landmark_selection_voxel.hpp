@@ -109,6 +109,7 @@ inline std::vector<std::pair<LandmarkId, double>> calcFlowSorted(const std::vect
     std::vector<unsigned char> n_cams(n, 0);
     bool overflow = false;
     for (const auto& kf : kfs) {
+        Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
         const auto& rows = kf->measurementTable();  // (landmark id, camera id) ascending: merged with the ids, no map node is visited for an id that is not asked for
         size_t im = 0;
         for (size_t i = 0; i < n && im < rows.size(); ++i) {
@@ -209,6 +210,7 @@ inline std::vector<LandmarkId> chooseFarLmIds(size_t max_num, const std::vector<
     // Keyframe::hasMeasurement(id) - some camera of the keyframe's rig measured it - per (id, keyframe), as a binary search in the
     // keyframe's measurement table (contiguous) instead of a descent through its map
     for (const auto& kf : keyframes) {
+        Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
         const auto& rows = kf.second->measurementTable();
         for (auto& k : keyed) {
             auto it = std::lower_bound(rows.begin(), rows.end(), k.second, [](const Keyframe::MeasurementRef& r, LandmarkId id) { return r.id < id; });
@@ -424,6 +426,7 @@ public:
             const EigenPose T = kf.getEigenPose();
             // the landmarks that qualify (a fifth of them with the ground-plane predicate), then their measurements in this
             // keyframe - both in id order: a merge with the keyframe's measurement table (binary search ahead when the next id is far)
+            Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
             const auto& rows = kf.measurementTable();
             size_t im = 0;
             for (const auto& lm_it : qualifies[cfg]) {

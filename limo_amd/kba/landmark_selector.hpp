@@ -95,6 +95,7 @@ public:
             const EigenPose T = kf.getEigenPose();
             std::map<CameraId, EigenPose> cam_T;
             for (const auto& c : kf.cameras_) cam_T[c.first] = c.second->getEigenPose();
+            Keyframe::MeasurementTableScope table_scope;  // (the table is trusted for the duration of this call: keyframe.hpp)
             const auto& rows = kf.measurementTable();  // (id, camera) rows in id order: the merge touches no map node
             auto il = landmarks.cbegin();
             size_t im = 0, i = 0;
@@ -166,6 +167,7 @@ public:
     // landmarks is built for it).  Between the schemes the landmarks travel as sorted vectors (LandmarkSchemeBase::
     // getSelectionSorted); the decisions are those of the map-based statements, id for id.
     std::set<LandmarkId> select(const LandmarkView& landmarks, const KeyframeMap& kfs) {
+        Keyframe::MeasurementTableScope table_scope;  // (measurement tables are trusted inside one public call: keyframe.hpp)
         using clk = std::chrono::steady_clock;
         static const bool trace = std::getenv("LIMO_SHIM_TRACE") != nullptr;
         const auto t0 = clk::now();

@@ -221,7 +221,9 @@ public:
         EigenPose pose = EigenPose::Identity();
         bool is_keyframe = false;
         if (ba_.keyframes_.empty()) {  // first frame: Pose-fixed keyframe at the origin (:305-326)
-            ba_.push(Keyframe(stamp, tracklets, camera_, EigenPose::Identity(), Keyframe::FixationStatus::Pose, ground_plane));
+            Keyframe first(stamp, tracklets, camera_, EigenPose::Identity(), Keyframe::FixationStatus::Pose, ground_plane);
+            first.freezeMeasurements();  // (this driver owns its keyframes and never edits their measurements_: the table may outlive the call)
+            ba_.push(std::move(first));
             is_keyframe = true;
         } else {
             EigenPose prior = external_prior ? *external_prior
@@ -234,6 +236,7 @@ public:
             }
             const auto t_kf = clk::now();
             auto cur = std::make_shared<Keyframe>(stamp, tracklets, camera_, prior, Keyframe::FixationStatus::None, ground_plane);
+            cur->freezeMeasurements();  // (as above: built once per keyframe, kept for its life in the window)
             stats_.sec_keyframe += std::chrono::duration<double>(clk::now() - t_kf).count();
             if (!external_prior) {  // a prior without scale is always refined against the fixed landmarks of the last
                                     // selection (:200-211; before the first solve() that selection is empty)

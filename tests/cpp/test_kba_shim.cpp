@@ -861,8 +861,10 @@ static void test_kitti_io() {
     CHECK(err.ate_max > 9. && err.ate_rmse > 3. && err.ate_rmse < err.ate_max);
 }
 
-// Keyframe::measurementTable(): the rows of measurements_ in map order with pointers INTO the map; follows insertions / erasures that
-// change the landmark count or an end id, values changed in place, copies and moves of the keyframe, and measurementsChanged().
+// Keyframe::measurementTable(): the rows of measurements_ in map order with pointers INTO the map.  measurements_ is a public member
+// a caller may edit between two calls: the table is only trusted inside one public call (MeasurementTableScope) or for a keyframe
+// whose owner froze it; everywhere else every use rebuilds it.  Edits the old (count, first id, last id) check could not see - an
+// interior erase + insert, a second camera added to existing ids - must be followed without any notification.
 static void test_measurement_table() {
     auto cam0 = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
     auto cam1 = std::make_shared<Camera>(600, Vector2d(300, 200), EigenPose::Identity());
@@ -878,13 +880,17 @@ static void test_measurement_table() {
     Keyframe kf(7, ts, std::map<CameraId, Camera::Ptr>{{0, cam0}, {1, cam1}}, seen, EigenPose::Identity());
     auto agrees = [](const Keyframe& k) {
         const auto& rows = k.measurementTable();
-        size_t i = 0;
-        for (const auto& lm : k.measurements_)
+        const auto& ids = k.measuredIds();
+        size_t i = 0, n = 0;
+        for (const auto& lm : k.measurements_) {
+            if (n >= ids.size() || ids[n] != lm.first) return false;
+            ++n;
             for (const auto& cm : lm.second) {
                 if (i >= rows.size() || rows[i].id != lm.first || rows[i].cam != cm.first || rows[i].m != &cm.second) return false;
                 ++i;
             }
-        return i == rows.size();
+        }
+        return i == rows.size() && n == ids.size();
     };
     CHECK(kf.measurementTable().size() == 5 && agrees(kf));
     kf.getMeasurement(5, 1).d = 12.f;  // a value changed in place is seen through the row's pointer
@@ -900,13 +906,87 @@ static void test_measurement_table() {
     CHECK(agrees(assigned));
     Keyframe moved(std::move(copy));  // a moved map keeps its nodes
     CHECK(agrees(moved) && moved.measurementTable().size() == 5);
-    // the one change the check cannot see by itself: same count, same ends
+    // same count, same first and last id - WITHOUT telling the keyframe: interior erase + insert ...
     kf.measurements_.erase(5);
     kf.measurements_[6][0] = FeaturePoint(3.f, 4.f);
-    kf.measurementsChanged();
     CHECK(kf.measurementTable().size() == 4 && agrees(kf));
+    // ... a second camera for ids that exist (the reference's stereo pattern, src/keyframe.cpp:43-59), through the public member
+    kf.measurements_[6][1] = FeaturePoint(5.f, 6.f);
+    CHECK(kf.measurementTable().size() == 5 && agrees(kf));
+    kf.assignMeasurements(ts, CameraId(1));  // ... and through assignMeasurements a second time
+    CHECK(agrees(kf) && kf.hasMeasurement(2, 1) && kf.hasMeasurement(40, 1));
+    // inner erase: the rows must not keep a pointer to the freed Measurement (run under -fsanitize=address: tests/test_kba_shim.py)
+    kf.measurements_[6].erase(0);
+    CHECK(agrees(kf) && kf.measurementTable().back().m->u == kf.measurements_.rbegin()->second.rbegin()->second.u);
+    {   // inside one public call the table is built once ...
+        Keyframe::MeasurementTableScope scope;
+        const auto* first = kf.measurementTable().data();
+        CHECK(kf.measurementTable().data() == first);
+        Keyframe::MeasurementTableScope nested;
+        CHECK(kf.measurementTable().data() == first);
+    }
+    {   // ... and a later call does not trust it: an edit between two calls is seen
+        kf.measurements_[3][0] = FeaturePoint(7.f, 8.f);
+        Keyframe::MeasurementTableScope scope;
+        CHECK(agrees(kf) && kf.measuredIds().size() == kf.measurements_.size());
+    }
+    // a frozen keyframe keeps its table across calls (the owner's promise); assignMeasurements() takes the promise back
+    Keyframe frozen(kf);
+    frozen.freezeMeasurements();
+    const auto* rows0 = frozen.measurementTable().data();
+    {
+        Keyframe::MeasurementTableScope scope;
+        CHECK(frozen.measurementTable().data() == rows0 && frozen.measurementsFrozen());
+    }
+    Keyframe frozen_copy(frozen);
+    CHECK(frozen_copy.measurementsFrozen() && agrees(frozen_copy));
+    frozen.assignMeasurements(ts, CameraId(0));
+    CHECK(!frozen.measurementsFrozen() && agrees(frozen));
     Keyframe empty;
-    CHECK(empty.measurementTable().empty());
+    CHECK(empty.measurementTable().empty() && empty.measuredIds().empty());
+}
+
+// Two solve() calls with the window's measurements edited in between through the PUBLIC member, no notification: in one keyframe an
+// interior id is erased and another inserted (count and end ids unchanged), and a second keyframe gets a measurement removed from an
+// inner map.  The second solve must build exactly the residual blocks of the edited maps (and, under -fsanitize=address, touch no
+// freed node: the rows of the first solve's table pointed into the erased ones).
+static void test_solve_follows_measurement_edits() {
+    const double f = 600.;
+    const Vector2d pp(200., 100.);
+    const std::vector<TimestampNSec> stamps{0, 1, 2, 3, 4};
+    auto poses_gt = getPoses(0., std::make_tuple(0., 0., 0.), stamps);
+    std::vector<Vector3d> lms;
+    const std::vector<Vector3d> base{{10., 3., 5.5}, {11., 1., 6.5}, {14., -5., 6.}, {9., 1., 5.}, {16., -1., 4.}};  // (the points of evaluate_ba)
+    for (int i = 0; i < 12; ++i) lms.push_back(base[i % 5] + Vector3d(0.6 * (i / 5), -0.4 * (i / 5), 0.3 * (i / 5)));
+    std::map<CameraId, Camera::Ptr> cams{{0, std::make_shared<Camera>(f, pp, camera_extrinsic_solve())}};
+    auto ts = makeTracklets(poses_gt, lms, cams, 0.05, 0.05, true, {}, stamps);
+    auto count_meas = [](const BundleAdjusterKeyframes& ba) {  // measurements of the SELECTED landmarks in the active keyframes
+        size_t n = 0;
+        for (const auto& kf : ba.keyframes_)
+            for (const auto& m : kf.second->measurements_)
+                if (ba.selected_landmark_ids_.count(m.first)) n += m.second.size();
+        return n;
+    };
+    BundleAdjusterKeyframes a;
+    a.set_solver_time(20.);
+    for (int i = 0; i < 5; ++i) {
+        Keyframe kf(stamps[i], ts, cams.at(0), poses_gt.at(stamps[i]), i == 0 ? Keyframe::FixationStatus::Pose : i == 1 ? Keyframe::FixationStatus::Scale : Keyframe::FixationStatus::None);
+        if (i == 2) kf.measurements_.erase(6);  // keyframe 2 does not see landmark 6 at first
+        a.push(kf);
+    }
+    a.solve();
+    CHECK((size_t)a.last_report_.n_repr_blocks == count_meas(a));
+    const size_t n_first = count_meas(a);
+    CHECK(a.selected_landmark_ids_.count(3) && a.selected_landmark_ids_.count(6) && a.selected_landmark_ids_.count(7));
+    Keyframe& k2 = *a.keyframes_.at(stamps[2]);
+    const Measurement m6 = a.keyframes_.at(stamps[1])->getMeasurement(6, 0);
+    k2.measurements_.erase(3);      // interior erase ...
+    k2.measurements_[6][0] = m6;    // ... interior insert: 11 landmarks, first id 0, last id 11 - as before
+    a.keyframes_.at(stamps[3])->measurements_.at(7).erase(0);  // an inner map emptied: a row of the old table dangles
+    a.keyframes_.at(stamps[3])->measurements_.erase(7);
+    a.solve();
+    CHECK((size_t)a.last_report_.n_repr_blocks == count_meas(a) && count_meas(a) + 1 == n_first);
+    for (const auto& kf : a.keyframes_) CHECK(kf.second->getEigenPose().isApprox(poses_gt.at(kf.first), 2e-2));
 }
 
 int main(int argc, char** argv) {
@@ -922,6 +1002,7 @@ int main(int argc, char** argv) {
                  {"LandmarkSelector.voxel", test_landmark_selector_voxel},
                  {"LandmarkSelector.schemes_equal_plain_statements", test_selector_schemes_equal_their_plain_statements},
                  {"Keyframe.measurementTable", test_measurement_table},
+                 {"BundleAdjusterKeyframes.solveFollowsMeasurementEdits", test_solve_follows_measurement_edits},
                  {"FivePoint.motion_prior", test_five_point_motion},
                  {"KeyFrameBundleAdjustment.solve", test_solve},
                  {"KeyFrameBundleAdjustment.solve_depth", test_solve_depth},

@@ -104,6 +104,17 @@ def build_shim_tests(gpu=False, oracle=False):
     return SHIM_TEST_GPU
 
 
+def build_shim_tests_asan():
+    """The shim tests, the shim and the emulated C-ABI in ONE executable under -fsanitize=address: the measurement tables of
+    limo_amd/kba/keyframe.hpp hold pointers into a public std::map a caller may edit between two calls."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    out = os.path.join(_HERE, "cpp", "_build", "test_kba_shim_emu_asan")
+    csrc = os.path.join(_HERE, "..", "limo_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-ffp-contract=off", "-std=c++17", "-pthread", "-DKBA_EMU_EXPORT_ABI",
+                           "-o", out, os.path.join(_HERE, "cpp", "test_kba_shim.cpp")] + SHIM_SRC + _SRC + [os.path.join(csrc, "host_misc.cpp")])
+    return out
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 

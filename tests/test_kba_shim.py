@@ -27,6 +27,17 @@ def test_reference_scenarios_with_the_oracle_behind_the_shim():
     run(emu_ffi.build_shim_tests(oracle=True))
 
 
+def test_reference_scenarios_under_address_sanitizer():
+    """The same scenarios under -fsanitize=address - among them Keyframe.measurementTable and
+    BundleAdjusterKeyframes.solveFollowsMeasurementEdits, which erase and insert measurements through the public member between
+    two uses of a keyframe: a table that outlived such an edit would read freed map nodes."""
+    exe = emu_ffi.build_shim_tests_asan()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    print(r.stdout[-3000:])
+    print(r.stderr[-3000:])
+    assert r.returncode == 0 and "0 failed tests" in r.stdout and "AddressSanitizer" not in r.stderr
+
+
 @pytest.mark.gpu
 def test_reference_scenarios_on_gpu():
     run(emu_ffi.build_shim_tests(gpu=True))
