@@ -158,8 +158,11 @@ typedef struct limo_ba_batch limo_ba_batch;
 /* --- context ------------------------------------------------------------------------------------ */
 int limo_abi_version(void);
 /* A context = one GPU + one stream + the scratch it reuses between calls.  Not thread-safe: one context per host
- * thread (several contexts may share a GPU).  Device blocks and pinned staging buffers released by finished calls
- * (<= 32 MB each, a few per size class) stay with the context for the next call and are freed by limo_ctx_destroy. */
+ * thread (several contexts may share a GPU).  Device blocks and pinned staging buffers released by finished calls stay with
+ * the context for the next call and are freed by limo_ctx_destroy: up to 32 MB a few per power-of-two size class, larger ones
+ * (the arena of a big batch) one per 64 MB class and at most 16 GB altogether (environment KBA_POOL_LARGE_MB sets that cap, 0
+ * keeps none).  Idle blocks never cost an allocation: when the device is out of memory they are released, largest first, and
+ * the allocation is tried again. */
 int limo_ctx_create(int device, limo_ctx** out);
 void limo_ctx_destroy(limo_ctx* ctx);
 /* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own. */

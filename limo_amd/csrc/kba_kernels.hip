@@ -1692,7 +1692,7 @@ constexpr int kCoopRedStride = 64 * 64;  // nf_pad <= 64 for fast-class windows 
 // constant clock ABORTS the launch: every workgroup of the window returns, the pinned flag tells the host, and the host
 // restores the batch's initial state and solves it through the launch sequence instead (limo_ba_batch_solve) - a timeout is
 // never an error the caller sees.  (That clock keeps running while a wave is preempted - a GPU shared with another process,
-// a debugger or a profiler serialising dispatches - so a healthy launch CAN time out; the default is 2 s, KBA_COOP_TIMEOUT_MS
+// a debugger or a profiler serialising dispatches - so a healthy launch CAN time out; the default is 50 ms, KBA_COOP_TIMEOUT_MS
 // sets it.)  `abort_word` is shared by the window's main barrier and the barrier of its Schur workgroups: whoever gives up
 // first releases everybody at their next poll.
 __device__ __forceinline__ bool coop_sync(int32_t* bar, int32_t* abort_word, int G, int& gen, int32_t* abort_host, long long timeout) {

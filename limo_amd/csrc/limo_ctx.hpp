@@ -19,6 +19,7 @@ struct limo_ctx {
     int comm_rank = 0, comm_world = 1;
     long long exchange_stats[3] = {0, 0, 0};  // last landmark-sharded solve: exchange steps, bytes per rank, LM iterations
     long long coop_fallbacks = 0;           // one-launch solves whose barrier timed out and that were redone as a launch sequence
+    int coop_strikes = 0;                   // ... in a row: after three the context stops taking the one-launch path (something shares the GPU)
     // Device blocks released by finished batches, kept for the next one (size class = power of two): a single-window
     // call (limo_ba_solve, limo_ba_adjust_pose_only) would otherwise spend more time in hipMalloc / hipFree than in
     // its kernels.  At most kPoolPerClass blocks per class are kept; everything is freed with the context.
@@ -54,14 +55,37 @@ struct limo_ctx {
             if (bytes > kPoolMaxBlock) pooled_large -= c;
             return hipSuccess;
         }
-        return hipMalloc(p, c);
+        hipError_t e = hipMalloc(p, c);
+        // Out of memory with idle blocks in the pool (a caller whose batches vary in size leaves one multi-GB block per 64 MB
+        // class behind; several contexts may share the GPU): give the idle blocks back, largest first, and try again - the
+        // pool may cost time, never an allocation that would have succeeded without it.
+        while (e == hipErrorOutOfMemory && trim_largest()) {
+            (void)hipGetLastError();
+            e = hipMalloc(p, c);
+        }
+        return e;
+    }
+    // frees the largest idle device block of the pool; false when the pool holds none
+    bool trim_largest() {
+        for (auto it = pool.rbegin(); it != pool.rend(); ++it) {
+            if (it->second.empty()) continue;
+            (void)hipFree(it->second.back());
+            it->second.pop_back();
+            if (it->first > kPoolMaxBlock) pooled_large -= it->first;
+            return true;
+        }
+        return false;
+    }
+    size_t pooled_large_cap() const {  // KBA_POOL_LARGE_MB: cap of the idle large blocks of a context (default 16 GB; 0 keeps none)
+        static const size_t cap = std::getenv("KBA_POOL_LARGE_MB") ? (size_t)std::strtoull(std::getenv("KBA_POOL_LARGE_MB"), nullptr, 10) << 20 : kPoolLargeBytes;
+        return cap;
     }
     void pool_free(void* p, size_t bytes) {
         const size_t c = size_class(bytes);
         auto& v = pool[c];
         static const bool no_reuse = std::getenv("KBA_NO_POOL") != nullptr;
         const bool large = bytes > kPoolMaxBlock;
-        if (!no_reuse && (large ? (v.empty() && pooled_large + c <= kPoolLargeBytes) : (int)v.size() < kPoolPerClass)) {
+        if (!no_reuse && (large ? (v.empty() && pooled_large + c <= pooled_large_cap()) : (int)v.size() < kPoolPerClass)) {
             v.push_back(p);
             if (large) pooled_large += c;
         } else {

@@ -375,7 +375,9 @@ struct limo_ba_batch : Executor {
         return LIMO_OK;
     }
 
+    bool pristine = true;  // the device state is the state of create / reset: what a recovered barrier timeout of the one-launch solve restores
     int reset_state() {
+        pristine = true;
         HIP_TRY(ctx, hipMemcpyAsync(bv.st, st0.data(), sizeof(WinState) * st0.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.pose, d_pose0, sizeof(double) * 7 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(bv.pdir, d_pdir0, sizeof(double) * 3 * P.TK, hipMemcpyDeviceToDevice, ctx->stream));
@@ -582,6 +584,7 @@ struct limo_ba_batch : Executor {
     void solve_init(int max_iter, int select) override {
         it_no = 0;
         first_lin = true;  // the next linearisation defines the Jacobi scaling (WinState::compute_scale)
+        assemble_pending = false;  // (a solve that ended right behind a linearisation leaves nothing for the next one)
         full_lists();
         hipLaunchKernelGGL(k_solve_init, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv, c, max_iter, select);
         LAUNCH_CHECK("k_solve_init");
@@ -668,6 +671,13 @@ struct limo_ba_batch : Executor {
     }
 
     void expire(int) override {
+        if (assemble_pending) {  // sharded: the camera assembly of the last linearisation was deferred behind the Schur slabs - the
+                                 // time cap ends the solve before them: assemble now (exchange of the linearisation sums only), so
+                                 // that the windows' cost is the cost of the point they stop at
+            assemble_pending = false;
+            exchange(1);
+            assemble(it_no - 1);
+        }
         hipLaunchKernelGGL(k_expire, dim3(cdiv(P.n_win, 256)), dim3(256), 0, ctx->stream, bv);
         LAUNCH_CHECK("k_expire");
     }
@@ -1009,7 +1019,9 @@ struct limo_ba_batch : Executor {
         cp.cap_ticks = opts.max_solver_time_sec > 0.0 ? std::max(1ll, (long long)(opts.max_solver_time_sec * 1e8)) : 0ll;
         // barrier timeout in ticks of the 100 MHz constant clock (read per call; KBA_COOP_TIMEOUT_MS=0: give up at the first wait -
         // how the tests reach the recovery path of limo_ba_batch_solve)
-        cp.timeout_ticks = 200000000ll;
+        // default 50 ms (the whole call is ~5 ms; the longest phase between two barriers - the quantile trimming - well under 1 ms):
+        // a barrier that is not met by then is lost, and the caller of a 10 Hz pipeline should not wait seconds to learn it
+        cp.timeout_ticks = 5000000ll;
         if (const char* e = std::getenv("KBA_COOP_TIMEOUT_MS")) cp.timeout_ticks = std::max(0ll, (long long)(std::atof(e) * 1e5));
         cp.bar = d_coop_bar;
         cp.abort_host = d_h_active + 8;
@@ -1283,22 +1295,28 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     };
     if (one_launch && b->wg_solve_applies())
         b->solve_wg();
-    else if (one_launch && b->coop_solve_applies() && b->solve_coop())
+    // (the cooperative solve only from the pristine state - its timeout recovery restores THAT state, a warm re-solve would lose the
+    // first solve's result - and not any more in a context whose launches keep timing out: something shares the GPU)
+    else if (one_launch && b->pristine && ctx->coop_strikes < 3 && b->coop_solve_applies() && b->solve_coop())
         ;
     else
         launch_sequence();
+    b->pristine = false;
     if (b->coop_launched) {
         // A device-wide barrier of k_solve_coop that was not met in time aborts the launch (kba_kernels.hip:coop_sync) and leaves
         // poses, landmarks and LM state half-updated.  That is recoverable: the batch's initial state is restored (the pristine
         // copies limo_ba_batch_reset uses) and the same windows go through the launch sequence - same results, bit for bit.
         b->coop_launched = false;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (b->h_active[8] == 0) ctx->coop_strikes = 0;
         if (b->h_active[8] != 0) {
             b->h_active[8] = 0;
             ++ctx->coop_fallbacks;
+            ++ctx->coop_strikes;
             if (b->reset_state() != LIMO_OK) return LIMO_ERR_RUNTIME;
             b->rc = LIMO_OK;
             launch_sequence();
+            b->pristine = false;
         }
     }
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"

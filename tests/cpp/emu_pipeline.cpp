@@ -139,6 +139,7 @@ struct EmuBatch : Executor {
             lm_solve_init(s, sel, max_iter, c);
         }
         first_lin = true;  // the next linearisation defines the Jacobi scaling (WinState::compute_scale)
+        assemble_pending = false;
     }
 
     // camera assembly + the LM decision at the linearisation point (k_cam_assemble)
@@ -223,6 +224,11 @@ struct EmuBatch : Executor {
     }
 
     void expire(int) override {
+        if (assemble_pending) {  // (as limo_hip.hip: the deferred camera assembly of the last linearisation)
+            assemble_pending = false;
+            exchange(1);
+            assemble();
+        }
         for (int w = 0; w < bv.n_win; ++w)
             if (bv.st[w].active) lm_terminate(bv.st[w], LIMO_NO_CONVERGENCE);
     }
