@@ -268,12 +268,14 @@ void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
     using MeasFinder = SortedFinder<decltype(kf.measurements_)>;
     std::vector<MeasFinder> finders;  // one per active keyframe, in the order of active_views' keyframes
     std::vector<std::pair<size_t, size_t>> views_of_kf;  // [first, last) of active_views
+    std::vector<const Keyframe*> kf_of_finder;            // (a keyframe without cameras has no view to take it from)
     for (const auto& id : active_keyframe_ids_) {
         const Keyframe& k = *keyframes_.at(id);
         const size_t first = active_views.size();
         views_of(k, active_views);
         views_of_kf.push_back({first, active_views.size()});
         finders.emplace_back(k.measurements_);
+        kf_of_finder.push_back(&k);
     }
     SortedFinder<decltype(landmarks_)> known(landmarks_);
     for (const auto& m : kf.measurements_) {
@@ -287,7 +289,7 @@ void BundleAdjusterKeyframes::push(Keyframe&& kf_in) {
                     if (v.cam == cam_meas.first) rays.push_back(ray_of(v, cam_meas.second));
         } else {  // collectRays(id): every active keyframe / camera that sees the landmark (getMeasurementsAndPoses, :125-159)
             for (size_t k = 0; k < finders.size(); ++k) {
-                const Keyframe& ak = *active_views[views_of_kf[k].first].kf;
+                const Keyframe& ak = *kf_of_finder[k];
                 const auto it = finders[k].find(m.first);
                 if (it == ak.measurements_.cend()) continue;
                 for (size_t vi = views_of_kf[k].first; vi < views_of_kf[k].second; ++vi) {

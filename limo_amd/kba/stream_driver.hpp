@@ -383,10 +383,10 @@ private:
         if (!worker_.joinable()) return;
         std::unique_lock<std::mutex> lk(job_mutex_);
         job_cv_.wait(lk, [this] { return job_state_ == JobState::Idle; });
-        if (job_ts_) {
-            ahead_valid_ = !job_ts_->stamps.empty();
-            ahead_stamp_ = ahead_valid_ ? job_ts_->stamps.front() : 0;
-            ahead_tracks_ = job_ts_->tracks.size();
+        if (job_ts_) {  // (the frame's identity was taken by the thread when it STARTED the job: the caller's message may be gone by now)
+            ahead_valid_ = job_has_stamp_;
+            ahead_stamp_ = job_stamp_;
+            ahead_tracks_ = job_tracks_;
             job_ts_ = nullptr;
         }
         if (job_error_) {
@@ -405,6 +405,9 @@ private:
             const Tracklets* ts = job_ts_;
             const float* cloud = job_cloud_;
             const size_t n_pts = job_n_pts_;
+            job_has_stamp_ = !ts->stamps.empty();
+            job_stamp_ = job_has_stamp_ ? ts->stamps.front() : 0;
+            job_tracks_ = ts->tracks.size();
             lk.unlock();
             std::exception_ptr err;
             const auto t0 = std::chrono::steady_clock::now();
@@ -440,7 +443,11 @@ private:
     // other core's cache, which cost as much as the thread saved.)
     void computeDepths(const Tracklets& ts, const float* cloud, size_t n_pts, std::vector<float>& out) {
         const size_t n = ts.tracks.size();
-        stats_.features += (int)n;
+        // A frame may come here twice (announced to the depth thread, then handed to process() with another message for the same
+        // stamp, or announced and never processed): the statistics count a stamp once and the per-track history REPLACES the
+        // entry of a stamp it already holds instead of pushing a second one.
+        const bool counted = counted_any_ && !ts.stamps.empty() && counted_stamp_ == ts.stamps.front();
+        if (!counted) stats_.features += (int)n;
         const bool from_sweep = p_.assign_depth && cloud && n_pts && n;
         if (from_sweep) {
             depth_.assign(n, -1.f);
@@ -469,10 +476,14 @@ private:
             const float d0 = (from_sweep && tr.feature_points[0].d < 0.f) ? depth_[i] : tr.feature_points[0].d;  // (a depth the caller knows stays)
             out.push_back(d0);
             History& h = history_[tr.id];
-            h.stamp[h.head] = stamp;
-            h.d[h.head] = d0;
-            h.head = (h.head + 1) & (History::kDepth - 1);
-            h.n = std::min<int>(History::kDepth, h.n + 1);
+            if (h.n > 0 && h.stamp[(h.head - 1) & (History::kDepth - 1)] == stamp) {
+                h.d[(h.head - 1) & (History::kDepth - 1)] = d0;
+            } else {
+                h.stamp[h.head] = stamp;
+                h.d[h.head] = d0;
+                h.head = (h.head + 1) & (History::kDepth - 1);
+                h.n = std::min<int>(History::kDepth, h.n + 1);
+            }
             for (size_t k = 1; k < tr.feature_points.size(); ++k) {
                 float dk = tr.feature_points[k].d;
                 if (dk < 0.f && k < ts.stamps.size()) {
@@ -490,8 +501,10 @@ private:
                 }
                 out.push_back(dk);
             }
-            stats_.features_with_depth += d0 > 0.f;
+            if (!counted) stats_.features_with_depth += d0 > 0.f;
         }
+        counted_any_ = true;
+        counted_stamp_ = stamp;
         stats_.sec_depth_history += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_hist).count();
         if (++frames_since_gc_ >= 64) {  // forget tracks that ended
             frames_since_gc_ = 0;
@@ -531,6 +544,11 @@ private:
     std::condition_variable job_cv_;
     JobState job_state_ = JobState::Idle;
     const Tracklets* job_ts_ = nullptr;
+    bool job_has_stamp_ = false;  // identity of the job's frame, read from the message when the job starts
+    TimestampNSec job_stamp_ = 0;
+    size_t job_tracks_ = 0;
+    TimestampNSec counted_stamp_ = 0;  // the last frame whose features went into stats_ (computeDepths is idempotent per stamp)
+    bool counted_any_ = false;
     const float* job_cloud_ = nullptr;
     size_t job_n_pts_ = 0;
     std::exception_ptr job_error_;
