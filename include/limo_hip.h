@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define LIMO_ABI_VERSION 4 /* 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms; 3: limo_ctx_coop_fallbacks; 4: limo_depth_estimate_begin / _end */
+#define LIMO_ABI_VERSION 5 /* 5: limo_ctx_comm_init_host; 2: limo_ba_evaluate_rows, limo_ctx_exchange_stats, limo_depth_last_ground_plane, limo_depth_set_timing, limo_depth_last_kernel_ms; 3: limo_ctx_coop_fallbacks; 4: limo_depth_estimate_begin / _end */
 
 /* Keyframe::FixationStatus, keyframe.hpp:30 */
 enum limo_fixation { LIMO_FIX_POSE = 0, LIMO_FIX_SCALE = 1, LIMO_FIX_NONE = 2 };
@@ -229,13 +229,20 @@ int limo_ba_batch_kernel_time(limo_ba_batch* batch, int kernel, double* ms, int6
 #define LIMO_COMM_ID_BYTES 128
 int limo_comm_unique_id(unsigned char id[LIMO_COMM_ID_BYTES]);            /* rank 0; broadcast the bytes to all ranks */
 int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES], int rank, int world);
+/* The same exchange through a transport of the CALLER instead of RCCL: every exchange step is staged through page-locked host
+ * memory and handed to `fn` - kind 0: all-gather (send = count doubles of this rank, recv = world * count doubles in rank order),
+ * kind 1: sum over the ranks (send = recv = count doubles).  For ranks that cannot form an RCCL communicator - two processes
+ * sharing ONE GPU (a device may appear once per communicator), a host-side fabric - and for tests of the multi-rank branch on a
+ * one-GPU box.  fn = NULL removes the transport; limo_ctx_comm_init replaces it. */
+typedef void (*limo_exchange_fn)(const double* send, double* recv, long long count, int kind, void* user);
+int limo_ctx_comm_init_host(limo_ctx* ctx, limo_exchange_fn fn, void* user, int rank, int world);
 int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
                           limo_ba_report* report);
 /* Exchange accounting of the last limo_ba_solve_sharded on this context: stats3 = (exchange steps = collective calls with a
  * communicator, counted per local shard; bytes this rank's shards put into them; LM iterations of the solve). */
 int limo_ctx_exchange_stats(limo_ctx* ctx, int64_t* stats3);
 /* How many one-launch solves (k_solve_coop behind limo_ba_solve / small batches) on this context gave up at a device-wide
- * barrier and were redone as a launch sequence.  A barrier waits at most KBA_COOP_TIMEOUT_MS (default 2000) of the GPU's
+ * barrier and were redone as a launch sequence.  A barrier waits at most KBA_COOP_TIMEOUT_MS (default 50) of the GPU's
  * constant clock, which keeps running while a wave is preempted (shared GPU, debugger, profiler); the redo starts from the
  * batch's initial state and gives the same results - the caller never sees an error, this counter is how it can tell. */
 int64_t limo_ctx_coop_fallbacks(const limo_ctx* ctx);

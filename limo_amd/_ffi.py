@@ -190,7 +190,10 @@ class DepthParams(C.Structure):  # struct limo_depth_params
     ]
 
 
-ABI_VERSION = 4  # LIMO_ABI_VERSION of include/limo_hip.h
+# limo_exchange_fn: (send, recv, count, kind, user) - kind 0 all-gather, 1 sum over the ranks
+EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_longlong, C.c_int, C.c_void_p)
+
+ABI_VERSION = 5  # LIMO_ABI_VERSION of include/limo_hip.h
 
 # every symbol include/limo_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -213,6 +216,7 @@ ABI_SYMBOLS = [
     "limo_ba_batch_kernel_time",
     "limo_comm_unique_id",
     "limo_ctx_comm_init",
+    "limo_ctx_comm_init_host",
     "limo_ba_solve_sharded",
     "limo_ctx_exchange_stats",
     "limo_ctx_coop_fallbacks",
@@ -277,6 +281,7 @@ def load():
     lib.limo_ba_batch_kernel_time.argtypes = [vp, C.c_int, c_double_p, c_int64_p]
     lib.limo_comm_unique_id.argtypes = [C.c_char_p]
     lib.limo_ctx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.limo_ctx_comm_init_host.argtypes = [vp, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]
     lib.limo_ba_solve_sharded.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int, C.POINTER(BaReport)]
     lib.limo_ba_evaluate_batch_time.argtypes = [vp, C.c_int32, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int32, C.POINTER(C.c_double)]
     lib.limo_ba_evaluate.argtypes = [

@@ -83,6 +83,21 @@ class Context:
     def comm_init(self, unique_id, rank, world):
         _check(self.lib.limo_ctx_comm_init(self.ptr, unique_id, int(rank), int(world)), self.ptr, "limo_ctx_comm_init")
 
+    def comm_init_host(self, rank, world, allgather, allreduce):
+        """limo_ctx_comm_init_host: the exchange steps of solve_sharded through the caller's transport, staged in host memory.
+        allgather(send[count], recv[world, count]) / allreduce(send[count], recv[count]) get numpy views of the staging buffers."""
+        import numpy as np
+
+        def _cb(send, recv, count, kind, _user):
+            s = np.ctypeslib.as_array(send, shape=(count,))
+            if kind == 0:
+                allgather(s, np.ctypeslib.as_array(recv, shape=(world, count)))
+            else:
+                allreduce(s, np.ctypeslib.as_array(recv, shape=(count,)))
+
+        self._xfn = _ffi.EXCHANGE_FN(_cb)  # (kept alive with the context)
+        _check(self.lib.limo_ctx_comm_init_host(self.ptr, self._xfn, None, int(rank), int(world)), self.ptr, "limo_ctx_comm_init_host")
+
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
         _check(self.lib.limo_comm_unique_id(buf), self.ptr, "limo_comm_unique_id")

@@ -17,6 +17,14 @@ struct limo_ctx {
     void (*depth_ws_free)(void*) = nullptr;
     void* comm = nullptr;                   // ncclComm_t of a landmark-sharded solve (limo_ctx_comm_init), else null
     int comm_rank = 0, comm_world = 1;
+    // ... or a transport of the caller's (limo_ctx_comm_init_host): the exchange steps are staged through pinned host memory and
+    // handed to this callback - how two processes that share ONE GPU (RCCL refuses a device twice in a communicator) or a host-side
+    // fabric run the landmark-sharded solve with world > 1
+    void (*xfn)(const double* send, double* recv, long long count, int kind, void* user) = nullptr;
+    void* xuser = nullptr;
+    double* xhost = nullptr;  // pinned staging: [1 + world][count]
+    size_t xhost_cap = 0;
+    bool has_transport() const { return comm != nullptr || xfn != nullptr; }
     long long exchange_stats[3] = {0, 0, 0};  // last landmark-sharded solve: exchange steps, bytes per rank, LM iterations
     long long coop_fallbacks = 0;           // one-launch solves whose barrier timed out and that were redone as a launch sequence
     int coop_strikes = 0;                   // ... in a row: after three the context stops taking the one-launch path (something shares the GPU)
@@ -117,6 +125,9 @@ struct limo_ctx {
             for (void* p : kv.second) (void)hipFree(p);
         pool.clear();
         pooled_large = 0;
+        if (xhost) (void)hipHostFree(xhost);
+        xhost = nullptr;
+        xhost_cap = 0;
         if (staging) (void)hipHostFree(staging);
         staging = nullptr;
         staging_cap = 0;

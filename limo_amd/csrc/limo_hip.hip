@@ -436,10 +436,14 @@ struct limo_ba_batch : Executor {
                                    local_shards[i], (int64_t)off, (int64_t)count);
                 LAUNCH_CHECK("k_unpack");
             } else {
-                ncclResult_t r = ncclAllGather(blocks[i] + off, d_gather, count, ncclDouble, (ncclComm_t)ctx->comm, s);
-                if (r != ncclSuccess && rc == LIMO_OK) {
-                    rc = LIMO_ERR_RUNTIME;
-                    ctx->err = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+                if (ctx->xfn) {
+                    host_exchange(blocks[i] + off, d_gather, count, 0);
+                } else {
+                    ncclResult_t r = ncclAllGather(blocks[i] + off, d_gather, count, ncclDouble, (ncclComm_t)ctx->comm, s);
+                    if (r != ncclSuccess && rc == LIMO_OK) {
+                        rc = LIMO_ERR_RUNTIME;
+                        ctx->err = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+                    }
                 }
                 for (int q = 0; q < ctx->comm_world; ++q) {
                     hipLaunchKernelGGL(k_unpack, dim3(cdiv((int64_t)count, 256)), dim3(256), 0, s, xl, (const WinDesc*)d_win_orig,
@@ -451,6 +455,28 @@ struct limo_ba_batch : Executor {
             exchange_bytes += (int64_t)count * (int64_t)sizeof(double);
         }
     }
+    // The caller's transport (limo_ctx_comm_init_host): `count` doubles at `src` (device) go to the host, through the callback
+    // (kind 0: all-gather into world * count doubles, rank order; kind 1: sum over the ranks into count doubles) and back to `dst`.
+    void host_exchange(const double* src, double* dst, size_t count, int kind) {
+        hipStream_t s = ctx->stream;
+        const size_t n_out = kind == 0 ? (size_t)ctx->comm_world * count : count, need = count + n_out;
+        if (ctx->xhost_cap < need) {
+            if (ctx->xhost) (void)hipHostFree(ctx->xhost);
+            ctx->xhost = nullptr;
+            ctx->xhost_cap = 0;
+            if (hipHostMalloc((void**)&ctx->xhost, sizeof(double) * need) != hipSuccess) {
+                note(hipErrorOutOfMemory, "hipHostMalloc(exchange staging)");
+                return;
+            }
+            ctx->xhost_cap = need;
+        }
+        note(hipMemcpyAsync(ctx->xhost, src, sizeof(double) * count, hipMemcpyDeviceToHost, s), "exchange: device -> host");
+        note(hipStreamSynchronize(s), "exchange: sync");
+        if (rc != LIMO_OK) return;
+        ctx->xfn(ctx->xhost, ctx->xhost + count, (long long)count, kind, ctx->xuser);
+        note(hipMemcpyAsync(dst, ctx->xhost + count, sizeof(double) * n_out, hipMemcpyHostToDevice, s), "exchange: host -> device");
+        note(hipStreamSynchronize(s), "exchange: sync");  // (the staging buffer is reused by the next step)
+    }
     // Trimming round: per-landmark residual maxima, one owner per entry and zero elsewhere - an exact sum in any order.
     void exchange_trim() {
         if (shard_P == 1) return;
@@ -460,7 +486,9 @@ struct limo_ba_batch : Executor {
         for (size_t i = 0; i < pv.size(); ++i) sp.p[i] = trims[1 + i];
         hipLaunchKernelGGL(k_sum_shards<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, trims[0], sp, (int)pv.size(), n);
         LAUNCH_CHECK("k_sum_shards");
-        if (!shard_virtual) {
+        if (!shard_virtual && ctx->xfn) {
+            host_exchange(trims[0], trims[0], (size_t)n, 1);
+        } else if (!shard_virtual) {
             ncclResult_t r = ncclAllReduce(trims[0], trims[0], (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
             if (r != ncclSuccess && rc == LIMO_OK) {
                 rc = LIMO_ERR_RUNTIME;
@@ -1322,10 +1350,15 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
     if (b->shard_P > 1 && !b->shard_virtual) {  // every rank ends with every landmark: sum of "owned, else zero"
         hipLaunchKernelGGL(k_lm_owned, dim3(cdiv(b->P.TL, 256)), dim3(256), 0, ctx->stream, b->bv, b->d_lm_tmp, b->shard_rank, b->shard_P,
                            ctx->comm_world);
-        ncclResult_t r = ncclAllReduce(b->d_lm_tmp, b->bv.lm, (size_t)3 * b->P.TL, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
-        if (r != ncclSuccess) {
-            ctx->err = std::string("ncclAllReduce(landmarks): ") + ncclGetErrorString(r);
-            return LIMO_ERR_RUNTIME;
+        if (ctx->xfn) {
+            b->host_exchange(b->d_lm_tmp, b->bv.lm, (size_t)3 * b->P.TL, 1);
+            if (b->rc != LIMO_OK) return b->rc;
+        } else {
+            ncclResult_t r = ncclAllReduce(b->d_lm_tmp, b->bv.lm, (size_t)3 * b->P.TL, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+            if (r != ncclSuccess) {
+                ctx->err = std::string("ncclAllReduce(landmarks): ") + ncclGetErrorString(r);
+                return LIMO_ERR_RUNTIME;
+            }
         }
         ++b->n_exchanges;
         b->exchange_bytes += (int64_t)sizeof(double) * 3 * b->P.TL;
@@ -1538,15 +1571,29 @@ int limo_ctx_comm_init(limo_ctx* ctx, const unsigned char id[LIMO_COMM_ID_BYTES]
         return LIMO_ERR_RUNTIME;
     }
     ctx->comm = comm;
+    ctx->xfn = nullptr;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
+    return LIMO_OK;
+}
+
+int limo_ctx_comm_init_host(limo_ctx* ctx, limo_exchange_fn fn, void* user, int rank, int world) {
+    if (!ctx || (fn && (world < 1 || rank < 0 || rank >= world))) return LIMO_ERR_INVALID;
+    if (ctx->comm) {
+        (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->xfn = fn;
+    ctx->xuser = user;
+    ctx->comm_rank = fn ? rank : 0;
+    ctx->comm_world = fn ? world : 1;
     return LIMO_OK;
 }
 
 int limo_ba_solve_sharded(limo_ctx* ctx, limo_ba_window* window, const limo_ba_options* opts, int n_shards,
                           limo_ba_report* report) {
     if (!ctx || !window) return LIMO_ERR_INVALID;
-    const bool ranks = ctx->comm != nullptr;
+    const bool ranks = ctx->has_transport();
     if (n_shards < 1 || (ranks && n_shards % ctx->comm_world != 0) || n_shards > 8 * (ranks ? ctx->comm_world : 1)) {
         ctx->err = "limo_ba_solve_sharded: n_shards must be a multiple of the communicator size, at most 8 shards per GPU";
         return LIMO_ERR_INVALID;

@@ -60,3 +60,66 @@ def test_rccl_exchange_on_one_rank_communicator():
     assert rr["final_cost"] == rv["final_cost"] and rr["iterations_total"] == rv["iterations_total"]
     assert np.array_equal(wr.kf_pose, wv.kf_pose)
     assert np.array_equal(wr.lm_pos, wv.lm_pos)
+
+
+# ---- the library's world > 1 branch on a ONE-GPU box: two processes, each with its own limo_ctx on device 0, exchange staged
+#      through host memory over gloo (limo_ctx_comm_init_host).  Real k_shard_reduce / k_slab_reduce / k_unpack / k_lm_owned
+#      launches with local shards = P / world; RCCL cannot do this (a device may appear once per communicator).
+def _gpu_rank_main(rank, world, n_shards, port, out_dir):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"gathers": 0, "gather_bytes": 0, "gather_max": 0, "reduces": 0}
+
+    def allgather(send, recv):
+        calls["gathers"] += 1
+        calls["gather_bytes"] += send.nbytes
+        calls["gather_max"] = max(calls["gather_max"], send.nbytes)
+        outs = [torch.empty(send.shape[0], dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, torch.from_numpy(np.array(send, copy=True)))
+        for r in range(world):
+            recv[r, :] = outs[r].numpy()
+
+    def allreduce(send, recv):
+        calls["reduces"] += 1
+        t = torch.from_numpy(np.array(send, copy=True))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        recv[:] = t.numpy()
+
+    w = synth.make_window(77, n_kf=6, n_lm=1500)
+    c = ba.Context(0)
+    c.comm_init_host(rank, world, allgather, allreduce)
+    rep = c.solve_sharded(w, default_options(), n_shards)
+    st = c.exchange_stats()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kf_pose=w.kf_pose, lm_pos=w.lm_pos, final_cost=rep["final_cost"], iters=rep["iterations_total"],
+             num_solves=rep["num_solves"], gathers=calls["gathers"], gather_bytes=calls["gather_bytes"], gather_max=calls["gather_max"],
+             reduces=calls["reduces"], exchanges=st["exchanges"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_two_processes_on_one_gpu_match_virtual_shards(tmp_path, n_shards):
+    """world = 2 ranks of the PRODUCT library (not the emulation): same bits as the virtual-shard run of the same P on one
+    context, and the call / byte pattern tests/test_sharded_cpu.py asserts for the emulated exchange."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    port = 30300 + (os.getpid() % 1500) + n_shards
+    mp.spawn(_gpu_rank_main, args=(2, n_shards, port, str(tmp_path)), nprocs=2, join=True)
+    wv = synth.make_window(77, n_kf=6, n_lm=1500)
+    rv = ba.Context(0).solve_sharded(wv, default_options(), n_shards)
+    for rank in (0, 1):
+        r = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert np.array_equal(r["kf_pose"], wv.kf_pose) and np.array_equal(r["lm_pos"], wv.lm_pos)
+        assert float(r["final_cost"]) == rv["final_cost"] and int(r["iters"]) == rv["iterations_total"]
+        iters, solves, slots = int(r["iters"]), int(r["num_solves"]), n_shards // 2
+        assert int(r["gathers"]) <= slots * (2 * (iters + solves) + solves), (int(r["gathers"]), iters, solves)
+        assert int(r["reduces"]) <= solves + 2        # the trimming round(s) + the landmarks at the end
+        assert int(r["gather_max"]) <= 48 << 10
