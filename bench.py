@@ -37,11 +37,18 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # fp64 matrix peak: 256 CU x 4 SIMD x 32 FLOP/clk x
 # observation: residual, J_pose, J_point written out) - that is k_evaluate, reported as `roofline_evaluate` - and the FUSED
 # normal-equation path: 52 B read per observation + 72 B written per landmark (V, g), "+ W only if W is materialised".
 # k_lin_lm is the fused path; instead of W (144 B per pair) the design stores the four scalars of the factored Jacobian
-# (DESIGN.md §3): 32 B per observation.  Its algorithmic unit is therefore 52 + 32 B per observation + 72 B per landmark;
+# (DESIGN.md §3): two of them, 16 B per observation, since round 5 (xn, yn are rebuilt by the readers from the landmark and
+# the view).  Its algorithmic unit is therefore 52 + 16 B per observation + 72 B per landmark;
 # `roofline.achieved` = that x what one launch linearises / launch time (never above what the kernel moves, so never above the
 # peak), `roofline.traffic` = the HBM bytes the counters see, `roofline.frac` = traffic / time / 8 TB/s.
-FUSED_BYTES_PER_OBS = 52 + 32
+FUSED_BYTES_PER_OBS = 52 + 16
 FUSED_BYTES_PER_LANDMARK = 72
+# The kernel is bound by the fp64 pipe, not by HBM, so the line also prices it there: `roofline.fp64` =
+# ALGORITHMIC fp64 flops / kernel time / 78.6 TF.  Per (landmark, view) pair the fused path needs ~300 multiply-adds whatever the
+# code looks like: pose + landmark Jacobian of the three residual rows ~100, the Gram terms U (21), g_c (6), V (6), g_l (3) at three
+# rows each ~110 + the 28-value cross-lane sum they leave through ~50, robust loss + corrector ~20, one reciprocal and two inverse
+# square roots ~20 - the count the round-4 review derived from cost_functors_ceres.hpp:71-155,193-212.
+FP64_FLOPS_PER_LINEARISED_OBS = 2 * 300
 def _newest_profile(suffix):
     import glob
 
@@ -102,7 +109,7 @@ class _StubBatch:
         return {"linearize_ms": 1.0, "linearize_launches": 1, "schur_ms": 1.0, "schur_launches": 1, "total_ms": 2.0}
 
     def download(self):
-        return [{"num_linearizations": 1, "iterations_total": 1, "n_trimmed_landmarks": 0, "termination": 0, "final_cost": 1.0} for _ in self.windows]
+        return [{"num_linearizations": 1, "iterations_total": 1, "successful_steps": 1, "n_trimmed_landmarks": 0, "termination": 0, "final_cost": 1.0} for _ in self.windows]
 
     def close(self):
         pass
@@ -267,6 +274,10 @@ def main():
                 "mean_lm_iterations": float(np.mean([r["iterations_total"] for r in reps])),
                 "max_lm_iterations": int(max(r["iterations_total"] for r in reps)),
                 "converged": int(sum(r["termination"] == 0 for r in reps)),
+                # share of the LM iterations whose step was accepted (what a speculative linearisation at the candidate would
+                # have to beat: DESIGN.md §4)
+                "accept_ratio": float(sum(r["successful_steps"] for r in reps)) / max(1, sum(r["iterations_total"] for r in reps)),
+                "linearisations_per_iteration": float(sum(r["num_linearizations"] for r in reps)) / max(1, sum(r["iterations_total"] for r in reps)),
             },
             "roofline": {
                 "kernel": "k_lin_lm (Jacobian evaluation + landmark blocks + damping, landmark-major; SURVEY 8d's fused normal-equation path)",
@@ -281,8 +292,12 @@ def main():
                 "launches": stats["linearize_launches"],
                 "avg_launch_ms": lin_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
-                "algorithmic_unit": "SURVEY 8d fused path: 52 B read per observation + 72 B (V, g) written per landmark, + the 32 B per observation of factored "
+                "algorithmic_unit": "SURVEY 8d fused path: 52 B read per observation + 72 B (V, g) written per landmark, + the 16 B per observation of factored "
                                     "Jacobian planes this design stores in place of W (144 B per pair); x the observations / landmarks this run linearised",
+                "fp64": {"achieved": FP64_FLOPS_PER_LINEARISED_OBS * lin_obs / lin_s / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": FP64_FLOPS_PER_LINEARISED_OBS * lin_obs / lin_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                         "algorithmic_flops_per_observation": FP64_FLOPS_PER_LINEARISED_OBS,
+                         "what": "algorithmic fp64 flops of the fused linearisation (~300 multiply-adds per (landmark, view) pair) / kernel time / the fp64 vector = matrix peak"},
                 "linearised_observations_per_launch": lin_obs / launches,
                 "measured_in": "one extra step with a single slot group (kernels of different groups overlap in the timed steps); HIP events on the kernel's stream",
                 "materialised_kernel": "the SURVEY 8d MATERIALISED Jacobian pass (212 B / observation + 84 B / depth observation) is k_evaluate: see roofline_evaluate",

@@ -1153,6 +1153,41 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
             gp_stage(g0);
             KBA_SYNC();
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        // gfx950, 256 lanes (round 5): [F | r]^T [F | r] of a keyframe's rows is ONE 16 x 16 Gram tile - wave kl (mod 4) runs
+        // v_mfma_f64_16x16x4 over the keyframe's staged rows, four rows per instruction (operand lane (i, k) = entry i of row
+        // 4 s + k, zero beyond the row's 11 values and beyond the keyframe's rows), and adds the tile's entries (a, b < 10) to H,
+        // (a, 10) to g_c.  ~100 rows per keyframe at C2: 25 dependent MFMAs instead of ~100 dependent multiply-adds behind two LDS
+        // reads each, on three passes of the workgroup (11 of the 30 us of this function, profiles/r03_single_window_phase_ticks.txt).
+        // Same products; an entry's rows are added four at a time inside the instruction (all device paths share this code, the
+        // CPU-tier emulation keeps the loop below).
+        if (nt == 256) {
+            typedef double v4d_t __attribute__((ext_vector_type(4)));
+            const int lane = tid & 63, li = lane & 15, kq = lane >> 4;
+            for (int kl = tid >> 6; kl < wd.n_kf; kl += 4) {
+                int lo = bv.kf_gp0[wd.kf0 + kl] - g0, hi = lo + bv.kf_ngp[wd.kf0 + kl];
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > ng ? ng : hi;
+                if (hi <= lo) continue;  // (uniform over the wave)
+                v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int g = lo; g < hi; g += 8) {  // two instructions per pass: their operand reads are in flight together
+                    const int r0 = g + kq, r1 = g + 4 + kq;
+                    const double z0 = (r0 < hi && li < 11) ? gps[r0 * 12 + li] : 0.0;
+                    const double z1 = (r1 < hi && li < 11) ? gps[r1 * 12 + li] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z1, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // f64 16x16x4 C / D layout: row = (lane >> 4) + 4 r, column = lane & 15
+                    const int a = kq + 4 * r;
+                    if (a < 10 && li < 10)
+                        H[(kl * kCamSlots + a) * nc + kl * kCamSlots + li] += acc[r];
+                    else if (a < 10 && li == 10)
+                        gc[kl * kCamSlots + a] += acc[r];
+                }
+            }
+        } else
+#endif
         for (int e = tid; e < wd.n_kf * 110; e += nt) {
             const int kl = e / 110, q = e % 110;
             const int a = q < 100 ? q / 10 : q - 100, bb = q < 100 ? q % 10 : 10;

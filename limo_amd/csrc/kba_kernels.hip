@@ -380,6 +380,7 @@ __global__ void k_view_consts(BatchView bv) {
 // Bytes per pair: 4 (slot) + 12 (u, v, d) read, 56 (planes) written; per landmark 32 read + 72 written - the separate
 // view-major linearise + landmark-major accumulate pair moved 101 + 93 B per observation.
 typedef const double __attribute__((address_space(4))) cdouble;
+constexpr int kLinAccl = 13;  // doubles per lane that k_lin_lm<4> parks in LDS: V 6 | g 3 | Jacobi scale 3 | ground-plane row
 // (the body of k_lin_lm for landmark workgroup b; k_solve_wg runs it for the workgroups of its window one after the other)
 // KVIEW: the view constants are read through the constant address space (scalar loads) - only valid when they were
 // written by an EARLIER launch (k_view_consts); k_solve_wg writes them in the same launch and reads them as plain memory.
@@ -391,7 +392,10 @@ template <>
 struct ViewPtr<false> {
     typedef const double* type;
 };
-template <bool KVIEW>
+// ACCL: the landmark block's nine running sums (V 6 | g 3) live in LDS ([9][kBlock] doubles in front of the view slices, one
+// column per lane: conflict-free) instead of registers - read, three rows added, written back once per view.  18 registers
+// less across the view loop: what the 128-register build (four waves per SIMD) spilled; the sums and their order are the same.
+template <bool KVIEW, bool ACCL = false>
 __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveConsts& c, int b) {
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
@@ -419,13 +423,40 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     const int32_t* slot = bv.lm_slot + gl;
     typename ViewPtr<KVIEW>::type vc = (typename ViewPtr<KVIEW>::type)(bv.view_lin + (int64_t)kViewLin * wd.view0);
     double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
-    extern __shared__ __attribute__((aligned(16))) double lv_lds[];  // [view][wave][kLinPartial]
+    extern __shared__ __attribute__((aligned(16))) double lin_lds[];  // ACCL: [kLinAccl][kBlock] sums, tail inputs | [view][wave][kLinPartial]
+    double* const lv_lds = lin_lds + (ACCL ? kLinAccl * kBlock : 0);
+    double* const accl = lin_lds + threadIdx.x;
     const int64_t dump = bv.SO - kObsBlock + threadIdx.x;
     LmAcc acc;
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc.V[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc.g[i] = 0.0;
+    if constexpr (ACCL) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) accl[i * kBlock] = 0.0;
+        // the tail's per-landmark inputs wait in LDS as well (fetched up here, in front of the loop's stores: LmTailIn)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accl[(9 + i) * kBlock] = tail.sc[i];
+        accl[12 * kBlock] = __hiloint2double(tail.gg, 0);
+    }
+    // (a lane only ever touches its own column of the sums: no barrier between these accesses)
+    auto accum = [&](auto vl, const double* r3, const double* c4) {
+        if constexpr (ACCL) {
+            LmAcc a;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a.V[i] = accl[i * kBlock];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a.g[i] = accl[(6 + i) * kBlock];
+            lin_lm_accum(vl, r3, c4, a);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) accl[i * kBlock] = a.V[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) accl[(6 + i) * kBlock] = a.g[i];
+        } else {
+            lin_lm_accum(vl, r3, c4, acc);
+        }
+    };
     int fail = 0;
     // pipeline: slot of view j + 2, measurement of view j + 1 in flight while view j computes
     int s_cur = slot[0];
@@ -469,7 +500,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
             bv.obs_c[o] = c4[0];
             bv.obs_c[bv.SO + o] = c4[3];
         }
-        lin_lm_accum(vl, r3, c4, acc);
+        accum(vl, r3, c4);
         const double tot = wave_sum_all(l.cost);
         if (lane < kLinPartial) lv_lds[(j * kLinWaves + wave) * kLinPartial + lane] = lane == 0 ? tot : 0.0;
     }
@@ -526,7 +557,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 #if KBA_ABLATE == 68 || KBA_ABLATE == 67
         acc.V[0] += r3[0] * c4[0]; acc.V[1] += r3[1] * c4[1]; acc.g[0] += r3[2] * c4[2]; acc.g[1] += c4[3];
 #else
-        lin_lm_accum(vl, r3, c4, acc);  // zeros where the pair does not exist
+        accum(vl, r3, c4);  // zeros where the pair does not exist
 #endif
         static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter14 x 2");
 #if KBA_ABLATE == 0
@@ -559,6 +590,15 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         const double tot = wave_reduce_scatter28(vals, lane);
 #endif
         if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
+    }
+    if constexpr (ACCL) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc.V[i] = accl[i * kBlock];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc.g[i] = accl[(6 + i) * kBlock];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tail.sc[i] = accl[(9 + i) * kBlock];
+        tail.gg = __double2hiint(accl[12 * kBlock]);
     }
     double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     // the landmark's ground-plane row (B3) is linearised by its own lane right here, before lin_lm_finish adds it to the
@@ -594,9 +634,12 @@ template <int WAVES>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
-    lin_lm_block<true>(bv, c, b);
+    lin_lm_block<true, WAVES >= 4>(bv, c, b);
 }
-__host__ __device__ inline int lin_lm_lds_bytes(int n_view_max) { return n_view_max * kLinWaves * kLinPartial * (int)sizeof(double); }
+// accl: the launch is k_lin_lm<4> (its landmark sums live in LDS)
+__host__ __device__ inline int lin_lm_lds_bytes(int n_view_max, bool accl = false) {
+    return (n_view_max * kLinWaves * kLinPartial + (accl ? kLinAccl * kBlock : 0)) * (int)sizeof(double);
+}
 
 // ------------------------------------------------------------------------------------------ landmarks
 __device__ __forceinline__ void lm_damp_block(const BatchView& bv, const SolveConsts& c, int b) {
@@ -912,7 +955,9 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         }
     };
     // stage 2 (one tile ahead): the landmark-side inputs
-    double c4[4], p[3], Bt[6], t3[3], gE[3], gF[kCamSlots];
+    // (g3 is written by loads only: with a variable that the fill also overwrites - t = Bt g in place - the compiler copied the loaded
+    // values into it right behind the loads, and that wait exposed the whole prefetch of a tile before its MFMAs)
+    double c4[4], p[3], Bt[6], g3[3], gE[3], gF[kCamSlots];
     bool live = false, seen = false, att = false;
     auto fetch_data = [&](int l0, int st, int slot, int gg) {
         const int gl = lm_first + l0 + li;
@@ -924,7 +969,7 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             c4[0] = c4[3] = 1.0 + l0;
             p[0] = p[1] = p[2] = 2.0 + li;
             for (int i = 0; i < 6; ++i) Bt[i] = 0.5 + i;
-            for (int i = 0; i < 3; ++i) t3[i] = 1.5;
+            for (int i = 0; i < 3; ++i) g3[i] = 1.5;
             return;
         }
 #endif
@@ -941,7 +986,7 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         }
         if (want_t) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) t3[i] = bv.lm_g[i * bv.SL + gl];  // (g here; turned into t = Bt g at the fill)
+            for (int i = 0; i < 3; ++i) g3[i] = bv.lm_g[i * bv.SL + gl];  // (turned into t = Bt g at the fill)
         }
         if constexpr (GP) {
             if (att) {
@@ -967,10 +1012,8 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
     const int mq = li < 8 ? li : li + 8;            // two-tile path: column of lane li in the second operand {0..7, 16..23}
     for (int l0 = 0; l0 < n_lm_blk; l0 += kSchurLm) {
         // ---- fill: this lane's 3 x NS block of Y' (zeros where the landmark has no row with the keyframe)
-        if (live && (kq == 0 || two_tile)) {
-            const double g3[3] = {t3[0], t3[1], t3[2]};
-            lm_t_of(Bt, g3, t3);
-        }
+        double t3[3] = {0.0, 0.0, 0.0};
+        if (live && (kq == 0 || two_tile)) lm_t_of(Bt, g3, t3);
         if (kq == 0 && !two_tile) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) Z[(3 * li + cc) * ld + nfq] = live ? t3[cc] : 0.0;
@@ -1202,7 +1245,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 }
 
 // ------------------------------------------------------------------------------------------ camera system
-__global__ __launch_bounds__(kBlock) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
+// (three waves per SIMD = three windows per CU: 168 registers; the ground-plane Gram tile of round 5 took the allocation to 172)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     WinState& st = bv.st[w];

@@ -589,21 +589,23 @@ struct limo_ba_batch : Executor {
         listed = n_wl_win;
     }
 
-    // k_lin_lm at 3 waves / SIMD.  Occupancy experiment (read once): KBA_LIN_WAVES=4 takes the 128-register build (spills 44 B),
-    // KBA_LIN_LDS_PAD=<bytes> adds dynamic LDS per workgroup (80000: two workgroups per CU = 2 waves / SIMD).
+    // k_lin_lm at 3 waves / SIMD (163 registers).  KBA_LIN_WAVES=4 (read once) takes the 128-register build whose nine running landmark
+    // sums and tail inputs live in LDS (kba_kernels.hip:lin_lm_block ACCL; no spill inside the view loop): its launches are 3 % shorter
+    // (535 vs 554 us per round of 4096 slots) but the bench line is 1.4 % lower with it - two slot groups share the CUs and the
+    // 4-wave build leaves the other group's kernels less room (profiles/r05_experiment_lin_lm_occupancy.txt).  KBA_LIN_LDS_PAD=<bytes>
+    // adds dynamic LDS per workgroup (occupancy experiments: 80000 = two workgroups per CU).
+    int lin_lds_set[2] = {0, 0};
     void launch_lin_lm(int grid, hipStream_t s, const BatchView& v, const int32_t* wl) {
         static const int lw = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
         static const int pad = std::getenv("KBA_LIN_LDS_PAD") ? std::atoi(std::getenv("KBA_LIN_LDS_PAD")) : 0;
-        const int lds = lin_lm_lds_bytes(P.Vmax) + pad;
-        if (pad) {
-            static bool once = false;
-            if (!once) {
-                once = true;
-                (void)hipFuncSetAttribute((const void*)k_lin_lm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                (void)hipFuncSetAttribute((const void*)k_lin_lm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            }
+        const bool four = lw >= 4;
+        const int lds = lin_lm_lds_bytes(P.Vmax, four) + pad;
+        if (lds > 48 * 1024 && lin_lds_set[four] < lds) {  // (beyond the default dynamic-LDS limit: many views, or the padding)
+            note(hipFuncSetAttribute(four ? (const void*)k_lin_lm<4> : (const void*)k_lin_lm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                 "hipFuncSetAttribute(k_lin_lm)");
+            lin_lds_set[four] = lds;
         }
-        if (lw == 4)
+        if (four)
             hipLaunchKernelGGL(k_lin_lm<4>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
         else
             hipLaunchKernelGGL(k_lin_lm<3>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
