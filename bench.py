@@ -585,17 +585,27 @@ def bench_depth(ctx):
     alg_d1 = 16 * n_pts + 20 * vis  # 16 B / return read + 20 B / visible return written
     alg_feat = 212 * n_feat         # 212 B / feature
     alg = alg_d1 + alg_feat
-    pmc_d = {}
+    # counter traffic of the depth kernels: only from a stored profile that was taken on THIS depth.hip (the file carries the sha of
+    # the source it ran on; scripts/gpu_depth_prof.sh PMC=1 writes it)
+    pmc_d, pmc_note = {}, "no stored counter profile of the depth kernels"
     if os.path.exists(PMC_DEPTH_FILE):
+        import hashlib
+
         with open(PMC_DEPTH_FILE) as f:
-            pmc_d = json.load(f).get("kernels", {})
+            stored = json.load(f)
+        with open(os.path.join(ROOT, "limo_amd", "csrc", "depth.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        if stored.get("depth_source_sha16") == sha:
+            pmc_d = stored.get("kernels", {})
+        else:
+            pmc_note = "none: %s was taken on another depth.hip (sha %s, now %s)" % (os.path.relpath(PMC_DEPTH_FILE, ROOT), stored.get("depth_source_sha16"), sha)
 
     def roof(kernel, alg_bytes, ms):
         tr = next((v.get("hbm_MB") for k, v in pmc_d.items() if k.startswith(kernel) and v.get("frames") == n_batch), None)
         return {"kernel": kernel, "bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launch_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic": None if tr is None else tr * 1e6,
-                "traffic_source": None if tr is None else "%s (stored rocprofv3 --pmc passes of a %d-frame call)" % (os.path.relpath(PMC_DEPTH_FILE, ROOT), n_batch)}
+                "traffic_source": pmc_note if tr is None else "%s (stored rocprofv3 --pmc passes of a %d-frame call, taken on this depth.hip)" % (os.path.relpath(PMC_DEPTH_FILE, ROOT), n_batch)}
 
     return {"value": 1e3 / single, "unit": "frames/s", "ms_per_frame_median": single,
             "points": fr["cloud"].shape[0], "features": fr["uv"].shape[0], "visible_points": synth_lidar.visible_points(fr),

@@ -95,8 +95,9 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // One observation at the CURRENT parameters: residual r (3, loss-corrected), the four scalars c4 = (au, xn, yn, sd) of
 // the factored Jacobian (kba_math.hpp:ft_build) and the camera-side sums U = Jp^T Jp, g = Jp^T r with
 // Jp = Ft [M | I], Ft = c^T Rc (ASSIGNED to out, not added).  The arithmetic of obs_residual_jacobian (kba_math.hpp), laid
-// out for the instruction stream of a gfx950 lane (profiles/r05_lin_lm_instruction_diet.txt: 626 -> ~390 instructions per
-// pair):
+// out for the instruction stream of a gfx950 lane (round 5: k_lin_lm 690 -> 547 us per round of 4096 slots,
+// profiles/r04_ / r05_rocprof_kernel_stats_bench_one_group*.txt; the static instruction mix of the view loop is in
+// profiles/r05_experiment_lin_lm_occupancy.txt):
 //   * every multiply-add takes at most ONE operand from the view's constants vl (wave-uniform: scalar registers, of which an
 //     instruction reads one);
 //   * the pose Jacobian's rotation block comes from the view's C_k (view_consts_item): Rc M(q, p) = sum_k p_k C_k;
@@ -230,7 +231,7 @@ KBA_HD void lin_lm_accum(VP vl, const double* r3, const double* c4, LmAcc& a) {
 }
 // What the landmark's tail needs from memory besides its sums - fetched BEFORE the view loop (lin_lm_tail_fetch): behind the
 // loop's plane stores these loads could not be moved up by the compiler (possible aliasing), and a dependent round trip per
-// landmark at the end of a workgroup's life is a fifth of the kernel (profiles/r05_experiment_lin_lm_ablations.txt).
+// landmark at the end of a workgroup's life is a quarter of the kernel (profiles/r05_experiment_lin_lm_occupancy.txt: "no tail").
 struct LmTailIn {
     int gg;             // ground-plane row of the landmark or -1
     int compute_scale;  // this linearisation defines the Jacobi scale
@@ -567,7 +568,9 @@ KBA_HD void slab_reduce_entry(const BatchView& bv, int w, int n_shards, int i) {
     schur_need_decode(i, wd.nf, ca, cb);
     const double* sp = bv.S_part + wd.spart_off + schur_need_offset(ca, cb, wd.nf, wd.nfq, wd.nf_pad);
     double a = 0.0;
-    for (int q = 0; q < wd.n_sblk; ++q) a += sp[q * slab];
+    // (one slab per Schur block here; the plain blocks' slabs are zero - and since round 5 unwritten - outside the pose slots + rhs)
+    const int q0 = (ca >= wd.nfq || (cb >= wd.nfq && cb < wd.nf)) ? wd.n_sblk_plain : 0;
+    for (int q = q0; q < wd.n_sblk; ++q) a += sp[q * slab];
     bv.S_red[wd.sred_off / n_shards + i] = a;
 }
 
@@ -1380,15 +1383,21 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     // alone on the GPU is bound by exactly this latency chain).  Per entry the order of the sum stays q mod 4.
     const int n_need = nf * (nf + 1) / 2 + nf;
     const int n_slab = c.schur_nslab > 0 ? c.schur_nslab : schur_slabs(wd, c.schur_span, c.schur_span_gp);
+    // The slabs of the PLAIN groups (landmarks without a ground-plane row) come first and are zero outside the pose slots and
+    // the rhs: an entry that involves a plane slot skips them - from a multiple of four on, so that every slab keeps its place
+    // in the (q mod 4) order and the sums keep their bits (a skipped term is an exact zero).  Round 5: this sum is what bounds
+    // k_cam_solve in a batch (137 KB of slab entries per window and iteration at C2; 86 KB with the skip).
+    const int q_gp = c.schur_nslab > 0 ? 0 : (schur_plain_slabs(wd, c.schur_span) & ~3);
     constexpr int kE = KBA_SLAB_ENTRIES;  // entries a lane sums at once
     for (int i0 = tid; i0 < n_need; i0 += kE * nt) {
         double s[kE], acc[kE][4];
         int64_t off[kE];
-        int dst[kE];
+        int dst[kE], qs[kE];
         for (int e = 0; e < kE; ++e) {
             const int i = i0 + e * nt;
             dst[e] = -1;
             off[e] = 0;
+            qs[e] = n_slab;
             s[e] = 0.0;
             for (int r = 0; r < 4; ++r) acc[e][r] = 0.0;
             if (i >= n_need) continue;
@@ -1406,13 +1415,16 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             // (packed slabs of a sharded solve hold exactly these entries in this order)
             off[e] = c.schur_packed ? (int64_t)i : schur_need_offset(ca, cb, nf, nfq, nfp);
             dst[e] = ca * lda + cb;
+            qs[e] = (ca >= nfq || (cb >= nfq && cb < nf)) ? q_gp : 0;
         }
         int q = 0;
         for (; q + 4 <= n_slab; q += 4)
             for (int e = 0; e < kE; ++e)
-                for (int r = 0; r < 4; ++r) acc[e][r] += sp[(int64_t)(q + r) * slab + off[e]];
+                if (q >= qs[e])
+                    for (int r = 0; r < 4; ++r) acc[e][r] += sp[(int64_t)(q + r) * slab + off[e]];
         for (; q < n_slab; ++q)
-            for (int e = 0; e < kE; ++e) acc[e][0] += sp[(int64_t)q * slab + off[e]];
+            for (int e = 0; e < kE; ++e)
+                if (q >= qs[e]) acc[e][0] += sp[(int64_t)q * slab + off[e]];
         for (int e = 0; e < kE; ++e)
             if (dst[e] >= 0) A[dst[e]] = s[e] - ((acc[e][0] + acc[e][1]) + (acc[e][2] + acc[e][3]));
     }

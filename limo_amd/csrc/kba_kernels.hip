@@ -1159,9 +1159,11 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         }
         schur_wave_sync<COOP>();
     }
-    // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix.  Entries outside the tile's columns are zero
-    //      for these landmarks and must be written: the slab may have belonged to a group of the other class at
-    //      another granularity.
+    // ---- the slab of this group: tiles (tr <= tc) of the nfp x nfp matrix.  A ground-plane group writes all of them (zeros
+    //      outside its columns included).  A plain group only writes the tiles that hold its pose columns and the rhs (rows and
+    //      columns <= nfq): the readers of the slabs - cam_solve, slab_reduce_entry, k_solve_coop's slab sum - never look at a
+    //      plain slab outside them (round 5: 6 KB instead of 12 KB per plain slab at C2), and a slab keeps its class for the
+    //      life of the batch (schur_slab_of: plain groups first, fixed spans).
     double* out = bv.S_part + wd.spart_off + (int64_t)schur_slab_of(wd, sb, span, span_gp) * ((int64_t)nfp * nfp);
     const int T = nfp / 16;
     if (two_tile) {
@@ -1194,25 +1196,22 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             }
         }
         schur_wave_sync<COOP>();
-        for (int tc = 0; tc < T; ++tc)
+        for (int tc = 0; tc < (T < 2 ? T : 2); ++tc)
             for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
-                    out[row * nfp + col] = (tc < 2) ? St[row * 32 + col] : 0.0;
+                    out[row * nfp + col] = St[row * 32 + col];
                 }
             }
         return;
     }
     if constexpr (kTT) {  // (one 16-column tile: windows of this batch with <= 2 free keyframes)
-        for (int tc = 0; tc < T; ++tc)
-            for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = tr * 16 + kq + 4 * r, col = tc * 16 + li;
-                    out[row * nfp + col] = (tc == 0 && row < ncol && col < ncol) ? acc[0][r] : 0.0;
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq + 4 * r, col = li;
+            out[row * nfp + col] = (row < ncol && col < ncol) ? acc[0][r] : 0.0;
+        }
     } else {
         int idx = 0;
 #pragma unroll
@@ -1229,11 +1228,13 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
                 }
                 ++idx;
             }
-        for (int tc = TM; tc < T; ++tc)
-            for (int tr = 0; tr <= tc; ++tr) {
+        if constexpr (GP) {
+            for (int tc = TM; tc < T; ++tc)
+                for (int tr = 0; tr <= tc; ++tr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
-            }
+                    for (int r = 0; r < 4; ++r) out[(tr * 16 + kq + 4 * r) * nfp + tc * 16 + li] = 0.0;
+                }
+        }
     }
 }
 template <int TM, bool GP, int WAVES>
@@ -1246,7 +1247,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
 // ------------------------------------------------------------------------------------------ camera system
 // (three waves per SIMD = three windows per CU: 168 registers; the ground-plane Gram tile of round 5 took the allocation to 172)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
+#ifndef KBA_CAM_ASM_WAVES
+#define KBA_CAM_ASM_WAVES 3
+#endif
+#ifndef KBA_CAM_SOLVE_WAVES
+#define KBA_CAM_SOLVE_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_ASM_WAVES, KBA_CAM_ASM_WAVES))) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     WinState& st = bv.st[w];
@@ -1287,7 +1294,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_SOLVE_WAVES, KBA_CAM_SOLVE_WAVES))) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     if (!bv.st[w].active) return;
@@ -1874,7 +1881,10 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 for (int e = (g - first) * kBlock + tid; e < slab; e += n_sum * kBlock) {
                     double acc[4] = {0.0, 0.0, 0.0, 0.0};
                     const int n4 = n_slab & ~3;
-                    for (int q0 = 0; q0 < n_slab; q0 += 16) {  // 16 loads in flight, then added in slab order
+                    // (the plain groups' slabs are zero and unwritten outside the pose slots + rhs, rows and columns <= nfq of the
+                    // slab: those entries start behind them, on a multiple of four - cam_solve's rule, cam_solve's bits)
+                    const int q_first = (e / nfp > wd.nfq || e % nfp > wd.nfq) ? (n_pg & ~3) : 0;
+                    for (int q0 = q_first; q0 < n_slab; q0 += 16) {  // 16 loads in flight, then added in slab order
                         double v[16];
 #pragma unroll
                         for (int j = 0; j < 16; ++j) v[j] = q0 + j < n_slab ? sp[(int64_t)(q0 + j) * slab + e] : 0.0;

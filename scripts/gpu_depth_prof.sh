@@ -54,8 +54,9 @@ if [ "${PMC:-0}" = "1" ]; then
     DEPTH_REPS=2 timeout 600 rocprofv3 --pmc $grp --kernel-trace -d gpurun_out/pmc_depth -o p$i -- python /tmp/dep.py > gpurun_out/pmc_depth_$i.log 2>&1 || echo "pass $i failed"
   done
   python - <<'PY'
-import sqlite3, glob, json, re
-out = {"command": "scripts/gpu_depth_prof.sh (PMC=1): rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python /tmp/dep.py; per kernel the 32-frame dispatch (largest counter value)",
+import sqlite3, glob, json, re, hashlib
+out = {"depth_source_sha16": hashlib.sha256(open("limo_amd/csrc/depth.hip", "rb").read()).hexdigest()[:16],
+       "command": "scripts/gpu_depth_prof.sh (PMC=1): rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python /tmp/dep.py; per kernel the 32-frame dispatch (largest counter value)",
        "correction": "gfx950: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section); counters in KiB", "kernels": {}}
 for db_path in sorted(glob.glob("gpurun_out/pmc_depth/*_results.db")):
     db = sqlite3.connect(db_path)
