@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 evidence in one gpurun call (everything lands in gpurun_out/$TAG/; the kept files are copied to profiles/r05_*):
 #   TESTS=1: the GPU test tier first;  1. the bench line (with its in-run counter passes);  2. rocprofv3 kernel table of the bench
-#   command with one slot group;  PMC=1: counter passes of full 1024-window rounds;  SINGLE=1: one window per call, latency + table.
+#   command with one slot group;  PMC=1: counter passes of full 1024-window rounds;  SINGLE=1: one window per call, latency + table;  DEPTH=1: counter passes of the depth kernels.
 # Counter passes carry --kernel-trace only.   usage: TAG=r05a TESTS=1 scripts/gpu_round_r05.sh
 TAG=${TAG:-r05}
 OUT=gpurun_out/$TAG
@@ -20,4 +20,8 @@ if [ -n "$PMC" ]; then
 fi
 if [ -n "$SINGLE" ]; then
   ./scripts/gpu_single_ab.sh "single:A=1" | tee $OUT/single_window.txt
+fi
+if [ -n "$DEPTH" ]; then  # counter passes of the depth kernels (32-frame call) -> pmc_depth_kernels.json, stamped with depth.hip's sha
+  PMC=1 DEPTH_ONLY_PMC=1 ./scripts/gpu_depth_prof.sh > $OUT/depth_prof.log 2>&1; tail -8 $OUT/depth_prof.log
+  cp gpurun_out/depth_pmc.json $OUT/pmc_depth_kernels.json 2>/dev/null
 fi
