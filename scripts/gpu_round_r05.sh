@@ -7,7 +7,7 @@ TAG=${TAG:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 if [ -n "$TESTS" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/gpu_tests.txt
+  ( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed|error|Error|assert|^real" $OUT/pytest_gpu.log | tail -12
 fi
 ( time python bench.py $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; tail -2 $OUT/bench.err; head -c 400 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
