@@ -43,11 +43,12 @@ struct LinLane {
 
 // Per-view constants of the current poses (one item per view, before the observations are linearised):
 //   vl[0..8] H = Rc R(q), vl[9..11] h0 = Rc t + tc (camera point = H p + h0), vl[12..20] Rc, vl[21..24] q, vl[25..27] f, cx, cy,
-//   vl[28..54] C_k = Rc B_k(q), k = 0..2 (9 each, row-major): the rotation-tangent Jacobian M(q, p) = d(R(q) p)/d(delta) of
-//   kba_math.hpp:rot_tangent_jac is LINEAR in p, M = p_0 B_0 + p_1 B_1 + p_2 B_2 with B_k = M(q, e_k), so the camera-frame
-//   Jacobian  d(camera point)/d(rotation tangent) = Rc M = sum_k p_k C_k  costs 27 multiply-adds per observation with
-//   wave-uniform operands instead of ~100 (the 3 x 4 quaternion derivative, its product with the 4 x 3 plus-Jacobian and the
-//   product with Rc) - the same polynomial in (q, p), summed in another order.
+//   vl[28..36] R2 = -2 Rh(q) (row-major), Rh = R(q) + (|q|^2 - 1) I the homogeneous form of the rotation polynomial.  The
+//   rotation-tangent Jacobian M(q, p) = d(R(q) p)/d(delta) of kba_math.hpp:rot_tangent_jac is the polynomial identity
+//   M = -2 [Rh(q) p]_x  (for every q, unit or not), so with  y = R2 p  (9 multiply-adds)  M = [y]_x  and the camera-frame Jacobian  d(camera point)/d(rotation tangent) =
+//   Rc M  has the entries  G[i][j] = Rc[i][j+1] y[j+2] - Rc[i][j+2] y[j+1]  (indices mod 3: 18 more) - 27 operations with
+//   wave-uniform operands like the 27 of the per-view matrices C_k = Rc M(q, e_k) that rounds 5's first sessions used, but 9
+//   constants per view instead of 27 (a pair's view constants are 37 doubles instead of 55: what the lane waits for in k_lin_lm).
 // In k_lin_lm every lane of a wave is at the same view of the same window, so these are wave-uniform (scalar registers).
 KBA_HD void view_consts_item(const BatchView& bv, int view) {
     const double* cam = bv.view_cam + 16 * (int64_t)view;
@@ -63,12 +64,8 @@ KBA_HD void view_consts_item(const BatchView& bv, int view) {
     vl[25] = cam[0];
     vl[26] = cam[1];
     vl[27] = cam[2];
-    for (int k = 0; k < 3; ++k) {
-        const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
-        double B[9];
-        rot_tangent_jac(pose, e, B);
-        mat3_mul(cam + 4, B, vl + 28 + 9 * k);
-    }
+    const double qq1 = quat_norm2_minus_1(pose);
+    for (int i = 0; i < 9; ++i) vl[28 + i] = -2.0 * (R[i] + ((i & 3) == 0 ? qq1 : 0.0));  // (i = 0, 4, 8: the diagonal)
 }
 
 // Inputs of one observation as the linearisation consumes them (a GPU lane fetches them one observation ahead).
@@ -100,7 +97,7 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // profiles/r05_experiment_lin_lm_occupancy.txt):
 //   * every multiply-add takes at most ONE operand from the view's constants vl (wave-uniform: scalar registers, of which an
 //     instruction reads one);
-//   * the pose Jacobian's rotation block comes from the view's C_k (view_consts_item): Rc M(q, p) = sum_k p_k C_k;
+//   * the pose Jacobian's rotation block in closed form from the view's -2 Rh(q) and Rc (view_consts_item): Rc M(q, p) = Rc [-2 Rh p]_x;
 //   * 1 / z and sqrt(rho') through rcp_nr / rsqrt_nr: sqrt(w / (1 + s c)) = sqrt(w) rsqrt(1 + s c), one seed + one
 //     refinement instead of a division followed by a square root;
 //   * the cost value (two logarithms) only where the LM loop reads it (want_cost: the first linearisation of a solve).
@@ -186,12 +183,15 @@ KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want
     c4[3] = sd;
     if (!CAM) return z_ok || in.live == 0;
     const double a1 = au * xn, a2 = au * yn;
-    // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = sum_k p_k C_k
+    // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = Rc [y]_x,  y = -2 Rh(q) p
+    const double yv[3] = {vl[28] * p0 + vl[29] * p1 + vl[30] * p2, vl[31] * p0 + vl[32] * p1 + vl[33] * p2, vl[34] * p0 + vl[35] * p1 + vl[36] * p2};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double g0 = vl[28 + j] * p0 + vl[37 + j] * p1 + vl[46 + j] * p2;
-        const double g1 = vl[31 + j] * p0 + vl[40 + j] * p1 + vl[49 + j] * p2;
-        const double g2 = vl[34 + j] * p0 + vl[43 + j] * p1 + vl[52 + j] * p2;
+        constexpr int kNext[3] = {1, 2, 0};
+        const int j1 = kNext[j], j2 = kNext[j1];
+        const double g0 = vl[12 + j1] * yv[j2] - vl[12 + j2] * yv[j1];
+        const double g1 = vl[15 + j1] * yv[j2] - vl[15 + j2] * yv[j1];
+        const double g2 = vl[18 + j1] * yv[j2] - vl[18 + j2] * yv[j1];
         J[0 + j] = au * g0 - a1 * g2;
         J[6 + j] = au * g1 - a2 * g2;
         J[12 + j] = sd * g2;
@@ -501,7 +501,7 @@ KBA_HD void schur_pair_block(const BatchView& bv, const WinDesc& wd, int gl, int
             if (s < 0) continue;
             if (!have) {
                 quat_R(pose, R);
-                rot_tangent_jac(pose, bv.lm + 3 * (int64_t)gl, M);
+                rot_tangent_from_R(R, quat_norm2_minus_1(pose), bv.lm + 3 * (int64_t)gl, M);
                 have = true;
             }
             double Ft[9], c4[4];

@@ -21,6 +21,8 @@
 // sequence serves a whole batch of windows that converge at different iterations.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #define KBA_SYNC() __syncthreads()
 #include "kba_items.hpp"
 #ifndef KBA_ABLATE  // (profiling builds only: scripts/gpu_lin_ablate.sh compiles variants of k_lin_lm with pieces left out)
@@ -395,7 +397,11 @@ struct ViewPtr<false> {
 // ACCL: the landmark block's nine running sums (V 6 | g 3) live in LDS ([9][kBlock] doubles in front of the view slices, one
 // column per lane: conflict-free) instead of registers - read, three rows added, written back once per view.  18 registers
 // less across the view loop: what the 128-register build (four waves per SIMD) spilled; the sums and their order are the same.
-template <bool KVIEW, bool ACCL = false>
+// VLDS: the window's view constants are copied into LDS once per workgroup ([view][kLinVlds], behind the ACCL region) and read from
+// there (ds_read, broadcast) instead of through scalar loads: LDS reads return in order and are waited for one by one, scalar loads
+// return out of order - every use of one waits for ALL of them (s_waitcnt lgkmcnt(0)), ten times per pair.
+constexpr int kLinVlds = 38;  // doubles of a view's constants the linearisation reads (view_consts_item: 37)
+template <bool KVIEW, bool ACCL = false, bool VLDS = false>
 __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveConsts& c, int b) {
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
@@ -421,11 +427,22 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     LmTailIn tail;  // (fetched here, in front of the view loop's stores: kba_items.hpp:LmTailIn)
     lin_lm_tail_fetch(bv, w, gl, tail);
     const int32_t* slot = bv.lm_slot + gl;
-    typename ViewPtr<KVIEW>::type vc = (typename ViewPtr<KVIEW>::type)(bv.view_lin + (int64_t)kViewLin * wd.view0);
     double* out = bv.lv_part + wd.lvpart_off + (int64_t)(b - wd.lblk0) * n_view * kLinPartial;
-    extern __shared__ __attribute__((aligned(16))) double lin_lds[];  // ACCL: [kLinAccl][kBlock] sums, tail inputs | [view][wave][kLinPartial]
-    double* const lv_lds = lin_lds + (ACCL ? kLinAccl * kBlock : 0);
+    extern __shared__ __attribute__((aligned(16))) double lin_lds[];  // ACCL: [kLinAccl][kBlock] sums, tail inputs | VLDS: [view][kLinVlds] | [view][wave][kLinPartial]
+    double* const vlds = lin_lds + (ACCL ? kLinAccl * kBlock : 0);
+    double* const lv_lds = vlds + (VLDS ? n_view * kLinVlds : 0);
     double* const accl = lin_lds + threadIdx.x;
+    typedef typename std::conditional<VLDS, const double*, typename ViewPtr<KVIEW>::type>::type VT;
+    constexpr int kVStride = VLDS ? kLinVlds : kViewLin;
+    VT vc;
+    if constexpr (VLDS) {
+        const double* src = bv.view_lin + (int64_t)kViewLin * wd.view0;
+        for (int i = threadIdx.x; i < n_view * kLinVlds; i += kBlock) vlds[i] = src[(i / kLinVlds) * kViewLin + i % kLinVlds];
+        __syncthreads();
+        vc = vlds;
+    } else {
+        vc = (VT)(bv.view_lin + (int64_t)kViewLin * wd.view0);
+    }
     const int64_t dump = bv.SO - kObsBlock + threadIdx.x;
     LmAcc acc;
 #pragma unroll
@@ -477,7 +494,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     for (int j = 0; j < j_cam0; ++j) {
         // (the constants are read where they are used - scalar loads the compiler places next to their instructions; a local
         // copy of all 55 would not fit the scalar register file)
-        typename ViewPtr<KVIEW>::type vl = vc + (int64_t)j * kViewLin;
+        VT vl = vc + (int64_t)j * kVStride;
         const int s = s_cur;
         in.u = u_n;
         in.v = v_n;
@@ -505,7 +522,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         if (lane < kLinPartial) lv_lds[(j * kLinWaves + wave) * kLinPartial + lane] = lane == 0 ? tot : 0.0;
     }
     for (int j = j_cam0; j < n_view; ++j) {
-        typename ViewPtr<KVIEW>::type vl = vc + (int64_t)j * kViewLin;
+        VT vl = vc + (int64_t)j * kVStride;
         const int s = s_cur;
         in.u = u_n;
         in.v = v_n;
@@ -630,15 +647,19 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         bv.lblk_linfail[b] = any_fail ? 1.0 : 0.0;
     }
 }
-template <int WAVES>
+// k_lin_lm<WAVES, VLDS>: <3, true> is the default (166 registers: view constants, landmark sums and tail inputs in LDS, 33 KB per
+// workgroup at five views); <3, false> reads the view constants through scalar loads and keeps the sums in registers (windows with so
+// many views that the LDS copy would cost occupancy); <4, false> is the 128-register experiment (KBA_LIN_WAVES=4).  Same statements,
+// same order, same bits in all of them.
+template <int WAVES, bool VLDS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
-    lin_lm_block<true, WAVES >= 4>(bv, c, b);
+    lin_lm_block<true, WAVES >= 4 || VLDS, VLDS>(bv, c, b);
 }
-// accl: the launch is k_lin_lm<4> (its landmark sums live in LDS)
-__host__ __device__ inline int lin_lm_lds_bytes(int n_view_max, bool accl = false) {
-    return (n_view_max * kLinWaves * kLinPartial + (accl ? kLinAccl * kBlock : 0)) * (int)sizeof(double);
+// accl: the launch keeps its landmark sums in LDS (k_lin_lm<4, .>, k_lin_lm<., true>); vlds: ... and a copy of the view constants
+__host__ __device__ inline int lin_lm_lds_bytes(int n_view_max, bool accl = false, bool vlds = false) {
+    return (n_view_max * (kLinWaves * kLinPartial + (vlds ? kLinVlds : 0)) + (accl || vlds ? kLinAccl * kBlock : 0)) * (int)sizeof(double);
 }
 
 // ------------------------------------------------------------------------------------------ landmarks
@@ -845,8 +866,8 @@ __global__ __launch_bounds__(64 * kWideWaves) void k_schur_wide(BatchView bv, co
 //     indices (slot, state, ground-plane row) are fetched two tiles ahead.
 // One wave per workgroup, no cross-wave synchronisation; `span` consecutive blocks of one class per wave.
 constexpr int kSpBatch = 4;  // k-steps whose panel reads are in flight together
-constexpr int kSpKf = 72;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots | B_k (27): the
-                             // rotation-tangent Jacobian is linear in the landmark, M(q, p) = sum_k p_k B_k, B_k = M(q, e_k) |
+constexpr int kSpKf = 72;    // doubles per free keyframe in LDS: R (9) | Rc (9) | q (4) | scale of its 10 slots | |q|^2 - 1 (+ 26 unused: the B_k of
+                             // rounds 3-5, M(q, p) = sum_k p_k B_k - now M = -2 [Rh p]_x from R, kba_math.hpp:rot_tangent_from_R) |
                              // H (9), h0 (3) of its view (view_xy: xn, yn of an observation are rebuilt from the landmark)
 
 __host__ __device__ inline int schur_lean_ld(int ncol) { return ncol | 1; }  // odd row stride: conflict-free fill
@@ -905,17 +926,11 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
             for (int i = 0; i < 9; ++i) mine[i] = R[i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) mine[18 + i] = pose[i];
+            mine[32] = quat_norm2_minus_1(pose);
         } else if (li < 10) {
             mine[9 + li - 1] = my_view >= 0 ? bv.view_cam[16 * (int64_t)my_view + 4 + li - 1] : 0.0;
         } else if (li == 13) {
             for (int i = 0; i < 12; ++i) mine[59 + i] = my_view >= 0 ? bv.view_lin[(int64_t)kViewLin * my_view + i] : 0.0;
-        } else if (li < 13) {
-            const int k = li - 10;
-            const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
-            double B[9];
-            rot_tangent_jac(pose, e, B);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) mine[32 + 9 * k + i] = B[i];
         }
         if (li < kCamSlots) {
             const int slot = wd.cam0 + my_kl * kCamSlots + li;
@@ -1034,8 +1049,7 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
                 for (int i = 0; i < 72; ++i) fake[i] = fk_c0 + i * fk_c1;
                 const double* mine = fake;
 #endif
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M[i] = p[0] * mine[32 + i] + p[1] * mine[41 + i] + p[2] * mine[50 + i];
+                rot_tangent_from_R(mine, mine[32], p, M);  // M(q, p) = -2 [Rh(q) p]_x: three entries of -2 Rh p instead of 27 products with the B_k
                 view_xy(mine + 59, p, &c4[1], &c4[2]);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block<true>(Ft, mine, M, Bt, mine + 22, Y);

@@ -116,6 +116,20 @@ KBA_HD void rot_tangent_jac(const double* q, const double* p, double* M) {
     M[8] = -Aw2 * z - Ax2 * y + Ay2 * x + Az2 * w;
 }
 
+// The same M from R = R(q):  M(q, p) = -2 [Rh(q) p]_x  with the HOMOGENEOUS rotation polynomial Rh = R(q) + (|q|^2 - 1) I
+// (quat_R is the form 1 - 2 (y^2 + z^2) ...: the two agree on unit quaternions) - a polynomial identity for every q, unit or not
+// (tests/test_emu_vs_oracle.py::test_closed_form_rotation_jacobian_is_the_chain_rule_form holds the two statements against each
+// other).  qq1 = |q|^2 - 1.  12 + 3 operations instead of ~100.
+KBA_HD void rot_tangent_from_R(const double* R, double qq1, const double* p, double* M) {
+    const double y0 = -2.0 * (R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + qq1 * p[0]);
+    const double y1 = -2.0 * (R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + qq1 * p[1]);
+    const double y2 = -2.0 * (R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + qq1 * p[2]);
+    M[0] = 0.0, M[1] = -y2, M[2] = y1;
+    M[3] = y2, M[4] = 0.0, M[5] = -y0;
+    M[6] = -y1, M[7] = y0, M[8] = 0.0;
+}
+KBA_HD double quat_norm2_minus_1(const double* q) { return (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) - 1.0; }
+
 // dR (3x3, row-major) = derivative of the polynomial R(q) along the tangent step delta of the left-multiplying quaternion
 // update (dq = P(q) delta, P = QuaternionParameterization::ComputeJacobian): rot_tangent_jac(q, p, M) M delta == dR p
 // for every p.  One matrix per keyframe instead of one M per observation wherever only the PRODUCT with a step is needed.

@@ -589,26 +589,31 @@ struct limo_ba_batch : Executor {
         listed = n_wl_win;
     }
 
-    // k_lin_lm at 3 waves / SIMD (163 registers).  KBA_LIN_WAVES=4 (read once) takes the 128-register build whose nine running landmark
-    // sums and tail inputs live in LDS (kba_kernels.hip:lin_lm_block ACCL; no spill inside the view loop): its launches are 3 % shorter
-    // (535 vs 554 us per round of 4096 slots) but the bench line is 1.4 % lower with it - two slot groups share the CUs and the
-    // 4-wave build leaves the other group's kernels less room (profiles/r05_experiment_lin_lm_occupancy.txt).  KBA_LIN_LDS_PAD=<bytes>
-    // adds dynamic LDS per workgroup (occupancy experiments: 80000 = two workgroups per CU).
-    int lin_lds_set[2] = {0, 0};
+    // k_lin_lm<3, true>: three waves per SIMD, the window's view constants, the landmark block's running sums and the tail's inputs in
+    // LDS (kba_kernels.hip:lin_lm_block VLDS / ACCL) - the scalar loads of the view constants return out of order, so every use of one
+    // waited for all of them; through LDS the kernel is 7 % shorter (550 -> 513 us per round of 4096 slots, bench line +1.4 %,
+    // profiles/r05_experiment_lin_lm_occupancy.txt).  Batches whose windows have so many views that the copy would cost occupancy
+    // (> 48 KB of LDS per workgroup: more than ~16 views) and KBA_LIN_VLDS=0 (read once) take <3, false>: scalar loads, sums in
+    // registers - same bits.  KBA_LIN_WAVES=4 (read once): the 128-register build, 3 % shorter than <3, false> and 1.4 % lower on the
+    // bench line (two slot groups share the CUs).  KBA_LIN_LDS_PAD=<bytes>: extra dynamic LDS per workgroup (occupancy experiments).
+    int lin_lds_set[3] = {0, 0, 0};
     void launch_lin_lm(int grid, hipStream_t s, const BatchView& v, const int32_t* wl) {
         static const int lw = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
+        static const int want_vlds = std::getenv("KBA_LIN_VLDS") ? std::atoi(std::getenv("KBA_LIN_VLDS")) : 1;
         static const int pad = std::getenv("KBA_LIN_LDS_PAD") ? std::atoi(std::getenv("KBA_LIN_LDS_PAD")) : 0;
         const bool four = lw >= 4;
-        const int lds = lin_lm_lds_bytes(P.Vmax, four) + pad;
-        if (lds > 48 * 1024 && lin_lds_set[four] < lds) {  // (beyond the default dynamic-LDS limit: many views, or the padding)
-            note(hipFuncSetAttribute(four ? (const void*)k_lin_lm<4> : (const void*)k_lin_lm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                 "hipFuncSetAttribute(k_lin_lm)");
-            lin_lds_set[four] = lds;
+        const bool vlds = !four && want_vlds != 0 && lin_lm_lds_bytes(P.Vmax, true, true) <= 48 * 1024;
+        const int which = four ? 2 : vlds ? 1 : 0;
+        const void* fn = four ? (const void*)k_lin_lm<4, false> : vlds ? (const void*)k_lin_lm<3, true> : (const void*)k_lin_lm<3, false>;
+        const int lds = lin_lm_lds_bytes(P.Vmax, four, vlds) + pad;
+        if (lds > 48 * 1024 && lin_lds_set[which] < lds) {  // (beyond the default dynamic-LDS limit: many views, or the padding)
+            note(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(k_lin_lm)");
+            lin_lds_set[which] = lds;
         }
-        if (four)
-            hipLaunchKernelGGL(k_lin_lm<4>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
-        else
-            hipLaunchKernelGGL(k_lin_lm<3>, dim3(grid), dim3(kBlock), lds, s, v, c, wl);
+        const BatchView* vp = &v;
+        const SolveConsts* cp = &c;
+        void* args[] = {(void*)vp, (void*)cp, (void*)&wl};
+        note(hipLaunchKernel(fn, dim3(grid), dim3(kBlock), args, lds, s), "launch k_lin_lm");
     }
 
     void solve_init(int max_iter, int select) override {

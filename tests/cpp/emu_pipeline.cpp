@@ -648,6 +648,15 @@ int emu_ba_evaluate_rows(const limo_ba_window* window, const limo_speed_prior* p
     return LIMO_OK;
 }
 
+// The two statements of the rotation-tangent Jacobian M(q, p) side by side (kba_math.hpp): the chain-rule form
+// rot_tangent_jac (what Problem::Evaluate's restatement uses) and the closed form -2 [Rh(q) p]_x the solve's kernels use.
+void emu_rot_tangent_forms(const double* q, const double* p, double* m_chain, double* m_closed) {
+    double R[9];
+    kba::rot_tangent_jac(q, p, m_chain);
+    kba::quat_R(q, R);
+    kba::rot_tangent_from_R(R, kba::quat_norm2_minus_1(q), p, m_closed);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -256,3 +256,25 @@ def test_window_of_the_drive_with_rejected_steps_at_a_large_radius(oracle, emu):
     assert abs(re["final_cost"] - ro["final_cost"]) <= TOL * abs(ro["final_cost"])
     assert rel_pose_err(we.kf_pose, wo.kf_pose) <= TOL
     assert re["iterations_total"] - re["successful_steps"] >= 5
+
+
+def test_closed_form_rotation_jacobian_is_the_chain_rule_form(emu):
+    """M(q, p) = d(R(q) p)/d(delta) as the kernels of the solve form it, -2 [Rh(q) p]_x from R(q) and |q|^2 - 1, against the chain-rule statement
+    (d(R p)/dq times the plus-Jacobian of the quaternion update) that the Problem::Evaluate path keeps - a polynomial identity,
+    also for quaternions that are not of unit length (the update keeps |q|)."""
+    import ctypes as C
+
+    import emu_ffi
+
+    lib = emu_ffi.load()
+    dp = C.POINTER(C.c_double)
+    lib.emu_rot_tangent_forms.argtypes = [dp, dp, dp, dp]
+    lib.emu_rot_tangent_forms.restype = None
+    rng = np.random.default_rng(11)
+    for k in range(200):
+        q = rng.normal(size=4)
+        q *= (1.0 if k % 2 == 0 else 1.0 + 0.2 * rng.normal()) / np.linalg.norm(q)
+        p = rng.normal(size=3) * 10.0 ** rng.uniform(-1, 2)
+        a, b = np.zeros(9), np.zeros(9)
+        lib.emu_rot_tangent_forms(q.ctypes.data_as(dp), p.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp))
+        assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(a).max())

@@ -61,12 +61,14 @@ def test_results_do_not_depend_on_stale_device_memory():
     assert all(" nan 0 " in l and " unchanged 0 " in l for l in out[0])
 
 
-def test_four_wave_linearisation_gives_the_same_bits():
-    """KBA_LIN_WAVES=4 selects k_lin_lm<4> (128 registers, the landmark block's running sums and the tail's inputs in LDS): the same
-    statements in the same order as the 163-register build, so every checksum of the poison script must be the same to the last bit."""
+def test_linearisation_variants_give_the_same_bits():
+    """k_lin_lm exists three times: <3, true> (default: view constants, landmark sums and tail inputs in LDS), <3, false>
+    (KBA_LIN_VLDS=0: scalar loads, sums in registers - also what batches with many views per window take) and <4, false>
+    (KBA_LIN_WAVES=4: 128 registers, sums in LDS).  The same statements in the same order: every checksum of the poison script must be
+    the same to the last bit whichever one runs."""
     out = []
-    for waves in ("3", "4"):
-        env = dict(os.environ, KBA_LIN_WAVES=waves)
+    for extra in ({}, {"KBA_LIN_VLDS": "0"}, {"KBA_LIN_WAVES": "4"}):
+        env = dict(os.environ, **extra)
         env.pop("KBA_POISON", None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_poison_check.py"), "short"], capture_output=True, text=True, timeout=600,
                            env=env, cwd=ROOT)
@@ -74,4 +76,4 @@ def test_four_wave_linearisation_gives_the_same_bits():
         lines = [l for l in r.stdout.splitlines() if "checksum" in l]
         assert len(lines) >= 3
         out.append(lines)
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]
