@@ -1591,8 +1591,8 @@ __global__ __launch_bounds__(kBlock) void k_trim_select(BatchView bv, SolveConst
 // solve is 9 LM iterations of 8 launches that each run for 4-10 us and wait 3 us for the next one; here the iteration is a
 // few microseconds of work and six barriers.  Same arithmetic, same summation orders as the launches it replaces:
 // the results are bit-identical (tests/test_gpu_parity.py compares the two paths).
-//   * the view constants are written and read in the same launch: plain loads (lin_lm_block<false>), not the scalar
-//     cache the multi-launch kernel reads them through;
+//   * the view constants are written and read in the same launch: the workgroup copies them into LDS with plain loads
+//     (lin_lm_block<false, true, true>), not through the scalar cache;
 //   * the step reduction of k_step_decide is a 64-lane sum: reduce_step(.., n_work = 64) forms exactly that one;
 //   * cap_ticks > 0: wall-clock cap of each solve in ticks of the 100 MHz constant clock (Solver::Options::
 //     max_solver_time_in_seconds as run_schedule applies it: checked once per iteration after the linearisation).
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
                 __syncthreads();
                 KBA_WTICK(1);
                 for (int b = lb0; b < lb1; ++b) {
-                    lin_lm_block<false>(bv, c, b);
+                    lin_lm_block<false, true, true>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
                     __syncthreads();
                 }
                 KBA_WTICK(2);
@@ -1914,7 +1914,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 const bool scale_first = st.compute_scale != 0 || G == 1;
                 // ---- k_lin_lm
                 for (int b = lb0 + g; b < lb1; b += G) {
-                    lin_lm_block<false>(bv, c, b);
+                    lin_lm_block<false, true, true>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
                     __syncthreads();
                 }
                 KBA_CTICK(0);

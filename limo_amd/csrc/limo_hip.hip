@@ -982,7 +982,7 @@ struct limo_ba_batch : Executor {
             if (d.n_lblk > kWgMaxLblk) return false;
         return wg_lds_bytes() <= kCamLdsCapBytes;
     }
-    int wg_lds_bytes() const { return std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax))); }
+    int wg_lds_bytes() const { return std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax, true, true))); }
     void solve_wg() {
         const int lds = wg_lds_bytes();
         set_span(P.n_win);
@@ -1005,7 +1005,7 @@ struct limo_ba_batch : Executor {
     int coop_G = 0, coop_xcd = 1;
     int coop_lds_bytes() const {
         const int wave = (std::max(plain_lds_bytes, leangp_lds_bytes) + 15) / 16 * 16;
-        return std::max(std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax))), (kBlock / 64) * wave);
+        return std::max(std::max(std::max(asm_bytes, solve_bytes), std::max(trim_bytes, lin_lm_lds_bytes(P.Vmax, true, true))), (kBlock / 64) * wave);
     }
     bool coop_solve_applies() {
         if (shard_P != 1 || P.evaluate_only || P.n_win < 1) return false;
