@@ -400,6 +400,9 @@ struct ViewPtr<false> {
 // VLDS: the window's view constants are copied into LDS once per workgroup ([view][kLinVlds], behind the ACCL region) and read from
 // there (ds_read, broadcast) instead of through scalar loads: LDS reads return in order and are waited for one by one, scalar loads
 // return out of order - every use of one waits for ALL of them (s_waitcnt lgkmcnt(0)), ten times per pair.
+#ifndef KBA_COOP_VLDS
+#define KBA_COOP_VLDS 1  // the one-launch kernels (k_solve_wg, k_solve_coop) linearise through LDS as well (0: A/B builds)
+#endif
 constexpr int kLinVlds = 38;  // doubles of a view's constants the linearisation reads (view_consts_item: 37)
 template <bool KVIEW, bool ACCL = false, bool VLDS = false>
 __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveConsts& c, int b) {
@@ -1644,7 +1647,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_wg(BatchView bv, SolveConsts c
                 __syncthreads();
                 KBA_WTICK(1);
                 for (int b = lb0; b < lb1; ++b) {
-                    lin_lm_block<false, true, true>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
+                    lin_lm_block<false, KBA_COOP_VLDS != 0, KBA_COOP_VLDS != 0>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
                     __syncthreads();
                 }
                 KBA_WTICK(2);
@@ -1914,7 +1917,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
                 const bool scale_first = st.compute_scale != 0 || G == 1;
                 // ---- k_lin_lm
                 for (int b = lb0 + g; b < lb1; b += G) {
-                    lin_lm_block<false, true, true>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
+                    lin_lm_block<false, KBA_COOP_VLDS != 0, KBA_COOP_VLDS != 0>(bv, c, b);  // (view constants, sums and tail inputs in LDS: lin_lm_lds_bytes(., true, true))
                     __syncthreads();
                 }
                 KBA_CTICK(0);
