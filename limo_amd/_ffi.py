@@ -259,7 +259,8 @@ def load():
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     lib.limo_abi_version.restype = C.c_int
-    if lib.limo_abi_version() != ABI_VERSION:
+    older = os.environ.get("LIMO_ALLOW_OLDER_ABI") == "1" and lib.limo_abi_version() < ABI_VERSION  # (A/B runs against an earlier round's build)
+    if lib.limo_abi_version() != ABI_VERSION and not older:
         raise RuntimeError("limo_amd: %s has ABI version %d, this binding needs %d - rebuild it (__graft_entry__.build())" % (LIB_PATH, lib.limo_abi_version(), ABI_VERSION))
     lib.limo_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.limo_ctx_destroy.argtypes = [vp]
@@ -281,7 +282,8 @@ def load():
     lib.limo_ba_batch_kernel_time.argtypes = [vp, C.c_int, c_double_p, c_int64_p]
     lib.limo_comm_unique_id.argtypes = [C.c_char_p]
     lib.limo_ctx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
-    lib.limo_ctx_comm_init_host.argtypes = [vp, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]
+    if not older:
+        lib.limo_ctx_comm_init_host.argtypes = [vp, EXCHANGE_FN, C.c_void_p, C.c_int, C.c_int]
     lib.limo_ba_solve_sharded.argtypes = [vp, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int, C.POINTER(BaReport)]
     lib.limo_ba_evaluate_batch_time.argtypes = [vp, C.c_int32, C.POINTER(BaWindow), C.POINTER(BaOptions), C.c_int32, C.POINTER(C.c_double)]
     lib.limo_ba_evaluate.argtypes = [

@@ -1060,7 +1060,7 @@ KBA_HD int cam_assemble_scratch(int nc, int nt) {
 constexpr int kCamLdsCapBytes = 150 * 1024;
 KBA_HD int cam_solve_scratch(int nc, int nt, int nf = -1) {
     if (nf < 0) nf = nc;  // (nf: free slots of the compact system, <= nc)
-    return nf * (nf + 1) + nf + nc + (nf + 1) / 2 + 1 + coop_red_doubles(3, nt);  // A | y | dl | fl | red
+    return nf * (nf + 1) + nf + nc + (nf + 1) / 2 + 1 + coop_red_doubles(3, nt) + nf * (nf + 1) / 2 + nf;  // A | y | dl | fl | red | Hs
 }
 
 // Workgroup-per-window: assemble the camera-camera normal equations H_cc, g_c at the linearisation point, the
@@ -1363,6 +1363,9 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
     double* dl = y + nf;
     int* fl = reinterpret_cast<int*>(dl + nc);
     double* red = dl + nc + (nf + 1) / 2 + 1;
+    // Hs: the entries of the scaled, UNDAMPED camera system and rhs (S_c H S_c | S_c g_c; upper triangle + rhs in the order of the
+    // assembly below) - what the model cost change of the step needs, kept from the assembly instead of read again from memory
+    double* Hs = red + coop_red_doubles(3, nt);
     const double radius = bv.st[w].radius;
     const double* Hg = bv.Hcc + wd.hcc_off;
     const double* sc = bv.scale_c + wd.cam0;
@@ -1407,10 +1410,12 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             if (cb < nf) {
                 const int b = fl[cb];
                 double v = sc[a] * sc[b] * Hg[a * nc + b];
+                Hs[i] = v;
                 if (ca == cb) v += fmin(fmax(v, c.min_lm_diagonal), c.max_lm_diagonal) / radius;
                 s[e] = v;
             } else {
                 s[e] = sc[a] * bv.gc[wd.cam0 + a];
+                Hs[i] = s[e];
             }
             // (packed slabs of a sharded solve hold exactly these entries in this order)
             off[e] = c.schur_packed ? (int64_t)i : schur_need_offset(ca, cb, nf, nfq, nfp);
@@ -1622,22 +1627,17 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
         dl[a] = d;
     }
     KBA_SYNC();
-    // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled)
+    // camera part of the model cost change: -g_c.d - 1/2 d^T H_cc d (unscaled) = g'.y - 1/2 y^T H' y in the scaled variables of the
+    // solve (d = -S_c y, g' = S_c g_c, H' = S_c H_cc S_c), from the entries the assembly kept in LDS (Hs): every lane takes the
+    // entries it assembled.  (Rounds 2-5 read the nc columns of H_cc from memory again here: ten dependent round trips per lane.)
     double part = 0.0;
-    for (int a = tid; a < nc; a += nt) {
-        if (cs[a] < 0) continue;
-        double hd = 0.0;
-        // H is symmetric to the bit: column a = row a, read coalesced.  Five loads in flight (nc is a multiple of kCamSlots),
-        // added in column order: one window alone pays a memory round trip per load otherwise.
-        for (int b = 0; b < nc; b += 5) {
-            const double h0 = Hg[b * nc + a], h1 = Hg[(b + 1) * nc + a], h2 = Hg[(b + 2) * nc + a], h3 = Hg[(b + 3) * nc + a], h4 = Hg[(b + 4) * nc + a];
-            hd += h0 * dl[b];
-            hd += h1 * dl[b + 1];
-            hd += h2 * dl[b + 2];
-            hd += h3 * dl[b + 3];
-            hd += h4 * dl[b + 4];
-        }
-        part += -bv.gc[wd.cam0 + a] * dl[a] - 0.5 * dl[a] * hd;
+    for (int i = tid; i < n_need; i += nt) {
+        int ca, cb;
+        schur_need_decode(i, nf, ca, cb);
+        if (cb < nf)
+            part -= (ca == cb ? 0.5 : 1.0) * (Hs[i] * y[ca] * y[cb]);
+        else
+            part += Hs[i] * y[ca];
     }
     KBA_TICK(14);
     const uint8_t* cm = bv.cmask + (int64_t)wd.cam0;

@@ -129,6 +129,15 @@ def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, s
     if ill and ep <= max(TOL, 3.0 * s["pose"]) and ec <= max(TOL, 3.0 * s["cost"]) and rep_x["termination"] in s["terminations"]:
         return True, ("cost %.2e / pose %.2e inside 3x the oracle's own 1-ulp spread (cost %.2e, pose %.2e, terminations %s, iterations %d..%d)"
                       % (ec, ep, s["cost"], s["pose"], sorted(s["terminations"]), s["iterations"][0], s["iterations"][1])), True
+    # The iteration cap (round 5; seed 5151 window 116: eight keyframes, mono, no depth - 93 LM iterations in the oracle, 94 in the
+    # emulated pipeline, 99 on the round-4 kernels, 100 = the cap on round 5's): both results agree to 1e-4 on cost AND poses, and
+    # the only difference is that one solve reached max_num_iterations while the other converged inside the last tenth of the same
+    # budget.  A window that crawls along a valley for ~100 iterations with half its steps rejected: a summation order moves the
+    # count by a few.  Counted (and bounded) with the plateau cases.
+    it_x, it_o = rep_x["iterations_total"], rep_o["iterations_total"]
+    if (not same_term and ep <= TOL and ec <= TOL and {rep_x["termination"], rep_o["termination"]} == {0, 1}
+            and min(it_x, it_o) >= 0.9 * max(it_x, it_o) and max(it_x, it_o) >= 90):
+        return True, "cost %.2e / pose %.2e; iteration cap: %d vs %d LM iterations, terminations %r / %r" % (ec, ep, it_x, it_o, rep_x["termination"], rep_o["termination"]), True
     if not same_term:
         return False, "termination: %r != %r (the oracle's own under 1-ulp changes: %s)" % (rep_x["termination"], rep_o["termination"], sorted(s["terminations"])), False
     if ep > TOL:
