@@ -1265,12 +1265,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 // ------------------------------------------------------------------------------------------ camera system
 // (three waves per SIMD = three windows per CU: 168 registers; the ground-plane Gram tile of round 5 took the allocation to 172)
 #ifndef KBA_CAM_ASM_WAVES
-#define KBA_CAM_ASM_WAVES 3
+#define KBA_CAM_ASM_WAVES 3  // (0: no attribute - 172 registers, two waves per SIMD)
 #endif
 #ifndef KBA_CAM_SOLVE_WAVES
-#define KBA_CAM_SOLVE_WAVES 3
+#define KBA_CAM_SOLVE_WAVES 0  // 0: no occupancy attribute on k_cam_solve (128 registers).  With amdgpu_waves_per_eu(3, 3) - or (4, 4) - the
+                               // compiler's schedule is 27 % slower (287 vs 226 us per round, profiles/r05_experiment_cam_solve_occupancy.txt)
 #endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_ASM_WAVES, KBA_CAM_ASM_WAVES))) void k_cam_assemble(BatchView bv, SolveConsts c, const int32_t* wl) {
+#if KBA_CAM_ASM_WAVES > 0
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_ASM_WAVES, KBA_CAM_ASM_WAVES))) void k_cam_assemble(
+#else
+__global__ __launch_bounds__(kBlock) void k_cam_assemble(
+#endif
+    BatchView bv, SolveConsts c, const int32_t* wl) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     WinState& st = bv.st[w];
@@ -1311,7 +1317,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_
     }
 }
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_SOLVE_WAVES, KBA_CAM_SOLVE_WAVES))) void k_cam_solve(BatchView bv, SolveConsts c, const int32_t* wl) {
+#if KBA_CAM_SOLVE_WAVES > 0
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KBA_CAM_SOLVE_WAVES, KBA_CAM_SOLVE_WAVES))) void k_cam_solve(
+#else
+__global__ __launch_bounds__(kBlock) void k_cam_solve(
+#endif
+    BatchView bv, SolveConsts c, const int32_t* wl) {
     const int w = wl_at(bv, wl, blockIdx.x);
     if (w < 0) return;
     if (!bv.st[w].active) return;
