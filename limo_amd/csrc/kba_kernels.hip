@@ -655,7 +655,12 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
 // many views that the LDS copy would cost occupancy); <4, false> is the 128-register experiment (KBA_LIN_WAVES=4).  Same statements,
 // same order, same bits in all of them.
 template <int WAVES, bool VLDS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(BatchView bv, SolveConsts c, const int32_t* wl) {
+#ifdef KBA_NOATTR_LIN
+__global__ __launch_bounds__(kBlock) void k_lin_lm(
+#else
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_lin_lm(
+#endif
+    BatchView bv, SolveConsts c, const int32_t* wl) {
     const int b = wl_at(bv, wl, blockIdx.x);
     if (b < 0) return;
     lin_lm_block<true, WAVES >= 4 || VLDS, VLDS>(bv, c, b);
@@ -1255,7 +1260,12 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
     }
 }
 template <int TM, bool GP, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(BatchView bv, const int32_t* wl, int span, int span_gp) {
+#ifdef KBA_NOATTR_SCHUR
+__global__ __launch_bounds__(64) void k_schur_lean(
+#else
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_schur_lean(
+#endif
+    BatchView bv, const int32_t* wl, int span, int span_gp) {
     const int sb = wl_at(bv, wl, blockIdx.x);
     if (sb < 0) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
