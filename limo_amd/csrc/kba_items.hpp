@@ -1422,14 +1422,23 @@ KBA_HD void cam_solve(const BatchView& bv, const SolveConsts& c, int w, int tid,
             dst[e] = ca * lda + cb;
             qs[e] = (ca >= nfq || (cb >= nfq && cb < nf)) ? q_gp : 0;
         }
+        // (branch-free: a skipped term loads the same entry of the LAST slab instead - a line the sum reads anyway - and adds an exact
+        // zero; with a branch around the loads the 16 loads of a step were no longer in flight together, and a window with 79 slabs -
+        // C4 - took 30 % longer per LM iteration)
         int q = 0;
         for (; q + 4 <= n_slab; q += 4)
             for (int e = 0; e < kE; ++e)
-                if (q >= qs[e])
-                    for (int r = 0; r < 4; ++r) acc[e][r] += sp[(int64_t)(q + r) * slab + off[e]];
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = q >= qs[e];
+                    const double v = sp[(int64_t)(on ? q + r : n_slab - 1) * slab + off[e]];
+                    acc[e][r] += on ? v : 0.0;
+                }
         for (; q < n_slab; ++q)
-            for (int e = 0; e < kE; ++e)
-                if (q >= qs[e]) acc[e][0] += sp[(int64_t)q * slab + off[e]];
+            for (int e = 0; e < kE; ++e) {
+                const bool on = q >= qs[e];
+                const double v = sp[(int64_t)(on ? q : n_slab - 1) * slab + off[e]];
+                acc[e][0] += on ? v : 0.0;
+            }
         for (int e = 0; e < kE; ++e)
             if (dst[e] >= 0) A[dst[e]] = s[e] - ((acc[e][0] + acc[e][1]) + (acc[e][2] + acc[e][3]));
     }
