@@ -8,9 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <thread>
+#include <unistd.h>
 
 #include "kba_items.hpp"
 
@@ -19,6 +23,77 @@ namespace kba {
 namespace {
 inline int64_t pad64(int64_t n) {
     return (n + 63) / 64 * 64;
+}
+
+// Host threads of the pack, kept between calls: a 1024-window create runs three parallel passes, and spawning 64 threads for each of
+// them cost more than the passes' own work on a busy 256-thread host.  One parallel region at a time (a second caller - another host
+// thread packing for another context - finds the pool busy and spawns its own threads as before); the caller takes part in the work.
+// The pool is never destroyed (its threads sleep on a condition variable until the process ends) and is rebuilt in a forked child.
+class PackPool {
+public:
+    // runs f(0 .. n - 1) on up to nt threads (the caller included); false = busy, nothing done
+    bool run(unsigned nt, int n, const std::function<void(int)>& f) {
+        std::unique_lock<std::mutex> region(region_, std::try_to_lock);
+        if (!region.owns_lock()) return false;
+        if (pid_ != getpid()) {  // (forked: the parent's threads do not exist here)
+            threads_.clear();    // NOLINT: the std::thread objects of the parent are abandoned, not joined
+            pid_ = getpid();
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while (threads_.size() + 1 < nt) {
+                threads_.emplace_back([this] { worker(); });
+                threads_.back().detach();
+            }
+            fn_ = &f;
+            n_ = n;
+            next_.store(0);
+            want_ = std::min<size_t>(threads_.size(), nt > 0 ? nt - 1 : 0);
+            running_ = (int)want_;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return running_ == 0; });
+        fn_ = nullptr;
+        return true;
+    }
+
+private:
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f = nullptr;
+            int n = 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen && want_ > 0; });
+                seen = gen_;
+                --want_;  // (only as many workers as the region asked for take part)
+                f = fn_;
+                n = n_;
+            }
+            for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--running_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex region_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, running_ = 0;
+    size_t want_ = 0;
+    uint64_t gen_ = 0;
+    pid_t pid_ = getpid();
+};
+PackPool& pack_pool() {
+    static PackPool* p = new PackPool();  // (leaked on purpose: see the class comment)
+    return *p;
 }
 }  // namespace
 
@@ -77,6 +152,8 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             for (int w = 0; w < n; ++w) f(w);
             return;
         }
+        static const bool use_pool = !(std::getenv("KBA_PACK_POOL") && std::atoi(std::getenv("KBA_PACK_POOL")) == 0);
+        if (use_pool && pack_pool().run(nt, n, std::function<void(int)>(f))) return;
         std::atomic<int> next{0};
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < nt; ++t)
@@ -217,14 +294,16 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         std::vector<uint8_t> has_gp(W.n_lm, 0);
         if (!po.pose_only && !po.evaluate_only) {
             const double weight = 10.;
+            double Rk[kMaxKf][9];  // (one rotation matrix per keyframe, not per (landmark, keyframe) pair)
+            for (int k = 0; k < W.n_kf; ++k) quat_R(W.kf_pose + 7 * k, Rk[k]);
             for (int l = 0; l < W.n_lm; ++l) {
                 if (!W.lm_is_ground[l]) continue;
                 double min_dist = std::numeric_limits<double>::max();
                 int kf_id = -1;
                 for (int k = 0; k < W.n_kf; ++k) {
                     if (W.kf_plane_dist[k] < -10.) continue;
-                    double R[9], y[3];
-                    quat_R(W.kf_pose + 7 * k, R);
+                    const double* R = Rk[k];
+                    double y[3];
                     mat3_vec(R, W.lm_pos + 3 * l, y);
                     y[0] += W.kf_pose[7 * k + 4];
                     y[1] += W.kf_pose[7 * k + 5];
@@ -285,13 +364,33 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             vc[14] = cam[8];
             vc[15] = cam[9];
         }
-        // observations sorted by (view, landmark)
+        // observations sorted by (view, landmark).  A (view, landmark) pair occurs at most once in a valid window, so the order is
+        // a placement: a dense table [view][packed landmark] -> observation, read out row by row (a comparison sort of the ~9000
+        // observations of a C2 window through two indirections was the pack's hot spot: 0.5 ms per window and host thread).
+        // Duplicates (rejected below with the same message as before) keep their input order behind the first one.
         std::vector<int> order(W.n_obs);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
-            return perm[W.obs_lm[a]] < perm[W.obs_lm[b]];
-        });
+        {
+            std::vector<int> first((size_t)std::max(1, d.n_view) * std::max(1, W.n_lm), -1);
+            bool dup = false;
+            for (int i = 0; i < W.n_obs; ++i) {
+                int& cell = first[(size_t)obs_view[w][i] * W.n_lm + perm[W.obs_lm[i]]];
+                if (cell < 0)
+                    cell = i;
+                else
+                    dup = true;
+            }
+            if (!dup) {
+                int nxt = 0;
+                for (size_t c = 0; c < first.size(); ++c)
+                    if (first[c] >= 0) order[nxt++] = first[c];
+            } else {  // (an invalid window: the plain stable sort puts the duplicates side by side for the check below)
+                std::iota(order.begin(), order.end(), 0);
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                    if (obs_view[w][a] != obs_view[w][b]) return obs_view[w][a] < obs_view[w][b];
+                    return perm[W.obs_lm[a]] < perm[W.obs_lm[b]];
+                });
+            }
+        }
         d.blk0 = (int)L.blk_view.size();
         std::vector<int> lm_nobs(W.n_lm, 0);
         int depth_blocks = 0;

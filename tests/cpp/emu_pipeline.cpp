@@ -5,6 +5,7 @@
 // lanes and workgroup reductions.  It exists so that the host logic and the kernel arithmetic can be unit-tested
 // against the oracle in the CPU-only test tier (`pytest -m "not gpu"`).  It is NOT part of the product: it is
 // built only into tests/cpp/_build/libkba_emu.so and nothing under limo_amd/ links or loads it.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -646,6 +647,17 @@ int emu_ba_evaluate_rows(const limo_ba_window* window, const limo_speed_prior* p
     }
     *n_rows = rows_from_linearisation(B.P, 0, B.bv.gp_r, B.bv.gp_F, B.bv.gp_E, B.bv.gp_cost, regs.data(), fixed.data(), cap, rows);
     return LIMO_OK;
+}
+
+// pack_windows alone (host-side flattening of a batch: what limo_ba_batch_create spends before the upload), milliseconds
+double emu_pack_ms(int32_t n, const limo_ba_window* windows, const limo_ba_options* o) {
+    PackedBatch P;
+    std::string err;
+    PackOptions po;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = pack_windows(n, windows, *o, po, P, err);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc == LIMO_OK ? ms : -1.0;
 }
 
 // The two statements of the rotation-tangent Jacobian M(q, p) side by side (kba_math.hpp): the chain-rule form

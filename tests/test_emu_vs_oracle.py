@@ -278,3 +278,33 @@ def test_closed_form_rotation_jacobian_is_the_chain_rule_form(emu):
         a, b = np.zeros(9), np.zeros(9)
         lib.emu_rot_tangent_forms(q.ctypes.data_as(dp), p.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp))
         assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(a).max())
+
+
+def test_packing_from_two_host_threads_at_once(emu):
+    """The pack keeps its host threads between calls (one parallel region at a time); a second host thread that packs at the same
+    moment finds the pool busy and takes the spawn path.  Both must produce what a lone call produces."""
+    import threading
+
+    o = default_options()
+    batches = [[synth.make_window(300 + 10 * k + i, n_kf=3 + i % 3, n_lm=150 + 40 * i) for i in range(12)] for k in range(2)]
+    ref = []
+    for b in batches:
+        ws = [w.copy() for w in b]
+        emu.solve_batch(ws, o)
+        ref.append(ws)
+    for _ in range(3):
+        got = [None, None]
+
+        def work(k):
+            ws = [w.copy() for w in batches[k]]
+            emu.solve_batch(ws, o)
+            got[k] = ws
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k in range(2):
+            for a, b in zip(got[k], ref[k]):
+                assert np.array_equal(a.kf_pose, b.kf_pose) and np.array_equal(a.lm_pos, b.lm_pos)
