@@ -372,17 +372,19 @@ __global__ void k_view_consts(BatchView bv) {
 // ------------------------------------------------------------------------------------------ linearisation, landmark-major
 // k_lin_lm: Jacobian evaluation (B1, B2, B5, B6) AND the landmark blocks V = sum E^T E, g = sum E^T r in one pass
 // (kba_items.hpp:lin_lm_lane has the plain statements).  Lane = landmark, loop over the window's views:
-//   * the view's 28 constants come through SCALAR loads: view_lin is read through the constant address space (written by
-//     k_view_consts, the launch before), so the loads stay s_load although plane stores precede them in the loop;
+//   * the view's 37 constants (kba_items.hpp:view_consts_item) are wave-uniform: the workgroup copies its window's constants
+//     into LDS once and reads them from there (VLDS, the default since round 5); the other variant reads view_lin through the
+//     constant address space (written by k_view_consts, the launch before: scalar loads although plane stores precede them);
 //   * the observation of the pair (slot table -> index s -> u, v, d: 12 B) is fetched one view ahead, the slot two ahead;
 //   * branch-free: a landmark that does not see the view (or is out of the problem) runs the same arithmetic on a valid
 //     dummy observation, contributes zeros and stores into the dump area behind the planes;
 //   * the 28 camera-side sums of the view leave each WAVE through one reduce-scatter into the wave's LDS slice (no
 //     barrier in the loop); after the last view one barrier, then lane (view, entry) adds the four slices.
-// Bytes per pair: 4 (slot) + 12 (u, v, d) read, 56 (planes) written; per landmark 32 read + 72 written - the separate
-// view-major linearise + landmark-major accumulate pair moved 101 + 93 B per observation.
+// Bytes per pair: 4 (slot) + 12 (u, v, d) read, 16 (planes au, sd) written; per landmark 32 read + 72 (V, g) + 48 (Bt) written -
+// 79 B per observation under counters (round 5); the separate view-major linearise + landmark-major accumulate pair of round 1
+// moved 101 + 93.
 typedef const double __attribute__((address_space(4))) cdouble;
-constexpr int kLinAccl = 13;  // doubles per lane that k_lin_lm<4> parks in LDS: V 6 | g 3 | Jacobi scale 3 | ground-plane row
+constexpr int kLinAccl = 13;  // doubles per lane that the ACCL variants of k_lin_lm park in LDS: V 6 | g 3 | Jacobi scale 3 | ground-plane row
 // (the body of k_lin_lm for landmark workgroup b; k_solve_wg runs it for the workgroups of its window one after the other)
 // KVIEW: the view constants are read through the constant address space (scalar loads) - only valid when they were
 // written by an EARLIER launch (k_view_consts); k_solve_wg writes them in the same launch and reads them as plain memory.
