@@ -242,9 +242,6 @@ KBA_HD void lin_lm_tail_fetch(const BatchView& bv, int w, int gl, LmTailIn& t) {
     t.gg = bv.lm_gp[gl];
     t.compute_scale = bv.st[w].compute_scale;
     t.radius = bv.st[w].radius;
-#if defined(KBA_ABLATE) && KBA_ABLATE >= 60 && KBA_ABLATE < 80
-    t.compute_scale = 0;  // (ablation builds: the steady-state tail - the scale is read, not computed)
-#endif
     for (int i = 0; i < 3; ++i) t.sc[i] = t.compute_scale ? 1.0 : bv.lm_scale[i * bv.SL + gl];
 }
 // after the views: the landmark's ground-plane row, V / g / Jacobi scale to memory, damping.

@@ -25,9 +25,6 @@
 
 #define KBA_SYNC() __syncthreads()
 #include "kba_items.hpp"
-#ifndef KBA_ABLATE  // (profiling builds only: scripts/gpu_lin_ablate.sh compiles variants of k_lin_lm with pieces left out)
-#define KBA_ABLATE 0
-#endif
 
 namespace kba {
 
@@ -411,11 +408,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
     if (!st.active || !st.need_lin) return;
-#if KBA_ABLATE >= 60 && KBA_ABLATE < 80
-    const bool want_cost = false;  // (ablation builds time the STEADY-STATE body on a first linearisation: no cost value, 70 = nothing left out)
-#else
     const bool want_cost = st.first != 0;  // workgroup-uniform
-#endif
     const WinDesc& wd = bv.win[w];
     const int n_view = wd.n_view;
     const int n = bv.lblk_n[b];
@@ -490,7 +483,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         v_n = bv.obs_v[o];
         d_n = bv.obs_d[o];
     }
-    const int rs_idx = rs28_index(lane), rs14_idx = rs14_index(lane);
+    const int rs14_idx = rs14_index(lane);
     // ---- the leading views of keyframes WITHOUT a free pose block (WinDesc::n_view_fixed0: the Pose-fixed oldest keyframe of
     //      a sliding window): same pipeline, same planes, same landmark-block terms, but no pose Jacobian, no U / g, and only the
     //      cost leaves the wave (the slice's other 27 entries are zeros).  A loop of its own: the general loop below stays one
@@ -544,45 +537,17 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         in.live = have;
         LinLane l;
         double r3[3], c4[4];
-#if KBA_ABLATE == 0
         double J[18];
         if (!lin_obs_core<true>(vl, c, in, want_cost, r3, c4, l.cost, J)) fail = 1;
-#elif KBA_ABLATE == 64 || KBA_ABLATE == 69
-        if (!lin_obs<false>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
-#pragma unroll
-        for (int i = 0; i < 21; ++i) l.U[i] = r3[i % 3] * c4[i % 4];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) l.g[i] = r3[i % 3];
-#elif KBA_ABLATE == 67
-        r3[0] = in.u; r3[1] = in.v; r3[2] = in.d;
-        c4[0] = in.p[0] * vl[0]; c4[1] = in.p[1]; c4[2] = in.p[2]; c4[3] = in.w;
-        l.cost = c4[0];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) l.U[i] = r3[i % 3] * c4[i % 4];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) l.g[i] = r3[i % 3];
-#else
-        if (!lin_obs<true>(vl, c, in, want_cost, r3, c4, l)) fail = 1;
-#endif
         {   // of the four scalars of the factored Jacobian the Schur / back-substitution kernels read au and sd (16 B per pair) and
             // rebuild xn, yn from the landmark and the view (kba_math.hpp:view_xy: the same statements as here); the residual
             // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
             const int64_t o = have ? s : dump;
-#if KBA_ABLATE == 61 || KBA_ABLATE == 69
-            if (c.pad == 12345)
-#endif
-            {
-                bv.obs_c[o] = c4[0];
-                bv.obs_c[bv.SO + o] = c4[3];
-            }
+            bv.obs_c[o] = c4[0];
+            bv.obs_c[bv.SO + o] = c4[3];
         }
-#if KBA_ABLATE == 68 || KBA_ABLATE == 67
-        acc.V[0] += r3[0] * c4[0]; acc.V[1] += r3[1] * c4[1]; acc.g[0] += r3[2] * c4[2]; acc.g[1] += c4[3];
-#else
         accum(vl, r3, c4);  // zeros where the pair does not exist
-#endif
         static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter14 x 2");
-#if KBA_ABLATE == 0
         // the 28 camera-side sums of the view leave the wave in two halves of 14 (register pressure: wave_reduce_scatter14)
         {
             double vals[14];
@@ -596,22 +561,6 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
             const double tot = wave_reduce_scatter14(vals, lane);
             if (rs14_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + 14 + rs14_idx] = tot;
         }
-        continue;
-#endif
-        double vals[kLinPartial];
-        vals[0] = l.cost;
-#pragma unroll
-        for (int i = 0; i < 21; ++i) vals[1 + i] = l.U[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vals[22 + i] = l.g[i];
-#if KBA_ABLATE == 63 || KBA_ABLATE == 69
-        double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < kLinPartial; ++i) tot += vals[i];
-#else
-        const double tot = wave_reduce_scatter28(vals, lane);
-#endif
-        if (rs_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs_idx] = tot;
     }
     if constexpr (ACCL) {
 #pragma unroll
@@ -626,12 +575,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     // the landmark's ground-plane row (B3) is linearised by its own lane right here, before lin_lm_finish adds it to the
     // landmark block (a separate k_gp launch per linearisation did this before: one launch per iteration less)
     if (in_block && tail.gg >= 0) gp_lane(bv, tail.gg, false, bv.gp_cost);
-#if KBA_ABLATE == 62 || KBA_ABLATE == 69
-    if (state == 1 && c.pad == 12345) lin_lm_finish(bv, c, gl, in.p, tail, acc, part);
-    part[0] = acc.V[0] + acc.V[1] + acc.V[2] + acc.V[3] + acc.V[4] + acc.V[5] + acc.g[0] + acc.g[1] + acc.g[2];
-#else
     if (state == 1) lin_lm_finish(bv, c, gl, in.p, tail, acc, part);
-#endif
     __shared__ double lds[8];
     const double m = wave_max(part[0]);
     const double sm = wave_sum(part[1]);
@@ -989,15 +933,6 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         live = st == 1;
         seen = live && slot >= 0;
         att = GP && live && gg >= 0;
-#if KBA_ABLATE == 83
-        if (bv.n_win != -12345) {
-            c4[0] = c4[3] = 1.0 + l0;
-            p[0] = p[1] = p[2] = 2.0 + li;
-            for (int i = 0; i < 6; ++i) Bt[i] = 0.5 + i;
-            for (int i = 0; i < 3; ++i) g3[i] = 1.5;
-            return;
-        }
-#endif
         if (seen) {
             c4[0] = bv.obs_c[slot];
             c4[3] = bv.obs_c[bv.SO + slot];
@@ -1029,9 +964,6 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         fetch_index(kSchurLm, n_st, n_slot, n_gg);
         fetch_data(0, st0, slot0, gg0);
     }
-#if KBA_ABLATE == 84
-    const double fk_c0 = mine[0], fk_c1 = mine[1];
-#endif
     constexpr int NS = GP ? kCamSlots : 6;  // slots of a keyframe this kernel fills
     double yt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // two-tile path: this lane's share of the rhs, slots of its keyframe
     const int mq = li < 8 ? li : li + 8;            // two-tile path: column of lane li in the second operand {0..7, 16..23}
@@ -1048,22 +980,11 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
 #pragma unroll
             for (int i = 0; i < 3 * NS; ++i) Y[i] = 0.0;
             if (seen) {
-#if KBA_ABLATE == 82
-#pragma unroll
-                for (int i = 0; i < 18; ++i) Y[i] = p[i % 3] * c4[0] + Bt[i % 6];
-#else
                 double M[9], Ft[9];
-#if KBA_ABLATE == 84  // (no LDS reads of the keyframe constants: lane-local stand-ins)
-                double fake[72];
-#pragma unroll
-                for (int i = 0; i < 72; ++i) fake[i] = fk_c0 + i * fk_c1;
-                const double* mine = fake;
-#endif
                 rot_tangent_from_R(mine, mine[32], p, M);  // M(q, p) = -2 [Rh(q) p]_x: three entries of -2 Rh p instead of 27 products with the B_k
                 view_xy(mine + 59, p, &c4[1], &c4[2]);
                 ft_build(c4, mine + 9, Ft);
                 schur_pose_block<true>(Ft, mine, M, Bt, mine + 22, Y);
-#endif
                 if (two_tile) {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) yt[a] += Y[a * 3 + 0] * t3[0] + Y[a * 3 + 1] * t3[1] + Y[a * 3 + 2] * t3[2];
@@ -1109,9 +1030,6 @@ __device__ __forceinline__ void schur_lean_group(const BatchView& bv, int sb, in
         schur_wave_sync<COOP>();
         // ---- Z^T Z over the 48 rows (rows of absent landmarks are zero): 12 k-steps, upper tiles
         const double* zp = Z + kq * ld + li;
-#if KBA_ABLATE == 81
-        if (bv.n_win == -12345)
-#endif
         if (TM == 1 || Tt == 1) {  // wave-uniform
 #pragma unroll
             for (int h = 0; h < 12; h += kSpBatch) {

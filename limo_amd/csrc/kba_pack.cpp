@@ -14,7 +14,9 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
+#include <pthread.h>
 #include <unistd.h>
+#include <exception>
 
 #include "kba_items.hpp"
 
@@ -28,17 +30,17 @@ inline int64_t pad64(int64_t n) {
 // Host threads of the pack, kept between calls: a 1024-window create runs three parallel passes, and spawning 64 threads for each of
 // them cost more than the passes' own work on a busy 256-thread host.  One parallel region at a time (a second caller - another host
 // thread packing for another context - finds the pool busy and spawns its own threads as before); the caller takes part in the work.
-// The pool is never destroyed (its threads sleep on a condition variable until the process ends) and is rebuilt in a forked child.
+//   * The caller only waits for the workers that JOINED the region: a worker that wakes after the items have run out (a loaded host)
+//     finds the region closed and goes back to sleep - nobody waits for threads the scheduler has not run yet.
+//   * An exception thrown by f on a worker is caught there and rethrown by run() on the caller (the first one wins).
+//   * The pool is never destroyed (its threads sleep on a condition variable until the process ends).  A forked child gets a FRESH pool
+//     object (pthread_atfork): the parent's threads do not exist there and its mutexes may have been held at the fork.
 class PackPool {
 public:
     // runs f(0 .. n - 1) on up to nt threads (the caller included); false = busy, nothing done
     bool run(unsigned nt, int n, const std::function<void(int)>& f) {
         std::unique_lock<std::mutex> region(region_, std::try_to_lock);
         if (!region.owns_lock()) return false;
-        if (pid_ != getpid()) {  // (forked: the parent's threads do not exist here)
-            threads_.clear();    // NOLINT: the std::thread objects of the parent are abandoned, not joined
-            pid_ = getpid();
-        }
         {
             std::lock_guard<std::mutex> lk(m_);
             while (threads_.size() + 1 < nt) {
@@ -49,14 +51,27 @@ public:
             n_ = n;
             next_.store(0);
             want_ = std::min<size_t>(threads_.size(), nt > 0 ? nt - 1 : 0);
-            running_ = (int)want_;
+            joined_ = 0;
+            open_ = true;
+            error_ = nullptr;
             ++gen_;
         }
         cv_.notify_all();
-        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i);
+        std::exception_ptr mine;
+        try {
+            for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i);
+        } catch (...) {
+            mine = std::current_exception();
+            next_.store(n);  // (the workers stop taking items)
+        }
         std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return running_ == 0; });
+        open_ = false;  // late wakers skip this region
+        done_.wait(lk, [this] { return joined_ == 0; });
         fn_ = nullptr;
+        std::exception_ptr e = mine ? mine : error_;
+        error_ = nullptr;
+        lk.unlock();
+        if (e) std::rethrow_exception(e);
         return true;
     }
 
@@ -68,16 +83,25 @@ private:
             int n = 0;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen && want_ > 0; });
+                cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
-                --want_;  // (only as many workers as the region asked for take part)
+                if (!open_ || want_ == 0) continue;  // closed already, or enough workers: not this region
+                --want_;
+                ++joined_;
                 f = fn_;
                 n = n_;
             }
-            for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*f)(i);
+            std::exception_ptr err;
+            try {
+                for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*f)(i);
+            } catch (...) {
+                err = std::current_exception();
+                next_.store(n);
+            }
             {
                 std::lock_guard<std::mutex> lk(m_);
-                if (--running_ == 0) done_.notify_one();
+                if (err && !error_) error_ = err;
+                if (--joined_ == 0) done_.notify_one();
             }
         }
     }
@@ -86,13 +110,32 @@ private:
     std::vector<std::thread> threads_;
     const std::function<void(int)>* fn_ = nullptr;
     std::atomic<int> next_{0};
-    int n_ = 0, running_ = 0;
+    int n_ = 0, joined_ = 0;
+    bool open_ = false;
     size_t want_ = 0;
     uint64_t gen_ = 0;
-    pid_t pid_ = getpid();
+    std::exception_ptr error_;
 };
+std::atomic<PackPool*> g_pack_pool{nullptr};
+void pack_pool_after_fork() { g_pack_pool.store(nullptr); }  // (the parent's object is abandoned in the child: its threads are not there)
 PackPool& pack_pool() {
-    static PackPool* p = new PackPool();  // (leaked on purpose: see the class comment)
+    PackPool* p = g_pack_pool.load(std::memory_order_acquire);
+    if (!p) {
+        static std::mutex make;
+        static bool hooked = false;
+        // (in a forked child `make` may have been copied in the locked state only if the fork raced the very first call; a process that
+        // forks while it is creating its first batch is outside what this pool supports)
+        std::lock_guard<std::mutex> lk(make);
+        p = g_pack_pool.load(std::memory_order_acquire);
+        if (!p) {
+            p = new PackPool();  // (leaked on purpose: see the class comment)
+            if (!hooked) {
+                pthread_atfork(nullptr, nullptr, pack_pool_after_fork);
+                hooked = true;
+            }
+            g_pack_pool.store(p, std::memory_order_release);
+        }
+    }
     return *p;
 }
 }  // namespace

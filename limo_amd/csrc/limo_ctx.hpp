@@ -27,6 +27,8 @@ struct limo_ctx {
     bool has_transport() const { return comm != nullptr || xfn != nullptr; }
     long long exchange_stats[3] = {0, 0, 0};  // last landmark-sharded solve: exchange steps, bytes per rank, LM iterations
     long long coop_fallbacks = 0;           // one-launch solves whose barrier timed out and that were redone as a launch sequence
+    static constexpr int kCoopRetryAfter = 64;  // solves through the launch sequence before a benched one-launch path is tried again
+    int coop_benched = 0;                   // ... counted here
     int coop_strikes = 0;                   // ... in a row: after three the context stops taking the one-launch path (something shares the GPU)
     // Device blocks released by finished batches, kept for the next one (size class = power of two): a single-window
     // call (limo_ba_solve, limo_ba_adjust_pose_only) would otherwise spend more time in hipMalloc / hipFree than in

@@ -400,11 +400,18 @@ struct limo_ba_batch : Executor {
     // (not a function of how many windows are in flight): the partial-slab layout of a window, and with it the order in
     // which its Schur complement is summed, is then the same alone and inside any batch - single-window and batched
     // solves give the same bits.  (Measured at 1024 C2 windows: span 2 is as fast as 4, span 1 costs 2 %.)
+    // The spans also decide which slabs of S_part are "plain" (written in part only, kba_kernels.hip:schur_lean_group) - a slab must keep
+    // its class for the life of the batch, so the A/B environment variables are read ONCE per batch, at its first solve.
+    int span_env = 0, span_gp_env = 0;  // 0: not read yet
     void set_span(int) {
-        c.schur_span = 2;
-        c.schur_span_gp = 1;
-        if (const char* e = std::getenv("KBA_SPAN_GP")) c.schur_span_gp = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("KBA_SPAN")) c.schur_span = std::max(1, std::atoi(e));  // A/B timing aids
+        if (span_env == 0) {
+            span_env = 2;
+            span_gp_env = 1;
+            if (const char* e = std::getenv("KBA_SPAN_GP")) span_gp_env = std::max(1, std::atoi(e));
+            if (const char* e = std::getenv("KBA_SPAN")) span_env = std::max(1, std::atoi(e));  // A/B timing aids
+        }
+        c.schur_span = span_env;
+        c.schur_span_gp = span_gp_env;
         if (shard_P > 1) c.schur_span = c.schur_span_gp = 1;  // Schur blocks are cut at shard boundaries
         c.schur_nslab = shard_P > 1 ? shard_P : 0;
         c.schur_packed = shard_P > 1 ? 1 : 0;
@@ -466,14 +473,22 @@ struct limo_ba_batch : Executor {
             ctx->xhost_cap = 0;
             if (hipHostMalloc((void**)&ctx->xhost, sizeof(double) * need) != hipSuccess) {
                 note(hipErrorOutOfMemory, "hipHostMalloc(exchange staging)");
+                std::vector<double> z(need, 0.0);  // (the peers are still met: see below)
+                ctx->xfn(z.data(), z.data() + count, (long long)count, kind, ctx->xuser);
                 return;
             }
             ctx->xhost_cap = need;
         }
-        note(hipMemcpyAsync(ctx->xhost, src, sizeof(double) * count, hipMemcpyDeviceToHost, s), "exchange: device -> host");
-        note(hipStreamSynchronize(s), "exchange: sync");
-        if (rc != LIMO_OK) return;
+        // The transport is a COLLECTIVE: a rank that skipped it after a local error would leave its peers blocked in it for ever.  So
+        // the call is made in every case - after an error with a zeroed contribution - and only the device copies are skipped; the
+        // solve of this rank ends with LIMO_ERR_RUNTIME, the peers' solves end (with a result that misses this rank's share).
+        if (rc == LIMO_OK) {
+            note(hipMemcpyAsync(ctx->xhost, src, sizeof(double) * count, hipMemcpyDeviceToHost, s), "exchange: device -> host");
+            note(hipStreamSynchronize(s), "exchange: sync");
+        }
+        if (rc != LIMO_OK) std::memset(ctx->xhost, 0, sizeof(double) * count);
         ctx->xfn(ctx->xhost, ctx->xhost + count, (long long)count, kind, ctx->xuser);
+        if (rc != LIMO_OK) return;
         note(hipMemcpyAsync(dst, ctx->xhost + count, sizeof(double) * n_out, hipMemcpyHostToDevice, s), "exchange: host -> device");
         note(hipStreamSynchronize(s), "exchange: sync");  // (the staging buffer is reused by the next step)
     }
@@ -1332,8 +1347,10 @@ int limo_ba_batch_solve(limo_ba_batch* b, const limo_ba_options* opts) {
         b->solve_wg();
     // (the cooperative solve only from the pristine state - its timeout recovery restores THAT state, a warm re-solve would lose the
     // first solve's result - and not any more in a context whose launches keep timing out: something shares the GPU)
-    else if (one_launch && b->pristine && ctx->coop_strikes < 3 && b->coop_solve_applies() && b->solve_coop())
-        ;
+    // (three strikes switch the one-launch path off - but not for the life of the context: after kCoopRetryAfter solves through the launch
+    // sequence ONE more attempt is made (a profiler session or a neighbour process that has gone away); its success clears the strikes)
+    else if (one_launch && b->pristine && b->coop_solve_applies() && (ctx->coop_strikes < 3 || ++ctx->coop_benched >= limo_ctx::kCoopRetryAfter) && b->solve_coop())
+        ctx->coop_benched = 0;
     else
         launch_sequence();
     b->pristine = false;

@@ -2,6 +2,7 @@
 // keyframe_bundle_adjustment/include/keyframe_bundle_adjustment/keyframe.hpp:27-196 and src/keyframe.cpp.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <iterator>
 
 #include "definitions.hpp"
@@ -120,16 +121,22 @@ public:
         CameraId cam;
         const Measurement* m;
     };
+    // Epochs are drawn from ONE process-wide counter: two threads that take turns on the same objects (a multi-threaded spinner
+    // behind a lock) can never see equal epochs, so a table built in one thread's call is not trusted in another thread's call.
     struct MeasurementTableScope {  // opened by the public entry points; nests (the outermost call defines the epoch)
         MeasurementTableScope() {
-            if (depth()++ == 0) ++epoch();
+            if (depth()++ == 0) epoch() = nextEpoch().fetch_add(1, std::memory_order_relaxed) + 1;
         }
         ~MeasurementTableScope() { --depth(); }
         MeasurementTableScope(const MeasurementTableScope&) = delete;
         MeasurementTableScope& operator=(const MeasurementTableScope&) = delete;
-        static unsigned long long& epoch() {
+        static unsigned long long& epoch() {  // the epoch of the call this thread is in
             static thread_local unsigned long long e = 0;
             return e;
+        }
+        static std::atomic<unsigned long long>& nextEpoch() {
+            static std::atomic<unsigned long long> n{1};  // (1 is the "built once" mark of frozen tables: never handed out)
+            return n;
         }
         static int& depth() {
             static thread_local int d = 0;

@@ -11,6 +11,7 @@
 #include <functional>
 #include <random>
 #include <string>
+#include <thread>
 #include <tuple>
 
 #include "../../limo_amd/kba/bundle_adjuster_keyframes.hpp"
@@ -929,6 +930,26 @@ static void test_measurement_table() {
         kf.measurements_[3][0] = FeaturePoint(7.f, 8.f);
         Keyframe::MeasurementTableScope scope;
         CHECK(agrees(kf) && kf.measuredIds().size() == kf.measurements_.size());
+    }
+    {   // two threads taking turns on one keyframe (a multi-threaded spinner behind a lock): the first call of thread A and the first
+        // call of thread B must not share an epoch, or B would trust rows that point into nodes erased between the two calls
+        unsigned long long ea = 0, eb = 0;
+        std::thread ta([&] {
+            Keyframe::MeasurementTableScope scope;
+            ea = Keyframe::MeasurementTableScope::epoch();
+            CHECK(agrees(kf));
+        });
+        ta.join();
+        kf.measurements_.erase(3);
+        kf.measurements_[4][0] = FeaturePoint(9.f, 1.f);
+        bool ok_b = false;
+        std::thread tb([&] {
+            Keyframe::MeasurementTableScope scope;
+            eb = Keyframe::MeasurementTableScope::epoch();
+            ok_b = agrees(kf) && kf.measuredIds().size() == kf.measurements_.size();
+        });
+        tb.join();
+        CHECK(ok_b && ea != 0 && eb != 0 && ea != eb);
     }
     // a frozen keyframe keeps its table across calls (the owner's promise); assignMeasurements() takes the promise back
     Keyframe frozen(kf);

@@ -221,3 +221,21 @@ def evaluate(window, opts, apply_loss=True):
     if rc != 0:
         raise RuntimeError("emu_ba_evaluate rc=%d" % rc)
     return float(cost[0]), res, jp, jl, valid
+
+
+MATH_PROBE_LIB = os.path.join(_HERE, "cpp", "_build", "libmath_probe.so")
+
+
+def build_math_probe(force=False):
+    """tests/cpp/math_probe.hip: kba_math.hpp's reciprocal helpers as gfx950 kernels (tests/test_gpu_math.py holds them against
+    IEEE arithmetic).  Cross-compiles without a GPU; the .so travels with the snapshot."""
+    import shutil
+
+    os.makedirs(os.path.dirname(MATH_PROBE_LIB), exist_ok=True)
+    src = os.path.join(_HERE, "cpp", "math_probe.hip")
+    deps = [src, os.path.join(_HERE, "..", "limo_amd", "csrc", "kba_math.hpp")]
+    if not force and os.path.exists(MATH_PROBE_LIB) and all(os.path.getmtime(MATH_PROBE_LIB) >= os.path.getmtime(d) for d in deps):
+        return MATH_PROBE_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", MATH_PROBE_LIB, src])
+    return MATH_PROBE_LIB

@@ -93,8 +93,13 @@ def well_posed(w, min_obs=8):
     return int(np.bincount(w.obs_kf, minlength=w.n_kf).min()) >= min_obs
 
 
+STRICT, BY_SPREAD, BY_CAP = 0, 1, 2  # which clause of the rule accepted a window (third value of check_parity)
+
+
 def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, solve_o):
-    """x = the implementation under test, o = the oracle.  Returns (ok, detail string, accepted by the 1-ulp spread)."""
+    """x = the implementation under test, o = the oracle.  Returns (ok, detail string, clause): clause = STRICT (0, also for the
+    weak checks of ill-posed windows), BY_SPREAD (1: inside 3x the oracle's own 1-ulp spread) or BY_CAP (2: the iteration-cap
+    clause).  The trimmed landmark SETS are compared before any clause: every accepted window has the oracle's set."""
     if not well_posed(w):
         for k in ("n_depth_blocks", "n_repr_blocks", "n_gp_blocks", "n_trimmed_landmarks"):
             if rep_x[k] != rep_o[k]:
@@ -128,16 +133,19 @@ def check_parity(w, rep_x, end_x, trimmed_x, solve_x, rep_o, end_o, trimmed_o, s
     # the termination type has to be one the oracle itself shows for this window - in every case
     if ill and ep <= max(TOL, 3.0 * s["pose"]) and ec <= max(TOL, 3.0 * s["cost"]) and rep_x["termination"] in s["terminations"]:
         return True, ("cost %.2e / pose %.2e inside 3x the oracle's own 1-ulp spread (cost %.2e, pose %.2e, terminations %s, iterations %d..%d)"
-                      % (ec, ep, s["cost"], s["pose"], sorted(s["terminations"]), s["iterations"][0], s["iterations"][1])), True
+                      % (ec, ep, s["cost"], s["pose"], sorted(s["terminations"]), s["iterations"][0], s["iterations"][1])), BY_SPREAD
     # The iteration cap (round 5; seed 5151 window 116: eight keyframes, mono, no depth - 93 LM iterations in the oracle, 94 in the
     # emulated pipeline, 99 on the round-4 kernels, 100 = the cap on round 5's): both results agree to 1e-4 on cost AND poses, and
     # the only difference is that one solve reached max_num_iterations while the other converged inside the last tenth of the same
     # budget.  A window that crawls along a valley for ~100 iterations with half its steps rejected: a summation order moves the
-    # count by a few.  Counted (and bounded) with the plateau cases.
+    # count by a few.  A KNOWN DEVIATION from the reference's observable behaviour (Ceres reports max_num_iterations as
+    # NO_CONVERGENCE, robust_solving.hpp:93-108; a caller that branches on the termination type sees it), caused by arithmetic that
+    # is not the oracle's to the last bit (summation orders; since round 5 the non-IEEE reciprocals) - counted on its own
+    # (BY_CAP), at most one window per sweep.
     it_x, it_o = rep_x["iterations_total"], rep_o["iterations_total"]
     if (not same_term and ep <= TOL and ec <= TOL and {rep_x["termination"], rep_o["termination"]} == {0, 1}
             and min(it_x, it_o) >= 0.9 * max(it_x, it_o) and max(it_x, it_o) >= 90):
-        return True, "cost %.2e / pose %.2e; iteration cap: %d vs %d LM iterations, terminations %r / %r" % (ec, ep, it_x, it_o, rep_x["termination"], rep_o["termination"]), True
+        return True, "cost %.2e / pose %.2e; iteration cap: %d vs %d LM iterations, terminations %r / %r" % (ec, ep, it_x, it_o, rep_x["termination"], rep_o["termination"]), BY_CAP
     if not same_term:
         return False, "termination: %r != %r (the oracle's own under 1-ulp changes: %s)" % (rep_x["termination"], rep_o["termination"], sorted(s["terminations"])), False
     if ep > TOL:
