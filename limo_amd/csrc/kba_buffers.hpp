@@ -25,6 +25,10 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     bv.SO = P.SO;
     bv.SL = P.SL;
     bv.SG = P.SG;
+    bv.SD = P.SD;
+    bv.echunk = nullptr;
+    bv.n_echunk = P.n_echunk;
+    bv.pad_e = 0;
     const size_t D = sizeof(double), I = sizeof(int32_t);
     const size_t TK = (size_t)(P.TK > 0 ? P.TK : 1), TL = (size_t)(P.TL > 0 ? P.TL : 1), TO = (size_t)(P.TO > 0 ? P.TO : 1),
                  TV = (size_t)(P.TV > 0 ? P.TV : 1), TG = (size_t)(P.TG > 0 ? P.TG : 1);
@@ -82,10 +86,12 @@ void for_each_buffer(const PackedBatch& P, BatchView& bv, F f) {
     KBA_BUF(gp_E, (size_t)P.SG * 3 * D, nullptr);
     KBA_BUF(gp_cost, TG * D, nullptr);
     KBA_BUF(gp_cost_c, TG * D, nullptr);
-    KBA_BUF(obs_r, (size_t)(P.evaluate_only ? P.SO * 3 : 1) * D, nullptr);  // residual planes: limo_ba_evaluate only
+    // evaluate-only batches (limo_ba_evaluate): rows u, v over the observations + the depth row over the depth observations
+    KBA_BUF(obs_r, (size_t)(P.evaluate_only ? P.SO * 2 + P.SD : 1) * D, nullptr);
     KBA_BUF(obs_c, (size_t)(P.evaluate_only ? 1 : P.SO * 2) * D, nullptr);
-    KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 18 : 1) * D, nullptr);
-    KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 9 : 1) * D, nullptr);
+    KBA_BUF(obs_Jp, (size_t)(P.evaluate_only ? P.SO * 12 + P.SD * 6 : 1) * D, nullptr);
+    KBA_BUF(obs_Jl, (size_t)(P.evaluate_only ? P.SO * 6 + P.SD * 3 : 1) * D, nullptr);
+    if (P.evaluate_only) KBA_BUF(echunk, (size_t)std::max(1, P.n_echunk) * sizeof(EvalChunk), P.echunk.empty() ? nullptr : P.echunk.data());
     KBA_BUF(lv_part, (size_t)(P.lvpart_total > 0 ? P.lvpart_total : 1) * D, nullptr);
     KBA_BUF(lblk_linfail, NL * D, nullptr);
     KBA_BUF(lm_V, (size_t)P.SL * 6 * D, nullptr);

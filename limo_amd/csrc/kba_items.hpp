@@ -50,10 +50,12 @@ struct LinLane {
 //   wave-uniform operands like the 27 of the per-view matrices C_k = Rc M(q, e_k) that rounds 5's first sessions used, but 9
 //   constants per view instead of 27 (a pair's view constants are 37 doubles instead of 55: what the lane waits for in k_lin_lm).
 // In k_lin_lm every lane of a wave is at the same view of the same window, so these are wave-uniform (scalar registers).
+KBA_HD void view_consts_compute(const double* cam, const double* pose, double* vl);
 KBA_HD void view_consts_item(const BatchView& bv, int view) {
-    const double* cam = bv.view_cam + 16 * (int64_t)view;
-    const double* pose = bv.pose + 7 * (int64_t)bv.view_kf[view];
-    double* vl = bv.view_lin + (int64_t)kViewLin * view;
+    view_consts_compute(bv.view_cam + 16 * (int64_t)view, bv.pose + 7 * (int64_t)bv.view_kf[view], bv.view_lin + (int64_t)kViewLin * view);
+}
+// cam = the view's 16 camera doubles (f, cx, cy, -, Rc 9, tc 3), pose = its keyframe's 7; vl receives the 37 constants
+KBA_HD void view_consts_compute(const double* cam, const double* pose, double* vl) {
     double R[9];
     quat_R(pose, R);
     mat3_mul(cam + 4, R, vl);
@@ -134,6 +136,28 @@ KBA_HD void lin_cam_entries(const double* J, const double* r3, double cost, doub
     }
 }
 
+// Jp of an observation, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = Rc [y]_x,  y = -2 Rh(q) p, from the view's
+// constants and the scalars (au, xn, yn, sd) of the factored form (shared by the solve's linearisation and the materialised pass)
+template <class VP>
+KBA_HD void lin_pose_jac(VP vl, const double* p, double au, double xn, double yn, double sd, double* J) {
+    const double p0 = p[0], p1 = p[1], p2 = p[2];
+    const double a1 = au * xn, a2 = au * yn;
+    const double yv[3] = {vl[28] * p0 + vl[29] * p1 + vl[30] * p2, vl[31] * p0 + vl[32] * p1 + vl[33] * p2, vl[34] * p0 + vl[35] * p1 + vl[36] * p2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        constexpr int kNext[3] = {1, 2, 0};
+        const int j1 = kNext[j], j2 = kNext[j1];
+        const double g0 = vl[12 + j1] * yv[j2] - vl[12 + j2] * yv[j1];
+        const double g1 = vl[15 + j1] * yv[j2] - vl[15 + j2] * yv[j1];
+        const double g2 = vl[18 + j1] * yv[j2] - vl[18 + j2] * yv[j1];
+        J[0 + j] = au * g0 - a1 * g2;
+        J[6 + j] = au * g1 - a2 * g2;
+        J[12 + j] = sd * g2;
+        J[3 + j] = au * vl[12 + j] - a1 * vl[18 + j];
+        J[9 + j] = au * vl[15 + j] - a2 * vl[18 + j];
+        J[15 + j] = sd * vl[18 + j];
+    }
+}
 // lin_obs_core: everything of lin_obs up to the pose Jacobian J (filled when CAM); lin_obs adds the camera-side sums.
 template <bool CAM = true, class VP = const double*>
 KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J);
@@ -149,7 +173,6 @@ KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost
 }
 template <bool CAM, class VP>
 KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J) {
-    const double p0 = in.p[0], p1 = in.p[1], p2 = in.p[2];
     double xn, yn, iz, z2;  // (z2 = 1 inside the failure band: keeps the arithmetic finite; masked below)
     const bool z_ok = view_xy(vl, in.p, &xn, &yn, &iz, &z2);
     const bool ok = in.live != 0 && z_ok;
@@ -182,24 +205,73 @@ KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want
     c4[2] = yn;
     c4[3] = sd;
     if (!CAM) return z_ok || in.live == 0;
-    const double a1 = au * xn, a2 = au * yn;
-    // Jp, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = Rc [y]_x,  y = -2 Rh(q) p
-    const double yv[3] = {vl[28] * p0 + vl[29] * p1 + vl[30] * p2, vl[31] * p0 + vl[32] * p1 + vl[33] * p2, vl[34] * p0 + vl[35] * p1 + vl[36] * p2};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        constexpr int kNext[3] = {1, 2, 0};
-        const int j1 = kNext[j], j2 = kNext[j1];
-        const double g0 = vl[12 + j1] * yv[j2] - vl[12 + j2] * yv[j1];
-        const double g1 = vl[15 + j1] * yv[j2] - vl[15 + j2] * yv[j1];
-        const double g2 = vl[18 + j1] * yv[j2] - vl[18 + j2] * yv[j1];
-        J[0 + j] = au * g0 - a1 * g2;
-        J[6 + j] = au * g1 - a2 * g2;
-        J[12 + j] = sd * g2;
-        J[3 + j] = au * vl[12 + j] - a1 * vl[18 + j];
-        J[9 + j] = au * vl[15 + j] - a2 * vl[18 + j];
-        J[15 + j] = sd * vl[18 + j];
-    }
+    lin_pose_jac(vl, in.p, au, xn, yn, sd, J);
     return z_ok || in.live == 0;
+}
+
+// ---- the MATERIALISED evaluation of one observation (Problem::Evaluate semantics; k_evaluate, SURVEY 8d's graded pass): residual
+// r (3), J_pose (3 x 6 row-major, tangent: rotation 3 | translation 3), J_point (3 x 3) and the cost, all multiplied by sqrt(rho') of
+// the block's loss when apply_loss - ReprojectionErrorWithQuaternions + LandmarkDepthError (cost_functors_ceres.hpp:53-222) through
+// the statements of the solve's linearisation: view constants, rcp_nr / rsqrt_nr, the closed-form rotation block.  Without the loss:
+// sqrt(rho') = 1, cost = 1/2 |r|^2.  Returns false where the functor fails (|z| < 0.01); the outputs are zero then.
+struct EvalOut {
+    double r[3], Jp[18], Jl[9], cost;
+};
+// Two stages, so that a kernel can finish with everything it LOADED (landmark, weight, measurement) before it issues its first store
+// (gfx950 counts loads and stores in one counter: a load waited for behind a store waits for the store's write acknowledge too):
+//   eval_obs_head: projection, residual, loss -> the scalars (au, xn, yn, sd) of the factored rows, r, cost
+//   eval_obs_rows: J_pose, J_point from the scalars, the landmark and the view's constants
+struct EvalHead {
+    double au, xn, yn, sd, r[3], cost;
+    bool ok;
+};
+template <class VP>
+KBA_HD void eval_obs_head(VP vl, const SolveConsts& c, const double* p, double w, float u, float v, float d, bool apply_loss, EvalHead& h) {
+    double xn, yn, iz, z2;
+    const bool ok = view_xy(vl, p, &xn, &yn, &iz, &z2);
+    const double ru = vl[25] * xn + (vl[26] - static_cast<double>(u));
+    const double rv = vl[25] * yn + (vl[27] - static_cast<double>(v));
+    const bool has_d = d > 0.0f;
+    const double rd = has_d ? z2 - static_cast<double>(d) : 0.0;
+    const double s_uv = ru * ru + rv * rv, s_d = rd * rd;
+    double su = 1.0, sd = 1.0, cost;
+    if (apply_loss) {  // (uniform over the launch)
+        const double sum_uv = fmin(1.0 + s_uv * c.inv_a_rep2, 1e300);
+        const double sum_d = fmin(1.0 + s_d * c.inv_a_dep2, 1e300);
+        const double sw = sqrt(w);
+        su = sw * rsqrt_nr(sum_uv);
+        sd = sw * rsqrt_nr(sum_d);
+        cost = 0.5 * (w * ((c.a_rep * c.a_rep) * log(sum_uv)));
+        cost += has_d ? 0.5 * (w * ((c.a_dep * c.a_dep) * log(sum_d))) : 0.0;
+    } else {
+        cost = 0.5 * s_uv + 0.5 * s_d;
+    }
+    su = ok ? su : 0.0;
+    sd = ok && has_d ? sd : 0.0;
+    h.cost = ok ? cost : 0.0;
+    h.r[0] = su * ru;
+    h.r[1] = su * rv;
+    h.r[2] = sd * rd;
+    h.au = su * (vl[25] * iz);
+    h.xn = xn;
+    h.yn = yn;
+    h.sd = sd;
+    h.ok = ok;
+}
+template <class VP>
+KBA_HD void eval_obs_rows(VP vl, const double* p, const EvalHead& h, double* Jp, double* Jl) {
+    lin_pose_jac(vl, p, h.au, h.xn, h.yn, h.sd, Jp);
+    const double c4[4] = {h.au, h.xn, h.yn, h.sd};
+    ft_build(c4, vl, Jl);  // E = c^T H, H = Rc R(q)
+}
+template <class VP>
+KBA_HD bool eval_obs(VP vl, const SolveConsts& c, const double* p, double w, float u, float v, float d, bool apply_loss, EvalOut& o) {
+    EvalHead h;
+    eval_obs_head(vl, c, p, w, u, v, d, apply_loss, h);
+    for (int i = 0; i < 3; ++i) o.r[i] = h.r[i];
+    o.cost = h.cost;
+    eval_obs_rows(vl, p, h, o.Jp, o.Jl);
+    return h.ok;
 }
 
 // ---- landmark-major linearisation (k_lin_lm): a lane holds ONE landmark and walks over the window's views.

@@ -2051,37 +2051,84 @@ __global__ void k_lm_owned(BatchView bv, double* out, int rank, int n_shards, in
 }
 
 // ------------------------------------------------------------------------------------------ evaluate (Problem::Evaluate)
-// Writes per-observation residuals / Jacobians (fully materialised) into the planes and per-observation cost / valid
-// flags.
-__device__ __forceinline__ void evaluate_lane(const BatchView& bv, const SolveConsts& c, int b, int t, int apply_loss,
-                                              double* obs_cost, uint8_t* obs_valid) {
-    if (t >= bv.blk_n[b]) return;
-    const int view = bv.blk_view[b];
-    const int64_t o = bv.blk_obs0[b] + t;
-    const int gl = bv.obs_lm[o];
-    const double* cam = bv.view_cam + 16 * (int64_t)view;
-    ObsOut oo;
-    const bool ok = obs_residual_jacobian(bv.pose + 7 * (int64_t)bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1], cam[2],
-                                          bv.lm + 3 * (int64_t)gl, bv.obs_u[o], bv.obs_v[o], bv.obs_d[o], bv.lm_weight[gl],
-                                          c.a_rep, c.a_dep, apply_loss != 0, &oo);
-    if (!ok) {
-        for (int i = 0; i < 3; ++i) oo.r[i] = 0.0;
-        for (int i = 0; i < 18; ++i) oo.Jp[i] = 0.0;
-        for (int i = 0; i < 9; ++i) oo.Jl[i] = 0.0;
-        oo.cost = 0.0;
-    }
-    for (int i = 0; i < 3; ++i) bv.obs_r[i * bv.SO + o] = oo.r[i];
-    for (int i = 0; i < 18; ++i) bv.obs_Jp[i * bv.SO + o] = oo.Jp[i];
-    for (int i = 0; i < 9; ++i) bv.obs_Jl[i * bv.SO + o] = oo.Jl[i];
-    obs_cost[o] = oo.cost;
-    obs_valid[o] = ok ? 1 : 0;
+// k_evaluate: the MATERIALISED Jacobian pass SURVEY 8d grades - per observation the residual, J_pose (tangent space) and J_point
+// written out (ReprojectionErrorWithQuaternions + LandmarkDepthError through AutoDiffCostFunction in the reference,
+// cost_functors_ceres.hpp:53-222, bundle_adjuster_keyframes.cpp:584-620).  A pure streaming-store kernel, so it is laid out for the
+// store path (scripts/micro/store_stream.hip: thirty planes of 8-byte stores run at 5.6 TB/s WHEN every wave's 512 bytes of a plane
+// are aligned; profiles/r06_experiment_evaluate_store_path.txt has the variants that were not):
+//   * it writes the rows that EXIST: rows u, v of every observation (r 2 + J_pose 12 + J_point 6 doubles = 160 B) into planes over
+//     the observations, and the depth row (1 + 6 + 3 doubles = 80 B) of the observations that HAVE a depth into compact planes over
+//     the depth observations (BatchView::obs_r / obs_Jp / obs_Jl) - the algorithmic unit, 212 B + 84 B per depth observation, is
+//     what moves (the round-2 kernel wrote 248 B for every observation);
+//   * the unit of work is a WAVE on an ALIGNED range of 64 observations clipped to one observation block (EvalChunk, from the
+//     pack; a range that straddles two views is two chunks): a wave's store to a plane is four whole 128-byte lines - no LDS, no
+//     barrier; the rank of a depth observation among the batch's = the chunk's first rank + one ballot;
+//   * workgroups are dealt to the XCDs in contiguous runs of chunks (block b runs on XCD b % 8): the lines two neighbouring waves
+//     share - a compact depth plane's run ends anywhere - meet in ONE L2 and leave it whole;
+//   * the view's constants (k_view_consts_all, the launch before) are wave-uniform: scalar loads, scalar registers; the arithmetic
+//     is the solve's (eval_obs_head / _rows: rcp_nr / rsqrt_nr, closed-form rotation block), not round 2's IEEE chain rule;
+//   * everything LOADED is consumed before the first store is issued (one counter for loads and stores on gfx950: a load waited
+//     for behind a store waits for the store's acknowledge);
+//   * the cost leaves the kernel as ONE double per wave (chunk_cost, fixed summation order), the validity flags as bytes.
+#ifndef KBA_EVAL_NT
+#define KBA_EVAL_NT 0  // 1: non-temporal stores for the planes (A/B builds)
+#endif
+__device__ __forceinline__ void store_plane(double* p, double v) {
+#if KBA_EVAL_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
 }
-
-__global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* obs_cost,
-                                                     uint8_t* obs_valid) {
-    // one observation per lane (grid: (observation blocks, kObsPerLane quarters of a block)): 31 plane stores per
-    // observation and nothing to reduce - the more independent lanes in flight, the better the stores overlap
-    evaluate_lane(bv, c, blockIdx.x, threadIdx.x + blockIdx.y * kBlock, apply_loss, obs_cost, obs_valid);
+// per-view constants of EVERY view of the batch at the current poses (evaluate-only batches have no LM state to ask)
+__global__ void k_view_consts_all(BatchView bv) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < bv.TV) view_consts_item(bv, v);
+}
+__host__ __device__ inline int evaluate_grid(int n_echunk) { return 8 * ((n_echunk + 8 * (kBlock / 64) - 1) / (8 * (kBlock / 64))); }
+__global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* chunk_cost, uint8_t* obs_valid) {
+    const int lane = threadIdx.x & 63;
+    // workgroup -> run of four chunks: XCD x (= blockIdx % 8, observed placement) takes the x-th eighth of the chunks
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ci = __builtin_amdgcn_readfirstlane(wg * (kBlock / 64) + (int)(threadIdx.x >> 6));  // (wave-uniform: scalar loads below)
+    if (ci >= bv.n_echunk) return;
+    const EvalChunk ch = bv.echunk[ci];
+    cdouble* vl = (cdouble*)(bv.view_lin + (int64_t)kViewLin * ch.view);
+    const int64_t o = (int64_t)ch.base + lane;
+    const bool in = o < ch.o1;
+    // (lanes past the block's end read the inert padding of the view's segment - valid entries - and store nothing)
+    const float u = bv.obs_u[o], v = bv.obs_v[o], d = bv.obs_d[o];
+    const int gl = bv.obs_lm[o];
+    const double p[3] = {bv.lm[3 * (int64_t)gl], bv.lm[3 * (int64_t)gl + 1], bv.lm[3 * (int64_t)gl + 2]};
+    const double w = bv.lm_weight[gl];
+    const bool dep = in && d > 0.0f;
+    const unsigned long long m = __ballot(dep);
+    const int64_t rank = ch.dep0 + __popcll(m & ((1ull << lane) - 1ull));  // packed order
+    const int64_t SO = bv.SO, SD = bv.SD;
+    EvalHead h;
+    double Jp[18], Jl[9];
+    eval_obs_head(vl, c, p, w, u, v, d, apply_loss != 0, h);
+    __builtin_amdgcn_sched_barrier(0);  // (loads above, stores below)
+    eval_obs_rows(vl, p, h, Jp, Jl);
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) store_plane(bv.obs_r + k * SO + o, h.r[k]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) store_plane(bv.obs_Jp + k * SO + o, Jp[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) store_plane(bv.obs_Jl + k * SO + o, Jl[k]);
+        obs_valid[o] = h.ok ? 1 : 0;
+    }
+    if (dep) {
+        store_plane(bv.obs_r + 2 * SO + rank, h.r[2]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) store_plane(bv.obs_Jp + 12 * SO + k * SD + rank, Jp[12 + k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) store_plane(bv.obs_Jl + 6 * SO + k * SD + rank, Jl[6 + k]);
+    }
+    const double ws = wave_sum(in ? h.cost : 0.0);  // lanes in a fixed order: deterministic
+    if (lane == 0) chunk_cost[ci] = ws;
 }
 
 // ------------------------------------------------------------------------------------------ evaluate rows (limo_ba_evaluate_rows)

@@ -38,6 +38,13 @@ constexpr int kGpRed = 65;  // per keyframe: upper triangle of F^T F (10 x 10: 5
 constexpr int kLinPartial = 28;
 constexpr int kLinWaves = 4;      // waves of a landmark workgroup: each keeps its own camera-side partial sums (no barrier per view)
 
+// One wave of k_evaluate (evaluate-only batches): the ALIGNED range of 64 observations [base, base + 64) of the observation block
+// [o0, o1) (one view; a view's observations start on a multiple of 64 in these batches); dep0 = rank, among the batch's depth
+// observations in packed order, of the chunk's first depth observation.
+struct EvalChunk {
+    int32_t base, view, o0, o1, dep0, pad;
+};
+
 struct WinDesc {
     int32_t kf0, n_kf;
     int32_t lm0, n_lm;
@@ -126,6 +133,7 @@ enum SchedList { SL_LBLK = 0, SL_SPLAIN, SL_SFGP, SL_SGEN, SL_WIN, SL_TBLK, SL_T
 
 struct SolveConsts {  // subset of limo_ba_options the kernels need
     double a_rep, a_dep;
+    double inv_a_rep2, inv_a_dep2;  // 1 / a^2 (IEEE division on the host: the bits of the device's 1.0 / (a * a))
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double initial_radius, max_radius, min_radius, min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
     int32_t max_invalid, jacobi_scaling;
@@ -214,8 +222,18 @@ struct BatchView {
     // of 240 B for J_pose 3x6 + J_point 3x3; the landmark-parallel kernels rebuild Ft = c^T Rc, F = Ft [M | I],
     // E = Ft R from the view / pose / landmark they hold anyway.  Evaluate-only batches (Problem::Evaluate)
     // materialise Jp / Jl in full.
-    double *obs_r, *obs_c;            // [3|2][SO]; obs_c = (au, sd); obs_r exists in evaluate-only batches only (the solve keeps residuals in registers)
-    double *obs_Jp, *obs_Jl;          // [18|9][SO], evaluate-only batches
+    // Evaluate-only batches: the planes hold the rows that EXIST (SURVEY 8d's materialised unit: 160 B written per observation,
+    // 80 B more per DEPTH observation): the reprojection rows u, v as planes over the observations, the depth row as COMPACT planes
+    // over the depth observations only (PackedBatch::obs_rank: rank of the observation among those with d > 0, packed order;
+    // stride SD):
+    //     obs_r  = [2][SO] r_u, r_v             | [1][SD] r_d
+    //     obs_Jp = [12][SO] rows u, v (2 x 6)   | [6][SD] row d
+    //     obs_Jl = [6][SO] rows u, v (2 x 3)    | [3][SD] row d
+    double *obs_r, *obs_c;            // obs_c = [2][SO] (au, sd), solver batches; obs_r exists in evaluate-only batches only (the solve keeps residuals in registers)
+    double *obs_Jp, *obs_Jl;          // evaluate-only batches
+    const EvalChunk* echunk;          // [n_echunk] evaluate-only batches: the wave-sized work items of k_evaluate
+    int64_t SD;                       // stride of the compact depth-row planes
+    int32_t n_echunk, pad_e;
     double* lv_part;            // camera-side partial sums of the landmark-major linearisation (WinDesc::lvpart_off)
     double* lblk_linfail;       // [n_lblk] 1.0: a functor failed in this landmark workgroup (a double: it travels in the exchange arena)
     // --- landmark side

@@ -145,6 +145,8 @@ SolveConsts make_consts(const limo_ba_options& o) {
     std::memset(&c, 0, sizeof(c));
     c.a_rep = o.reprojection_thres;
     c.a_dep = o.depth_thres;
+    c.inv_a_rep2 = 1.0 / (c.a_rep * c.a_rep);
+    c.inv_a_dep2 = 1.0 / (c.a_dep * c.a_dep);
     c.function_tolerance = o.function_tolerance;
     c.gradient_tolerance = o.gradient_tolerance;
     c.parameter_tolerance = o.parameter_tolerance;
@@ -185,6 +187,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     };
     std::vector<std::vector<View>> views(n);
     std::vector<std::vector<int>> obs_view(n);
+    std::vector<std::vector<int>> view_pad_off(n);  // evaluate-only batches: offset of every view's 64-aligned segment inside its window
     // host threads over the windows (used by both passes)
     auto for_windows = [&](auto&& f) {
         unsigned nt = std::thread::hardware_concurrency();
@@ -263,6 +266,19 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.n_view = nv;
         d.obs0 = P.TO;
         d.n_obs = W.n_obs;
+        if (po.evaluate_only) {
+            // evaluate-only batches: every view's observations start on a multiple of 64 (k_evaluate: a wave takes an ALIGNED range
+            // of 64 observations of ONE view; landmark order inside a view as everywhere: the landmark gathers of a wave stay
+            // inside ~1.5 KB).  The padding entries are inert observations (src -1, no depth) that no wave stores anything for.
+            // (Tried and dropped: the view's depth observations first, so that a wave's depth rows are 64 aligned entries - the
+            // depth planes then cost what their bytes say, but every wave's gather spans twice the landmarks and the pass as a
+            // whole got 4 % slower: profiles/r06_experiment_evaluate_store_path.txt.)
+            std::vector<int>& vo = view_pad_off[w];
+            vo.assign(nv + 1, 0);
+            for (int i = 0; i < W.n_obs; ++i) vo[obs_view[w][i] + 1]++;
+            for (int v = 0; v < nv; ++v) vo[v + 1] = vo[v] + (int)pad64(vo[v + 1]);
+            d.n_obs = vo[nv];
+        }
         d.nc = W.n_kf * kCamSlots;
         d.nc_pad = (d.nc + 15) / 16 * 16;
         d.cam0 = d.kf0 * kCamSlots;
@@ -270,7 +286,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.TK += W.n_kf;
         P.TL += W.n_lm;
         P.TV += nv;
-        P.TO += W.n_obs;
+        P.TO += d.n_obs;
     }
     P.SO = pad64(std::max(1, P.TO)) + kObsBlock;  // + a dump area: lanes past the end of a partial block store there (k_linearize)
     P.SL = pad64(std::max(1, P.TL));
@@ -441,6 +457,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         for (int v = 0; v < d.n_view; ++v) {
             const int start = pos;
             while (pos < W.n_obs && obs_view[w][order[pos]] == v) ++pos;
+            auto packed_at = [&](int i) { return d.obs0 + (po.evaluate_only ? view_pad_off[w][v] + (i - start) : i); };
             for (int b0 = start; b0 < pos;) {
                 int b1 = std::min(pos, b0 + kObsBlock);
                 const int s0 = seg_of[perm[W.obs_lm[order[b0]]]];
@@ -453,14 +470,14 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 if (P.kf_nblk[gkf] == 0) P.kf_blk0[gkf] = (int)L.blk_view.size();
                 P.kf_nblk[gkf]++;
                 L.blk_view.push_back(d.view0 + v);
-                L.blk_obs0.push_back(d.obs0 + b0);
+                L.blk_obs0.push_back(packed_at(b0));
                 L.blk_n.push_back(b1 - b0);
                 L.blk_owner.push_back(W.obs_lm[order[b0]] % NS);
                 b0 = b1;
             }
             for (int i = start; i < pos; ++i) {
                 const int src = order[i];
-                const int o = d.obs0 + i;
+                const int o = packed_at(i);
                 const int l = perm[W.obs_lm[src]];
                 P.obs_lm[o] = d.lm0 + l;
                 P.obs_u[o] = W.obs_u[src];
@@ -476,6 +493,14 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
                 slot = o;
                 lm_nobs[l]++;
                 if (W.obs_d[src] > 0.0f) depth_blocks++;
+            }
+            if (po.evaluate_only) {  // the padding behind the view's observations: inert entries
+                for (int o = d.obs0 + view_pad_off[w][v] + (pos - start); o < d.obs0 + view_pad_off[w][v + 1]; ++o) {
+                    P.obs_lm[o] = d.lm0;
+                    P.obs_u[o] = P.obs_v[o] = 0.0f;
+                    P.obs_d[o] = -1.0f;
+                    P.obs_src[o] = -1;
+                }
             }
         }
         d.n_blk = (int)L.blk_view.size() - d.blk0;
@@ -709,6 +734,39 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.n_blk = (int)P.blk_view.size();
     P.n_lblk = (int)P.lblk_win.size();
     P.n_sblk = (int)P.sblk_win.size();
+    if (P.evaluate_only) {
+        // The materialised pass (k_evaluate) writes the rows that EXIST: the depth rows go into COMPACT planes over the depth
+        // observations only, indexed by the observation's rank among them in packed order (obs_rank).  Its work items are
+        // wave-sized: an aligned range of 64 observations of one observation block (= one view), each knowing the rank of its
+        // first depth observation.
+        P.echunk.clear();
+        P.obs_rank.assign((size_t)std::max(1, P.TO), -1);
+        P.TD = 0;
+        for (int o = 0; o < P.TO; ++o)
+            if (P.obs_d[o] > 0.0f) P.obs_rank[o] = P.TD++;
+        P.SD = pad64(std::max(1, P.TD)) + 64;
+        for (int b = 0; b < P.n_blk; ++b) {
+            const int o0 = P.blk_obs0[b], o1 = o0 + P.blk_n[b];
+            int next_rank = 0;  // rank of the first depth observation at or behind `a`
+            for (int o = o0; o < P.TO; ++o)
+                if (P.obs_rank[o] >= 0) {
+                    next_rank = P.obs_rank[o];
+                    break;
+                }
+            for (int a = o0; a < o1; a += 64) {  // (o0 is a multiple of 64: views are aligned, blocks are 1024 apart inside one)
+                EvalChunk ch;
+                ch.base = a;
+                ch.view = P.blk_view[b];
+                ch.o0 = o0;
+                ch.o1 = o1;
+                ch.dep0 = next_rank;
+                ch.pad = 0;
+                for (int o = a; o < std::min(o1, a + 64); ++o) next_rank += P.obs_rank[o] >= 0 ? 1 : 0;
+                P.echunk.push_back(ch);
+            }
+        }
+        P.n_echunk = (int)P.echunk.size();
+    }
     return LIMO_OK;
 }
 

@@ -40,6 +40,8 @@ using uvec = std::vector<T, default_init_allocator<T>>;
 struct PackedBatch {
     int32_t n_win = 0, TK = 0, TL = 0, TO = 0, TV = 0, TG = 0, n_blk = 0, n_lblk = 0, n_sblk = 0, Vmax = 0;
     int64_t SO = 0, SL = 0, SG = 0;
+    int64_t SD = 0;              // evaluate-only batches: stride of the COMPACT depth-row planes (depth observations only, kba_layout.hpp)
+    int32_t TD = 0;              // ... and how many depth observations (d > 0) the batch has
     int64_t hcc_total = 0, spart_total = 0, sred_total = 0, camscr_total = 0, lvpart_total = 0, xlv_total = 0;
     bool evaluate_only = false;  // planes hold the full Jacobians instead of the factored form
     int32_t n_shards = 1;        // landmark shards; owner of landmark l = (caller's index of l) mod n_shards
@@ -58,6 +60,10 @@ struct PackedBatch {
     std::vector<int32_t> view_kf, view_win;
     std::vector<double> view_cam;
     std::vector<int32_t> blk_view, blk_obs0, blk_n;
+    // evaluate-only batches: the wave-sized work items of k_evaluate (kba_layout.hpp:EvalChunk), n_echunk of them
+    std::vector<EvalChunk> echunk;
+    int32_t n_echunk = 0;
+    std::vector<int32_t> obs_rank;  // evaluate-only batches: index of the observation's depth row in the depth planes or -1
     uvec<int32_t> obs_lm;
     uvec<float> obs_u, obs_v, obs_d;
     uvec<int32_t> obs_src;  // packed observation -> index in the caller's window

@@ -1694,22 +1694,25 @@ int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_
     int rc = batch_create_impl(ctx, 1, window, opts, po, &b);
     if (rc != LIMO_OK) return rc;
     const PackedBatch& P = b->P;
-    const int M = P.TO;
+    const int M = P.TO, NB = std::max(1, P.n_echunk);
     double* d_cost = nullptr;
     uint8_t* d_valid = nullptr;
-    rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, M));
-    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, std::max(1, M));
-    if (rc == LIMO_OK && P.n_blk) {
-        hipLaunchKernelGGL(k_evaluate, dim3(P.n_blk, kObsPerLane), dim3(kBlock), 0, ctx->stream, b->bv, b->c, apply_loss, d_cost, d_valid);
+    rc = b->dmalloc((void**)&d_cost, sizeof(double) * NB);
+    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, (size_t)std::max(1, M) + 2);
+    if (rc == LIMO_OK && P.n_echunk) {
+        hipLaunchKernelGGL(k_view_consts_all, dim3(cdiv(P.TV, 256)), dim3(256), 0, ctx->stream, b->bv);
+        hipLaunchKernelGGL(k_evaluate, dim3(evaluate_grid(P.n_echunk)), dim3(kBlock), 0, ctx->stream, b->bv, b->c, apply_loss, d_cost, d_valid);
         if (hipGetLastError() != hipSuccess) rc = LIMO_ERR_RUNTIME;
     }
-    std::vector<double> hr((size_t)3 * P.SO), hjp((size_t)18 * P.SO), hjl((size_t)9 * P.SO), hc(std::max(1, M));
+    // device layout (kba_layout.hpp): rows u, v as planes over the observations, the depth row as compact planes over the depth observations
+    const size_t SO = (size_t)P.SO, SD = (size_t)P.SD;
+    std::vector<double> hr(2 * SO + SD), hjp(12 * SO + 6 * SD), hjl(6 * SO + 3 * SD), hc(NB, 0.0);
     std::vector<uint8_t> hv(std::max(1, M));
     if (rc == LIMO_OK) {
         hipError_t e = hipMemcpyAsync(hr.data(), b->bv.obs_r, sizeof(double) * hr.size(), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(hjp.data(), b->bv.obs_Jp, sizeof(double) * hjp.size(), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(hjl.data(), b->bv.obs_Jl, sizeof(double) * hjl.size(), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cost, sizeof(double) * std::max(1, M), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && P.n_echunk) e = hipMemcpyAsync(hc.data(), d_cost, sizeof(double) * NB, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(hv.data(), d_valid, std::max(1, M), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -1719,16 +1722,30 @@ int limo_ba_evaluate(limo_ctx* ctx, const limo_ba_window* window, const limo_ba_
     }
     if (rc == LIMO_OK) {
         double total = 0.0;
+        for (int q = 0; q < P.n_echunk; ++q) total += hc[q];
         for (int o = 0; o < M; ++o) {
             const int src = P.obs_src[o];
-            total += hc[o];
+            if (src < 0) continue;  // (padding of a view's segment)
+            const bool dep = P.obs_rank[o] >= 0;
+            const size_t rank = dep ? (size_t)P.obs_rank[o] : 0;
             if (valid) valid[src] = hv[o];
-            if (residuals)
-                for (int i = 0; i < 3; ++i) residuals[3 * (size_t)src + i] = hr[(size_t)i * P.SO + o];
+            if (residuals) {
+                residuals[3 * (size_t)src + 0] = hr[o];
+                residuals[3 * (size_t)src + 1] = hr[SO + o];
+                residuals[3 * (size_t)src + 2] = dep ? hr[2 * SO + rank] : 0.0;
+            }
             if (jac_pose)
-                for (int i = 0; i < 18; ++i) jac_pose[18 * (size_t)src + i] = hjp[(size_t)i * P.SO + o];
+                for (int i = 0; i < 6; ++i) {
+                    jac_pose[18 * (size_t)src + i] = hjp[(size_t)i * SO + o];
+                    jac_pose[18 * (size_t)src + 6 + i] = hjp[(size_t)(6 + i) * SO + o];
+                    jac_pose[18 * (size_t)src + 12 + i] = dep ? hjp[12 * SO + (size_t)i * SD + rank] : 0.0;
+                }
             if (jac_lm)
-                for (int i = 0; i < 9; ++i) jac_lm[9 * (size_t)src + i] = hjl[(size_t)i * P.SO + o];
+                for (int i = 0; i < 3; ++i) {
+                    jac_lm[9 * (size_t)src + i] = hjl[(size_t)i * SO + o];
+                    jac_lm[9 * (size_t)src + 3 + i] = hjl[(size_t)(3 + i) * SO + o];
+                    jac_lm[9 * (size_t)src + 6 + i] = dep ? hjl[6 * SO + (size_t)i * SD + rank] : 0.0;
+                }
         }
         if (cost) *cost = total;
     }
@@ -1786,15 +1803,20 @@ int limo_ba_evaluate_batch_time(limo_ctx* ctx, int32_t n, const limo_ba_window* 
     const int M = b->P.TO;
     double* d_cost = nullptr;
     uint8_t* d_valid = nullptr;
-    rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, M));
-    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, std::max(1, M));
+    rc = b->dmalloc((void**)&d_cost, sizeof(double) * std::max(1, b->P.n_echunk));
+    if (rc == LIMO_OK) rc = b->dmalloc((void**)&d_valid, (size_t)std::max(1, M) + 2);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rc == LIMO_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = LIMO_ERR_RUNTIME;
-    if (rc == LIMO_OK && b->P.n_blk) {
+    if (rc == LIMO_OK && b->P.n_echunk) {
         hipStream_t s = ctx->stream;
-        hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk, kObsPerLane), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);  // warm-up
+        // (an evaluation = the per-view constants + the materialised pass: both launches are inside the timed region)
+        auto eval = [&]() {
+            hipLaunchKernelGGL(k_view_consts_all, dim3(cdiv(b->P.TV, 256)), dim3(256), 0, s, b->bv);
+            hipLaunchKernelGGL(k_evaluate, dim3(evaluate_grid(b->P.n_echunk)), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);
+        };
+        eval();  // warm-up
         (void)hipEventRecord(e0, s);
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_evaluate, dim3(b->P.n_blk, kObsPerLane), dim3(kBlock), 0, s, b->bv, b->c, 1, d_cost, d_valid);
+        for (int r = 0; r < reps; ++r) eval();
         (void)hipEventRecord(e1, s);
         float ms = 0.f;
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {

@@ -587,7 +587,6 @@ int emu_ba_solve_sharded(limo_ba_window* window, const limo_ba_options* o, int n
 
 int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int apply_loss, double* cost,
                     double* residuals, double* jac_pose, double* jac_lm, uint8_t* valid) {
-    (void)apply_loss;
     EmuBatch B;
     std::string err;
     PackOptions po;
@@ -603,14 +602,13 @@ int emu_ba_evaluate(const limo_ba_window* window, const limo_ba_options* o, int 
         for (int t = 0; t < B.bv.blk_n[b]; ++t) {
             const int64_t o_ = B.bv.blk_obs0[b] + t;
             const int gl = B.bv.obs_lm[o_];
-            ObsOut oo;
-            bool ok = obs_residual_jacobian(B.bv.pose + 7 * (int64_t)B.bv.view_kf[view], cam + 4, cam + 13, cam[0], cam[1],
-                                            cam[2], B.bv.lm + 3 * (int64_t)gl, B.bv.obs_u[o_], B.bv.obs_v[o_],
-                                            B.bv.obs_d[o_], B.bv.lm_weight[gl], B.c.a_rep, B.c.a_dep, apply_loss != 0, &oo);
+            // (the statements of k_evaluate: the view's constants, then eval_obs - with the IEEE operations on the host)
+            double vl[40];
+            view_consts_compute(cam, B.bv.pose + 7 * (int64_t)B.bv.view_kf[view], vl);
+            EvalOut oo;
+            const bool ok = eval_obs((const double*)vl, B.c, B.bv.lm + 3 * (int64_t)gl, B.bv.lm_weight[gl], B.bv.obs_u[o_], B.bv.obs_v[o_], B.bv.obs_d[o_],
+                                     apply_loss != 0, oo);
             const int src = B.P.obs_src[o_];
-            if (!ok) {
-                std::memset(&oo, 0, sizeof(oo));
-            }
             total += oo.cost;
             if (valid) valid[src] = ok ? 1 : 0;
             if (residuals) std::memcpy(residuals + 3 * (size_t)src, oo.r, sizeof(oo.r));

@@ -125,7 +125,7 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
         return ctx.solve(w, opts)
 
     cases = fc.random_windows(n, seed)
-    singles, n_plateau, n_cap, n_ill, worst_c, worst_p, worst_at = [], 0, 0, 0, 0.0, 0.0, -1
+    singles, n_plateau, n_cap, n_ill, n_watch, worst_c, worst_p, worst_at = [], 0, 0, 0, 0, 0.0, 0.0, -1
     for i, (kw, w) in enumerate(cases):
         wg, wo = w.copy(), w.copy()
         b = ba.Batch(ctx, [wg])  # a batch of one: same kernels as limo_ba_solve, and the trimmed set can be read back
@@ -146,15 +146,24 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
         if clause != fc.BY_SPREAD and posed:  # (windows whose result the input does not determine are judged by the spread rule)
             worst_c = max(worst_c, fc.rel_cost_err(rg, ro))
             ep = fc.rel_pose_err(wg.kf_pose, wo.kf_pose)
-            if ep > worst_p:
+            if ep > POSE_WATCH:
+                # inside the bar but close to it: is that the kernels' arithmetic, or does the INPUT not determine the poses any
+                # better?  (seed 123 window 53 - ten keyframes, stereo, 2 % depth: the oracle's own poses move by 6.5e-5 under a
+                # 1-ulp change of one input coordinate, and the IEEE emulation differs from it by exactly as much)
+                s_own = fc.input_sensitivity(w, so, n=16)
+                print("fuzz seed %d window %d: rel pose %.2e above the watch level; the oracle's own 1-ulp spread is %.2e" % (seed, i, ep, s_own["pose"]))
+                assert ep <= 3.0 * s_own["pose"], "seed %d window %d: rel pose %.2e is within 2x of the 1e-4 bar and NOT explained by the oracle's own spread (%.2e)" % (seed, i, ep, s_own["pose"])
+                n_watch += 1
+            elif ep > worst_p:
                 worst_p, worst_at = ep, i
         singles.append(wg)
     # windows whose result is not determined to 1e-4 by their input are rare: 1 in 290 / 1 in 60 / 4 in 240 at full size
     assert n_plateau <= max(1, n // 40)
     # the iteration-cap clause (a termination type that differs from the reference's: fuzz_common.BY_CAP) has its own, tighter count
     assert n_cap <= 1, n_cap
-    # the margin to the 1e-4 bar is watched, not discovered: worst strictly-judged pose error of the sweep
-    assert worst_p <= POSE_WATCH, "seed %d: worst rel pose %.2e at window %d is within 2x of the 1e-4 bar" % (seed, worst_p, worst_at)
+    # the margin to the 1e-4 bar is watched, not discovered: a strictly-judged window above POSE_WATCH must be explained by the
+    # oracle's own spread (checked above, window by window), and such windows stay rare
+    assert worst_p <= POSE_WATCH and n_watch <= max(1, n // 100), (worst_p, n_watch)
     # windows that only get the weak checks (a keyframe with < 8 observations: 9 of 290 / 1 of 60 at full size) stay few:
     # the strict rule (sets, termination, pose and cost to 1e-4) covers >= 95 % of the sweep
     assert n_ill <= max(1, n // 20) or scale < 1, n_ill  # (a property of the sample: only meaningful at full size)
@@ -165,5 +174,5 @@ def test_gpu_fuzz_vs_oracle(ctx, oracle, seed, n):
     for i, (ws, wb) in enumerate(zip(singles, b.windows)):
         assert np.array_equal(ws.kf_pose, wb.kf_pose) and np.array_equal(ws.lm_pos, wb.lm_pos), "batch != single, window %d" % i
     b.close()
-    print("fuzz seed %d: %d windows, %d plateau cases, %d at the iteration cap, %d ill-posed (weak checks), worst rel cost %.2e, worst rel pose %.2e (window %d)"
-          % (seed, n, n_plateau, n_cap, n_ill, worst_c, worst_p, worst_at))
+    print("fuzz seed %d: %d windows, %d plateau cases, %d at the iteration cap, %d ill-posed (weak checks), %d above the pose watch level (explained by the oracle's own spread), worst rel cost %.2e, worst rel pose of the others %.2e (window %d)"
+          % (seed, n, n_plateau, n_cap, n_ill, n_watch, worst_c, worst_p, worst_at))
