@@ -2086,17 +2086,30 @@ __global__ void k_view_consts_all(BatchView bv) {
     if (v < bv.TV) view_consts_item(bv, v);
 }
 __host__ __device__ inline int evaluate_grid(int n_echunk) { return 8 * ((n_echunk + 8 * (kBlock / 64) - 1) / (8 * (kBlock / 64))); }
+#ifndef KBA_EVAL_STAGE
+#define KBA_EVAL_STAGE 1  // 1: the depth rows of a workgroup leave through LDS as whole 128-byte lines; 0: every lane stores its own (A/B builds)
+#endif
 __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c, int apply_loss, double* chunk_cost, uint8_t* obs_valid) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // workgroup -> run of four chunks: XCD x (= blockIdx % 8, observed placement) takes the x-th eighth of the chunks
     const int per_xcd = gridDim.x >> 3;
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int ci = __builtin_amdgcn_readfirstlane(wg * (kBlock / 64) + (int)(threadIdx.x >> 6));  // (wave-uniform: scalar loads below)
-    if (ci >= bv.n_echunk) return;
-    const EvalChunk ch = bv.echunk[ci];
+    const int ci = __builtin_amdgcn_readfirstlane(wg * (kBlock / 64) + wave);  // (wave-uniform: scalar loads below)
+    const bool have = ci < bv.n_echunk;
+#if KBA_EVAL_STAGE
+    // The depth rows of the workgroup's (up to) 256 observations have consecutive ranks [R0, R1) - the chunks are consecutive and
+    // ranks follow the packed order - so they are collected in LDS and written as whole lines: a lane per plane entry, 64 consecutive
+    // entries per wave from a multiple of 16 on.  (Each lane storing its own row at its rank: a run of ~29 x 8 B at any alignment per
+    // instruction = three partial-line writes, 1.65x the requests per byte; profiles/r06_experiment_evaluate_store_path.txt.)
+    __shared__ double stage[10][kBlock];
+    __shared__ int wave_end[kBlock / 64];
+#else
+    if (!have) return;
+#endif
+    const EvalChunk ch = bv.echunk[have ? ci : 0];
     cdouble* vl = (cdouble*)(bv.view_lin + (int64_t)kViewLin * ch.view);
     const int64_t o = (int64_t)ch.base + lane;
-    const bool in = o < ch.o1;
+    const bool in = have && o < ch.o1;
     // (lanes past the block's end read the inert padding of the view's segment - valid entries - and store nothing)
     const float u = bv.obs_u[o], v = bv.obs_v[o], d = bv.obs_d[o];
     const int gl = bv.obs_lm[o];
@@ -2104,7 +2117,7 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c
     const double w = bv.lm_weight[gl];
     const bool dep = in && d > 0.0f;
     const unsigned long long m = __ballot(dep);
-    const int64_t rank = ch.dep0 + __popcll(m & ((1ull << lane) - 1ull));  // packed order
+    const int rank = ch.dep0 + __popcll(m & ((1ull << lane) - 1ull));  // packed order
     const int64_t SO = bv.SO, SD = bv.SD;
     EvalHead h;
     double Jp[18], Jl[9];
@@ -2120,6 +2133,30 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c
         for (int k = 0; k < 6; ++k) store_plane(bv.obs_Jl + k * SO + o, Jl[k]);
         obs_valid[o] = h.ok ? 1 : 0;
     }
+#if KBA_EVAL_STAGE
+    const int R0 = bv.echunk[min(wg * (kBlock / 64), bv.n_echunk - 1)].dep0;  // first rank of the workgroup (its first chunk exists whenever one does)
+    if (dep) {
+        const int lr = rank - R0;  // < kBlock: at most one depth row per observation of the workgroup
+        stage[0][lr] = h.r[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) stage[1 + k][lr] = Jp[12 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stage[7 + k][lr] = Jl[6 + k];
+    }
+    if (lane == 0) wave_end[wave] = have ? ch.dep0 + (int)__popcll(m) : 0;
+    __syncthreads();
+    const int R1 = max(max(wave_end[0], wave_end[1]), max(wave_end[2], wave_end[3]));
+    for (int e = (R0 & ~15) + (int)threadIdx.x; e < R1; e += kBlock) {
+        if (e < R0) continue;
+        const int lr = e - R0;
+        store_plane(bv.obs_r + 2 * SO + e, stage[0][lr]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) store_plane(bv.obs_Jp + 12 * SO + k * SD + e, stage[1 + k][lr]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) store_plane(bv.obs_Jl + 6 * SO + k * SD + e, stage[7 + k][lr]);
+    }
+    if (!have) return;
+#else
     if (dep) {
         store_plane(bv.obs_r + 2 * SO + rank, h.r[2]);
 #pragma unroll
@@ -2127,6 +2164,7 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(BatchView bv, SolveConsts c
 #pragma unroll
         for (int k = 0; k < 3; ++k) store_plane(bv.obs_Jl + 6 * SO + k * SD + rank, Jl[6 + k]);
     }
+#endif
     const double ws = wave_sum(in ? h.cost : 0.0);  // lanes in a fixed order: deterministic
     if (lane == 0) chunk_cost[ci] = ws;
 }

@@ -840,6 +840,7 @@ struct limo_ba_batch : Executor {
         int32_t *h_done = nullptr, *d_h_done = nullptr;  // pinned ring of 4
         int n_slots = 0;
         int cap[SL_COUNT] = {0};
+        int mx[SL_COUNT] = {0};  // entries of list k a single window can have
         BatchView sv;
     };
     std::vector<StreamGroup> groups;
@@ -889,6 +890,7 @@ struct limo_ba_batch : Executor {
             g.sv = bv;
             size_t total = 0;
             for (int k = 0; k < SL_COUNT; ++k) {
+                g.mx[k] = mx[k];
                 g.cap[k] = g.n_slots * mx[k];
                 g.sv.sched_off[k] = (int32_t)total;
                 total += 1 + (size_t)std::max(1, g.cap[k]);
@@ -926,10 +928,17 @@ struct limo_ba_batch : Executor {
 
     // One round of one group = scheduler + (side stream) trimming of the windows whose trimming solve just ended + one LM
     // iteration of every window in the group's slots.
-    void enqueue_round(StreamGroup& g, int round, bool time_kernels) {
+    // in_flight_max: an upper bound on the windows this group can have in its slots in this round (the batch's unfinished windows as
+    // of the pinned done-counter the host read last).  The list-driven kernels are launched over bound x (entries per window)
+    // workgroups instead of the lists' capacities: while the batch drains, a round of 200 windows in 2048 slots no longer
+    // dispatches 16 000 workgroups per kernel that read one count word and leave (~3 ns each: 50 us per kernel, and a round has
+    // a dozen of them - the "launch-latency floor" of the drain was mostly this).
+    void enqueue_round(StreamGroup& g, int round, bool time_kernels, int in_flight_max) {
         hipStream_t s = g.stream;
         const BatchView& sv = g.sv;
-        const int* cap = g.cap;
+        int cap[SL_COUNT];
+        const int bound = std::max(1, std::min(g.n_slots, in_flight_max));
+        for (int k = 0; k < SL_COUNT; ++k) cap[k] = std::min(g.cap[k], bound * g.mx[k]);
         auto L = [&](int k) { return (const int32_t*)(g.d_lists + sv.sched_off[k] + 1); };
         if (round > 0) note(hipStreamWaitEvent(s, g.trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
         hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(g.n_slots, 256)), dim3(256), 0, s, sv, c);
@@ -1126,16 +1135,25 @@ struct limo_ba_batch : Executor {
         // KBA_SCHED_TRACE=1 (profiling aid): windows finished as of every round -> how full the slots are over the solve
         static const bool sched_trace = std::getenv("KBA_SCHED_TRACE") != nullptr;
         std::vector<int> done_curve;
+        double enq_us = 0.0;  // host time inside enqueue_round (KBA_SCHED_TRACE)
+        const auto t_solve0 = std::chrono::steady_clock::now();
         bool finished = false;
+        int done_seen = 0;  // windows finished, as last read from the pinned ring (monotone, kLag + 1 rounds old when it is used)
+        static const bool shrink = !(std::getenv("KBA_NO_GRID_SHRINK") && std::atoi(std::getenv("KBA_NO_GRID_SHRINK")) != 0);
         for (int round = 0; !finished; ++round) {
-            for (StreamGroup& g : groups) enqueue_round(g, round, time_kernels);
+            const int in_flight_max = shrink ? (int)P.n_win - done_seen : (int)P.n_win;
+            const auto t_enq0 = std::chrono::steady_clock::now();
+            for (StreamGroup& g : groups) enqueue_round(g, round, time_kernels, in_flight_max);
+            if (sched_trace) enq_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq0).count();
             if (rc != LIMO_OK) break;
             if (round >= kLag) {
                 finished = true;
                 for (StreamGroup& g : groups) {
                     note(hipEventSynchronize(g.round_ev[(round - kLag) & 3]), "sync round");
                     if (rc != LIMO_OK) break;
-                    if (g.h_done[(round - kLag) & 3] < P.n_win) finished = false;
+                    const int d = g.h_done[(round - kLag) & 3];
+                    if (d < P.n_win) finished = false;
+                    done_seen = std::max(done_seen, d);
                 }
                 if (sched_trace) done_curve.push_back(groups[0].h_done[(round - kLag) & 3]);
             }
@@ -1152,7 +1170,8 @@ struct limo_ba_batch : Executor {
             std::fprintf(stderr, "[kba] streaming solve: %d windows, %d slots, %d groups, %d rounds; in flight at 0,10,..100 %% of the rounds:", (int)P.n_win, n_slots, (int)groups.size(), R);
             for (int r = 0; r < R; ++r) occ += std::min(n_slots, (int)P.n_win - done_curve[r]);
             for (int d = 0; d <= 10; ++d) std::fprintf(stderr, " %d", std::min(n_slots, (int)P.n_win - done_curve[std::min(R - 1, d * R / 10)]));
-            std::fprintf(stderr, "; mean occupancy %.3f\n", (double)occ / ((double)R * n_slots));
+            std::fprintf(stderr, "; mean occupancy %.3f; host: %.1f us per round inside the enqueue calls, %.1f us per round wall\n", (double)occ / ((double)R * n_slots),
+                         enq_us / (R + kLag), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_solve0).count() / (R + kLag));
         }
         for (StreamGroup& g : groups) {  // everything joins the context's stream again
             note(hipStreamWaitEvent(g.stream, g.trim_ev, 0), "wait trim");
