@@ -34,11 +34,11 @@ __device__ long long kba_ticks[2][24];
 namespace kba {
 
 // ======================================================================================= observations
+// Camera-side sums of one (landmark, view) pair in the RAW form the linearisation accumulates (kLinPartial = 28 entries, 26 used;
+// lin_cam_half0 / lin_cam_half1 below): the camera assembly turns the per-view totals into U = Jp^T Jp and g = Jp^T r (cam_raw_entry).
 struct LinLane {
-    double cost;
+    double e[kLinPartial];  // [0] cost | [1..25] raw sums | [26, 27] zero
     int fail;
-    double U[21];  // upper triangle of Jp^T Jp (6x6), row-major
-    double g[6];   // Jp^T r
 };
 
 // Per-view constants of the current poses (one item per view, before the observations are linearised):
@@ -111,29 +111,104 @@ KBA_HD void lin_fetch(const BatchView& bv, int64_t o, int gl, LinIn& in) {
 // the camera system anyway, so the pose Jacobian and U / g are not formed (a third of the arithmetic of a pair).  The cost, the
 // residual and the planes are the same statements either way.
 // VP: pointer to the view's constants - plain memory, or the constant address space (scalar loads) in k_lin_lm.
-// Entry k (0..27: cost | U 21, upper triangle row-major | g 6) of the camera-side sums of a pair from its pose Jacobian J
-// (3 x 6, row-major) and residual r3 - k is a compile-time constant at every call site (unrolled loops).
-template <int K>
-KBA_HD double lin_cam_entry_t(const double* J, const double* r3, double cost) {
-    if constexpr (K == 0) {
-        return cost;
-    } else if constexpr (K >= 22) {
-        constexpr int a = K - 22;
-        return J[a] * r3[0] + J[6 + a] * r3[1] + J[12 + a] * r3[2];
-    } else {
-        constexpr int q = K - 1;  // row a of the upper triangle starts at a * 6 - a (a - 1) / 2
-        constexpr int a = q < 6 ? 0 : q < 11 ? 1 : q < 15 ? 2 : q < 18 ? 3 : q < 20 ? 4 : 5;
-        constexpr int bb = a + (q - (a * 6 - a * (a - 1) / 2));
-        return J[a] * J[bb] + J[6 + a] * J[6 + bb] + J[12 + a] * J[12 + bb];
+// ---- camera-side sums of a pair, RAW form (round 6).  The pose Jacobian of a pair is  J = C [G | Rc]  with
+//   C = [[au, 0, -a1], [0, au, -a2], [0, 0, sd]]  (a1 = au xn, a2 = au yn: the rows u, v, d over the camera-frame coordinates),
+//   G = Rc [y]_x,  y = -2 Rh(q) p  (lin_pose_jac),
+// so  U = J^T J = [G | Rc]^T W [G | Rc]  with  W = C^T C  (four distinct values)  and  g = J^T r = [G | Rc]^T v,  v = C^T r.
+// Rc is the VIEW's, so it leaves the sums over the landmarks: the lane accumulates
+//   [1..4]   wa = au^2, wb = au a1, wc = au a2, wd = a1^2 + a2^2 + sd^2     W = [[wa, 0, -wb], [0, wa, -wc], [-wb, -wc, wd]]
+//   [5..7]   v = (au r0, au r1, sd r2 - a1 r0 - a2 r1)
+//   [8..16]  A = W G  (3 x 3, row-major)
+//   [17..22] G^T A  (the rotation-rotation block, upper triangle 00 01 02 11 12 22)
+//   [23..25] G^T v  (the rotation part of g)
+// and the camera assembly forms  U_rot,trans = A^T Rc,  U_trans,trans = Rc^T W Rc,  g_trans = Rc^T v  from the per-view totals
+// (cam_raw_entry).  86 multiply-adds per pair instead of the 138 of J (57) + J^T J, J^T r (81), 26 sums instead of 28, and the 3 x 6
+// Jacobian itself is never formed (36 registers).  Two halves of 14 entries: what the second needs of the first stays in CamTmp.
+struct CamTmp {
+    double G[9], A01[6], v[3], wb, wc, wd;
+};
+template <class VP>
+KBA_HD void lin_cam_half0(VP vl, const double* p, const double* c4, const double* r3, double cost, CamTmp& t, double* out) {
+    const double p0 = p[0], p1 = p[1], p2 = p[2];
+    const double au = c4[0], sd = c4[3];
+    const double a1 = au * c4[1], a2 = au * c4[2];
+    const double yv[3] = {vl[28] * p0 + vl[29] * p1 + vl[30] * p2, vl[31] * p0 + vl[32] * p1 + vl[33] * p2, vl[34] * p0 + vl[35] * p1 + vl[36] * p2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        constexpr int kNext[3] = {1, 2, 0};
+        const int j1 = kNext[j], j2 = kNext[j1];
+        t.G[0 + j] = vl[12 + j1] * yv[j2] - vl[12 + j2] * yv[j1];
+        t.G[3 + j] = vl[15 + j1] * yv[j2] - vl[15 + j2] * yv[j1];
+        t.G[6 + j] = vl[18 + j1] * yv[j2] - vl[18 + j2] * yv[j1];
+    }
+    const double wa = au * au;
+    t.wb = au * a1;
+    t.wc = au * a2;
+    t.wd = a1 * a1 + a2 * a2 + sd * sd;
+    t.v[0] = au * r3[0];
+    t.v[1] = au * r3[1];
+    t.v[2] = sd * r3[2] - a1 * r3[0] - a2 * r3[1];
+    out[0] = cost;
+    out[1] = wa;
+    out[2] = t.wb;
+    out[3] = t.wc;
+    out[4] = t.wd;
+    out[5] = t.v[0];
+    out[6] = t.v[1];
+    out[7] = t.v[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t.A01[j] = wa * t.G[j] - t.wb * t.G[6 + j];
+        t.A01[3 + j] = wa * t.G[3 + j] - t.wc * t.G[6 + j];
+        out[8 + j] = t.A01[j];
+        out[11 + j] = t.A01[3 + j];
     }
 }
-// entries K0 .. K0 + N - 1 into out[0 .. N - 1]
-template <int K0, int N>
-KBA_HD void lin_cam_entries(const double* J, const double* r3, double cost, double* out) {
-    if constexpr (N > 0) {
-        out[0] = lin_cam_entry_t<K0>(J, r3, cost);
-        lin_cam_entries<K0 + 1, N - 1>(J, r3, cost, out + 1);
+KBA_HD void lin_cam_half1(const CamTmp& t, double* out) {
+    double A2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        A2[j] = t.wd * t.G[6 + j] - t.wb * t.G[j] - t.wc * t.G[3 + j];
+        out[j] = A2[j];
     }
+    // G^T A, upper triangle: (i, j) = sum_k G[k][i] A[k][j]
+    int q = 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) out[q++] = t.G[i] * t.A01[j] + t.G[3 + i] * t.A01[3 + j] + t.G[6 + i] * A2[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[9 + i] = t.G[i] * t.v[0] + t.G[3 + i] * t.v[1] + t.G[6 + i] * t.v[2];
+    out[12] = 0.0;
+    out[13] = 0.0;
+}
+// Entry q (0..26: U upper triangle row-major over the six pose slots [rot 3 | trans 3] 21, g 6) of a view's camera block from
+// the view's raw totals R (kLinPartial entries) and its Rc (3 x 3 row-major).
+KBA_HD double cam_raw_entry(int q, const double* R, const double* Rc) {
+    if (q >= 21) {
+        const int i = q - 21;
+        if (i < 3) return R[23 + i];
+        const int j = i - 3;
+        return Rc[j] * R[5] + Rc[3 + j] * R[6] + Rc[6 + j] * R[7];
+    }
+    int a = 0, rem = q;
+    while (rem >= 6 - a) {
+        rem -= 6 - a;
+        ++a;
+    }
+    const int b = a + rem;
+    if (b < 3) {  // rotation x rotation: G^T A (upper triangle 00 01 02 11 12 22)
+        return R[17 + (a == 0 ? b : a == 1 ? 2 + b : 5)];
+    }
+    const int j = b - 3;
+    if (a < 3)  // rotation x translation: (A^T Rc)[a][j]
+        return R[8 + a] * Rc[j] + R[11 + a] * Rc[3 + j] + R[14 + a] * Rc[6 + j];
+    // translation x translation: (Rc^T W Rc)[i][j],  W = [[wa, 0, -wb], [0, wa, -wc], [-wb, -wc, wd]]
+    const int i = a - 3;
+    const double wr0 = R[1] * Rc[j] - R[2] * Rc[6 + j];                    // (W Rc)[0][j]
+    const double wr1 = R[1] * Rc[3 + j] - R[3] * Rc[6 + j];                // (W Rc)[1][j]
+    const double wr2 = R[4] * Rc[6 + j] - R[2] * Rc[j] - R[3] * Rc[3 + j];  // (W Rc)[2][j]
+    return Rc[i] * wr0 + Rc[3 + i] * wr1 + Rc[6 + i] * wr2;
 }
 
 // Jp of an observation, row-major 3 x 6: [Ft M | Ft] = c^T [G | Rc],  G = Rc M(q, p) = Rc [y]_x,  y = -2 Rh(q) p, from the view's
@@ -158,21 +233,22 @@ KBA_HD void lin_pose_jac(VP vl, const double* p, double au, double xn, double yn
         J[15 + j] = sd * vl[18 + j];
     }
 }
-// lin_obs_core: everything of lin_obs up to the pose Jacobian J (filled when CAM); lin_obs adds the camera-side sums.
-template <bool CAM = true, class VP = const double*>
-KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J);
+// lin_obs_core: residual r3, the scalars c4 = (au, xn, yn, sd) of the factored rows and the cost of a pair; lin_obs adds the
+// camera-side raw sums (CAM) or the cost alone.
+template <class VP = const double*>
+KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out);
 template <bool CAM = true, class VP = const double*>
 KBA_HD bool lin_obs(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, LinLane& out) {
-    double J[18];
-    const bool ok = lin_obs_core<CAM>(vl, c, in, want_cost, r3, c4, out.cost, J);
+    const bool ok = lin_obs_core(vl, c, in, want_cost, r3, c4, out.e[0]);
     if (CAM) {
-        lin_cam_entries<1, 21>(J, r3, 0.0, out.U);
-        lin_cam_entries<22, 6>(J, r3, 0.0, out.g);
+        CamTmp t;
+        lin_cam_half0(vl, in.p, c4, r3, out.e[0], t, out.e);
+        lin_cam_half1(t, out.e + 14);
     }
     return ok;
 }
-template <bool CAM, class VP>
-KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out, double* J) {
+template <class VP>
+KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want_cost, double* r3, double* c4, double& cost_out) {
     double xn, yn, iz, z2;  // (z2 = 1 inside the failure band: keeps the arithmetic finite; masked below)
     const bool z_ok = view_xy(vl, in.p, &xn, &yn, &iz, &z2);
     const bool ok = in.live != 0 && z_ok;
@@ -204,8 +280,6 @@ KBA_HD bool lin_obs_core(VP vl, const SolveConsts& c, const LinIn& in, bool want
     c4[1] = xn;
     c4[2] = yn;
     c4[3] = sd;
-    if (!CAM) return z_ok || in.live == 0;
-    lin_pose_jac(vl, in.p, au, xn, yn, sd, J);
     return z_ok || in.live == 0;
 }
 
@@ -356,10 +430,8 @@ KBA_HD int lin_lm_lane(const BatchView& bv, const SolveConsts& c, int w, int gl,
     const WinDesc& wd = bv.win[w];
     part[0] = part[1] = part[5] = 0.0;
     for (int j = 0; j < wd.n_view; ++j) {
-        cam[j].cost = 0.0;
         cam[j].fail = 0;
-        for (int i = 0; i < 21; ++i) cam[j].U[i] = 0.0;
-        for (int i = 0; i < 6; ++i) cam[j].g[i] = 0.0;
+        for (int i = 0; i < kLinPartial; ++i) cam[j].e[i] = 0.0;
     }
     const int state = bv.lm_state[gl];
     if (state == 0) return 0;
@@ -1114,16 +1186,19 @@ KBA_HD int cam_max_reg_rows(int nc) {  // upper bound of reg_row_count for a win
     return 1 + (nkf > 0 ? (nkf - 1) * 5 + 3 * nkf : 0) + 3;
 }
 // scratch of cam_assemble: H (nc x nc) | regulariser rows, aliased by the ground-plane staging | dense regulariser
-// rows, aliased by the reduction tree of the last phase
+// rows, aliased by the views' raw camera-side totals of the first phase and by the reduction tree of the last
 KBA_HD int cam_assemble_union(int nc) {
     const int rows = (int)((sizeof(RegRow) * cam_max_reg_rows(nc) + 7) / 8);
     const int gp = kGpChunk * 12;
     return rows > gp ? rows : gp;
 }
-KBA_HD int cam_assemble_scratch(int nc, int nt) {
+// n_view: views of the window (their raw camera-side totals, n_view x kLinPartial doubles, share the third region)
+KBA_HD int cam_assemble_scratch(int nc, int nt, int n_view) {
     const int dense = cam_max_reg_rows(nc) * kRegDense;
     const int red = coop_red_doubles(6, nt);
-    return nc * nc + cam_assemble_union(nc) + (red > dense ? red : dense);
+    const int raw = n_view * kLinPartial;
+    const int third = red > dense ? red : dense;
+    return nc * nc + cam_assemble_union(nc) + (raw > third ? raw : third);
 }
 // Windows whose scratch exceeds this many bytes work in global memory (WinDesc::cam_scr_off) instead of LDS (160 KB / CU).
 constexpr int kCamLdsCapBytes = 150 * 1024;
@@ -1165,24 +1240,33 @@ KBA_HD void cam_assemble(const BatchView& bv, const SolveConsts& c, int w, int t
     };
     if (wd.n_gp > 0 && !bv.gp_red) gp_stage(wd.gp0);
     KBA_SYNC();
-    // (1) observations: U_k (6x6) and g_k per keyframe = sum of the camera-side partial sums of its views over the
-    //     window's landmark workgroups and their waves (k_lin_lm); one lane per (keyframe, entry): single writer, fixed order.
+    // (1) observations: the camera-side RAW sums of every view (lin_cam_half0 / _half1) totalled over the window's landmark
+    //     workgroups - one lane per (view, entry), in workgroup order - then U_k (6x6) and g_k per keyframe from its views' totals
+    //     (cam_raw_entry: the view's Rc enters here, once per window instead of once per pair); one lane per (keyframe, entry):
+    //     single writer, fixed order.
+    double* raw = dense;  // [n_view][kLinPartial]: the dense regulariser rows only move in behind phase (2)
+    for (int e = tid; e < wd.n_view * kLinPartial; e += nt) {
+        const double* lp = bv.lv_part + wd.lvpart_off + e;
+        const int64_t stride = (int64_t)wd.n_view * kLinPartial;
+        double acc = 0.0;
+        int b = 0;
+        for (; b + 4 <= wd.n_lblk; b += 4) {  // four loads in flight, added in workgroup order
+            const double v0 = lp[b * stride], v1 = lp[(b + 1) * stride], v2 = lp[(b + 2) * stride], v3 = lp[(b + 3) * stride];
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; b < wd.n_lblk; ++b) acc += lp[b * stride];
+        raw[e] = acc;
+    }
+    KBA_SYNC();
     for (int e = tid; e < wd.n_kf * 27; e += nt) {
         const int kl = e / 27, q = e % 27;
         double acc = 0.0;
         for (int j = 0; j < wd.n_view; ++j) {
             if (bv.view_kf[wd.view0 + j] - wd.kf0 != kl) continue;
-            const double* lp = bv.lv_part + wd.lvpart_off + (int64_t)j * kLinPartial + 1 + q;
-            const int64_t stride = (int64_t)wd.n_view * kLinPartial;
-            int b = 0;
-            for (; b + 4 <= wd.n_lblk; b += 4) {  // four loads in flight, added in workgroup order
-                const double v0 = lp[b * stride], v1 = lp[(b + 1) * stride], v2 = lp[(b + 2) * stride], v3 = lp[(b + 3) * stride];
-                acc += v0;
-                acc += v1;
-                acc += v2;
-                acc += v3;
-            }
-            for (; b < wd.n_lblk; ++b) acc += lp[b * stride];
+            acc += cam_raw_entry(q, raw + j * kLinPartial, bv.view_cam + 16 * (int64_t)(wd.view0 + j) + 4);
         }
         if (q < 21) {
             int a = 0, rem = q;

@@ -516,7 +516,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
             bv.obs_c[bv.SO + o] = c4[3];
         }
         accum(vl, r3, c4);
-        const double tot = wave_sum_all(l.cost);
+        const double tot = wave_sum_all(l.e[0]);
         if (lane < kLinPartial) lv_lds[(j * kLinWaves + wave) * kLinPartial + lane] = lane == 0 ? tot : 0.0;
     }
     for (int j = j_cam0; j < n_view; ++j) {
@@ -537,8 +537,7 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         in.live = have;
         LinLane l;
         double r3[3], c4[4];
-        double J[18];
-        if (!lin_obs_core<true>(vl, c, in, want_cost, r3, c4, l.cost, J)) fail = 1;
+        if (!lin_obs_core(vl, c, in, want_cost, r3, c4, l.e[0])) fail = 1;
         {   // of the four scalars of the factored Jacobian the Schur / back-substitution kernels read au and sd (16 B per pair) and
             // rebuild xn, yn from the landmark and the view (kba_math.hpp:view_xy: the same statements as here); the residual
             // r3 has done its work inside this lane (g += E^T r, camera-side g) - nobody reads it from memory in a solve
@@ -548,16 +547,18 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         }
         accum(vl, r3, c4);  // zeros where the pair does not exist
         static_assert(kLinPartial == 28 && kLinWaves * 64 == kBlock, "wave_reduce_scatter14 x 2");
-        // the 28 camera-side sums of the view leave the wave in two halves of 14 (register pressure: wave_reduce_scatter14)
+        // the camera-side RAW sums of the view (kba_items.hpp:lin_cam_half0 / _half1: 26 values - the 3 x 6 pose Jacobian is never
+        // formed) leave the wave in two halves of 14 (register pressure: wave_reduce_scatter14)
+        CamTmp ct;
         {
             double vals[14];
-            lin_cam_entries<0, 14>(J, r3, l.cost, vals);
+            lin_cam_half0(vl, in.p, c4, r3, l.e[0], ct, vals);
             const double tot = wave_reduce_scatter14(vals, lane);
             if (rs14_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + rs14_idx] = tot;
         }
         {
             double vals[14];
-            lin_cam_entries<14, 14>(J, r3, l.cost, vals);
+            lin_cam_half1(ct, vals);
             const double tot = wave_reduce_scatter14(vals, lane);
             if (rs14_idx >= 0) lv_lds[(j * kLinWaves + wave) * kLinPartial + 14 + rs14_idx] = tot;
         }
@@ -596,10 +597,10 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
         bv.lblk_linfail[b] = any_fail ? 1.0 : 0.0;
     }
 }
-// k_lin_lm<WAVES, VLDS>: <3, true> is the default (166 registers: view constants, landmark sums and tail inputs in LDS, 33 KB per
-// workgroup at five views); <3, false> reads the view constants through scalar loads and keeps the sums in registers (windows with so
-// many views that the LDS copy would cost occupancy); <4, false> is the 128-register experiment (KBA_LIN_WAVES=4).  Same statements,
-// same order, same bits in all of them.
+// k_lin_lm<WAVES, VLDS>: <4, true> is the default (128 registers: view constants, landmark sums and tail inputs in LDS, 33 KB per
+// workgroup at five views); <3, true> the same at three waves per SIMD (KBA_LIN_WAVES=3); <., false> reads the view constants through
+// scalar loads (windows with so many views that the LDS copy would cost occupancy; <3, false> keeps the sums in registers).  Same
+// statements, same order, same bits in all of them.
 template <int WAVES, bool VLDS>
 #ifdef KBA_NOATTR_LIN
 __global__ __launch_bounds__(kBlock) void k_lin_lm(

@@ -683,7 +683,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
             d.lvpart_off = P.lvpart_total;
             P.lvpart_total += (int64_t)d.n_lblk * d.n_view * kLinPartial;
             {   // camera system too large for LDS: scratch in global memory (kba_items.hpp:kCamLdsCapBytes)
-                const int need = std::max(cam_assemble_scratch(d.nc, kBlock), cam_solve_scratch(d.nc, kBlock));
+                const int need = std::max(cam_assemble_scratch(d.nc, kBlock, d.n_view), cam_solve_scratch(d.nc, kBlock));
                 d.cam_scr_off = -1;
                 if (need * (int)sizeof(double) > kCamLdsCapBytes) {
                     d.cam_scr_off = P.camscr_total;

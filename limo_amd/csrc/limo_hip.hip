@@ -350,13 +350,14 @@ struct limo_ba_batch : Executor {
             }
         }
         {   // LDS of the window-level kernels: the largest window that still works in LDS (the others: cam_scr_off)
-            int nc_lds = kCamSlots, nf_lds = 1;
+            int nc_lds = kCamSlots, nf_lds = 1, nv_lds = 1;
             for (const WinDesc& d : P.win)
                 if (d.cam_scr_off < 0) {
                     nc_lds = std::max(nc_lds, (int)d.nc);
                     nf_lds = std::max(nf_lds, (int)d.nf);
+                    nv_lds = std::max(nv_lds, (int)d.n_view);
                 }
-            asm_bytes = cam_assemble_scratch(nc_lds, kBlock) * (int)sizeof(double);
+            asm_bytes = cam_assemble_scratch(nc_lds, kBlock, nv_lds) * (int)sizeof(double);
             solve_bytes = cam_solve_scratch(nc_lds, kBlock, nf_lds) * (int)sizeof(double);  // the compact system: nf <= nc free slots
         }
         int max_lm = 1;
@@ -604,22 +605,23 @@ struct limo_ba_batch : Executor {
         listed = n_wl_win;
     }
 
-    // k_lin_lm<3, true>: three waves per SIMD, the window's view constants, the landmark block's running sums and the tail's inputs in
-    // LDS (kba_kernels.hip:lin_lm_block VLDS / ACCL) - the scalar loads of the view constants return out of order, so every use of one
-    // waited for all of them; through LDS the kernel is 7 % shorter (550 -> 513 us per round of 4096 slots, bench line +1.4 %,
-    // profiles/r05_experiment_lin_lm_occupancy.txt).  Batches whose windows have so many views that the copy would cost occupancy
-    // (> 48 KB of LDS per workgroup: more than ~16 views) and KBA_LIN_VLDS=0 (read once) take <3, false>: scalar loads, sums in
-    // registers - same bits.  KBA_LIN_WAVES=4 (read once): the 128-register build, 3 % shorter than <3, false> and 1.4 % lower on the
-    // bench line (two slot groups share the CUs).  KBA_LIN_LDS_PAD=<bytes>: extra dynamic LDS per workgroup (occupancy experiments).
+    // k_lin_lm<4, true> (the default since round 6): four waves per SIMD, the window's view constants, the landmark block's running sums and
+    // the tail's inputs in LDS (kba_kernels.hip:lin_lm_block VLDS / ACCL) - scalar loads of the view constants return out of order, so
+    // every use of one waited for all of them (round 5: 550 -> 513 us per round of 4096 slots through LDS).  With the camera-side sums in
+    // their raw form (kba_items.hpp:lin_cam_half0: the 3 x 6 pose Jacobian is never formed) the kernel needs 129 registers instead of 149,
+    // so the fourth wave costs nothing else: 505 -> 495 us per round, bench line +0.7 % (KBA_LIN_WAVES=3, read once, takes <3, true>).
+    // Batches whose windows have so many views that the copy would cost occupancy (> 48 KB of LDS per workgroup: more than ~16 views)
+    // and KBA_LIN_VLDS=0 (read once) take <., false>: scalar loads, sums in registers - same bits in all variants.
+    // KBA_LIN_LDS_PAD=<bytes>: extra dynamic LDS per workgroup (occupancy experiments).
     int lin_lds_set[3] = {0, 0, 0};
     void launch_lin_lm(int grid, hipStream_t s, const BatchView& v, const int32_t* wl) {
-        static const int lw = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 3;
+        static const int lw = std::getenv("KBA_LIN_WAVES") ? std::atoi(std::getenv("KBA_LIN_WAVES")) : 4;
         static const int want_vlds = std::getenv("KBA_LIN_VLDS") ? std::atoi(std::getenv("KBA_LIN_VLDS")) : 1;
         static const int pad = std::getenv("KBA_LIN_LDS_PAD") ? std::atoi(std::getenv("KBA_LIN_LDS_PAD")) : 0;
         const bool four = lw >= 4;
-        const bool vlds = !four && want_vlds != 0 && lin_lm_lds_bytes(P.Vmax, true, true) <= 48 * 1024;
+        const bool vlds = want_vlds != 0 && lin_lm_lds_bytes(P.Vmax, true, true) <= 48 * 1024;
         const int which = four ? 2 : vlds ? 1 : 0;
-        const void* fn = four ? (const void*)k_lin_lm<4, false> : vlds ? (const void*)k_lin_lm<3, true> : (const void*)k_lin_lm<3, false>;
+        const void* fn = four ? (vlds ? (const void*)k_lin_lm<4, true> : (const void*)k_lin_lm<4, false>) : vlds ? (const void*)k_lin_lm<3, true> : (const void*)k_lin_lm<3, false>;
         const int lds = lin_lm_lds_bytes(P.Vmax, four, vlds) + pad;
         if (lds > 48 * 1024 && lin_lds_set[which] < lds) {  // (beyond the default dynamic-LDS limit: many views, or the padding)
             note(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(k_lin_lm)");

@@ -145,7 +145,7 @@ struct EmuBatch : Executor {
 
     // camera assembly + the LM decision at the linearisation point (k_cam_assemble)
     void assemble() {
-        std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1));
+        std::vector<double> H((size_t)cam_assemble_scratch(kMaxNc, 1, kMaxViews));
         for (int w = 0; w < bv.n_win; ++w) {
             if (!bv.st[w].active || !bv.st[w].need_lin) continue;
             cam_assemble(bv, c, w, 0, 1, H.data());
@@ -187,9 +187,7 @@ struct EmuBatch : Executor {
                     damp_fail |= part[5] != 0.0;
                     for (int j = 0; j < wd.n_view; ++j) {
                         double* o = slices.data() + ((size_t)j * kLinWaves + t / 64) * kLinPartial;
-                        o[0] += cam[j].cost;
-                        for (int i = 0; i < 21; ++i) o[1 + i] += cam[j].U[i];
-                        for (int i = 0; i < 6; ++i) o[22 + i] += cam[j].g[i];
+                        for (int i = 0; i < kLinPartial; ++i) o[i] += cam[j].e[i];
                     }
                 }
                 for (int e = 0; e < wd.n_view * kLinPartial; ++e) {

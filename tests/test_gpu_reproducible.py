@@ -62,12 +62,12 @@ def test_results_do_not_depend_on_stale_device_memory():
 
 
 def test_linearisation_variants_give_the_same_bits():
-    """k_lin_lm exists three times: <3, true> (default: view constants, landmark sums and tail inputs in LDS), <3, false>
-    (KBA_LIN_VLDS=0: scalar loads, sums in registers - also what batches with many views per window take) and <4, false>
-    (KBA_LIN_WAVES=4: 128 registers, sums in LDS).  The same statements in the same order: every checksum of the poison script must be
-    the same to the last bit whichever one runs."""
+    """k_lin_lm exists four times: <4, true> (default: view constants, landmark sums and tail inputs in LDS, four waves per SIMD),
+    <3, true> (KBA_LIN_WAVES=3), <4, false> (KBA_LIN_VLDS=0: scalar loads of the view constants - also what batches with many views per
+    window take) and <3, false> (both: sums in registers).  The same statements in the same order: every checksum of the poison script
+    must be the same to the last bit whichever one runs."""
     out = []
-    for extra in ({}, {"KBA_LIN_VLDS": "0"}, {"KBA_LIN_WAVES": "4"}):
+    for extra in ({}, {"KBA_LIN_VLDS": "0"}, {"KBA_LIN_WAVES": "3"}, {"KBA_LIN_WAVES": "3", "KBA_LIN_VLDS": "0"}):
         env = dict(os.environ, **extra)
         env.pop("KBA_POISON", None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_poison_check.py"), "short"], capture_output=True, text=True, timeout=600,
@@ -76,4 +76,4 @@ def test_linearisation_variants_give_the_same_bits():
         lines = [l for l in r.stdout.splitlines() if "checksum" in l]
         assert len(lines) >= 3
         out.append(lines)
-    assert out[0] == out[1] == out[2]
+    assert out[0] == out[1] == out[2] == out[3]
