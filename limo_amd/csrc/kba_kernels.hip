@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kSchedThreads) void k_sched_scan(BatchView bv, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_sched_fill(BatchView bv, SolveConsts c) {
+__global__ __launch_bounds__(256) void k_sched_fill(BatchView bv, SolveConsts c, int view_consts_here) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (s >= bv.n_slots) return;
     const int32_t* off = bv.slot_cnt + (int64_t)s * (SL_COUNT + 1);
@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256) void k_sched_fill(BatchView bv, SolveConsts c)
     for (int i = lane; i < n_pg; i += 64) lp[i] = wd.sblk0 + i * c.schur_span;
     for (int i = lane; i < n_gg; i += 64) lg[i] = wd.sblk0 + wd.n_sblk_plain + i * c.schur_span_gp;
     if (lane == 0) L(SL_WIN)[0] = w;
+    // the per-view constants of a window that is linearised this round (the former k_view_consts launch: the wave is here anyway)
+    const WinState& st = bv.st[w];
+    if (view_consts_here && st.active && st.need_lin && lane < wd.n_view) view_consts_item(bv, wd.view0 + lane);
 }
 
 // ------------------------------------------------------------------------------------------ observations
@@ -1321,6 +1324,30 @@ __global__ void k_accept(BatchView bv) {
     if (l >= bv.TL) return;
     if (!bv.st[bv.lm_win[l]].accept) return;
     for (int q = 0; q < 3; ++q) bv.lm[3 * (int64_t)l + q] = bv.lm_c[3 * (int64_t)l + q];
+}
+
+// Streaming solve: what the step decision asks of a window's landmarks, in ONE launch over the landmark workgroups of the iterating
+// windows (the former k_accept and - for the next round - k_lm_damp): accepted -> candidate becomes current; rejected -> the landmark
+// blocks are damped again with the new radius (before the next round's Schur complement; after an accepted step the relinearisation
+// damps).  (Tried and dropped: the decision itself REPLICATED in every landmark workgroup instead of k_step_decide's launch - eight
+// workgroups per window each summing the ground-plane costs and evaluating the regulariser rows cost 70 us per round more than the
+// launch they saved: profiles/r06_experiment_launch_train.txt.)
+__global__ __launch_bounds__(kBlock) void k_after_step(BatchView bv, SolveConsts c, const int32_t* wl) {
+    const int b = wl_at(bv, wl, blockIdx.x);
+    if (b < 0) return;
+    const int w = bv.lblk_win[b];
+    const WinState& st = bv.st[w];
+    if (st.accept) {
+        if ((int)threadIdx.x < bv.lblk_n[b]) {
+            const int64_t l = bv.lblk_lm0[b] + threadIdx.x;
+            for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
+        }
+    } else if (st.active && st.redamp) {
+        int fail = 0;
+        if ((int)threadIdx.x < bv.lblk_n[b]) fail = lm_damp_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x);
+        const int any = __syncthreads_or(fail);
+        if (threadIdx.x == 0) bv.lblk_part[(int64_t)b * 8 + 5] = any ? 1.0 : 0.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ trimming

@@ -847,6 +847,10 @@ struct limo_ba_batch : Executor {
     };
     std::vector<StreamGroup> groups;
     int stream_groups_built = 0;
+    // The launch train of a round (round 6): the per-view constants inside k_sched_fill, accepted landmarks + re-damping in ONE launch
+    // (k_after_step) - 12 launches per round instead of 14.  KBA_UNFUSED_TRAIN=1 (read per solve) keeps k_view_consts, k_lm_damp and
+    // k_accept as launches of their own: the same device functions, the same bits (tests/test_gpu_reproducible.py).
+    bool fused_train = true;
     hipEvent_t start_ev = nullptr;
 
     void stream_teardown() {
@@ -862,14 +866,18 @@ struct limo_ba_batch : Executor {
         start_ev = nullptr;
     }
 
+    int stream_slots() const {
+        int n = std::min((int)P.n_win, std::max(1024, std::min(kSchedMaxSlots, (int)P.n_win / 4)));
+        if (const char* e = std::getenv("KBA_SLOTS")) n = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedMaxSlots}));
+        return n;
+    }
     int stream_setup(int n_groups) {
         if (stream_groups_built == n_groups) return LIMO_OK;
         (void)hipStreamSynchronize(ctx->stream);
         stream_teardown();  // (device blocks of an earlier layout stay with the batch until it is destroyed)
         // windows in flight: a quarter of the batch (so that the ramp-down at the end of the batch is a small part of the
         // solve), at least 1024 (a round of fewer windows is bound by the latency of its window-level kernels)
-        n_slots = std::min((int)P.n_win, std::max(1024, std::min(kSchedMaxSlots, (int)P.n_win / 4)));
-        if (const char* e = std::getenv("KBA_SLOTS")) n_slots = std::max(1, std::min({std::atoi(e), (int)P.n_win, kSchedMaxSlots}));
+        n_slots = stream_slots();
         set_span(P.n_win);
         int mx[SL_COUNT] = {0};
         for (const WinDesc& d : P.win) {
@@ -945,7 +953,7 @@ struct limo_ba_batch : Executor {
         if (round > 0) note(hipStreamWaitEvent(s, g.trim_ev, 0), "wait trim");  // last round's trimming re-armed its windows
         hipLaunchKernelGGL(k_sched_advance, dim3(cdiv(g.n_slots, 256)), dim3(256), 0, s, sv, c);
         hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(kSchedThreads), 0, s, sv, round);
-        hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(g.n_slots, 4)), dim3(256), 0, s, sv, c);
+        hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(g.n_slots, 4)), dim3(256), 0, s, sv, c, fused_train ? 1 : 0);
         LAUNCH_CHECK("scheduler kernels");
         // ---- trimming of the windows whose trimming solve just ended, on the side stream: k_trim_select is a
         //      latency-bound sort (one workgroup per window, ~0.3 ms) - the other windows iterate meanwhile, the
@@ -957,8 +965,8 @@ struct limo_ba_batch : Executor {
         hipLaunchKernelGGL(k_trim_select, dim3(cap[SL_TWIN]), dim3(kBlock), trim_bytes, g.trim_stream, sv, c);
         LAUNCH_CHECK("trim kernels");
         note(hipEventRecord(g.trim_ev, g.trim_stream), "record trim");
-        // ---- linearisation of the windows that need it
-        hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
+        // ---- linearisation of the windows that need it (their per-view constants: k_sched_fill above, or the launch of its own)
+        if (!fused_train) hipLaunchKernelGGL(k_view_consts, dim3(cap[SL_WIN]), dim3(64), 0, s, sv);
         {
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_LINEARIZE, s) : nullptr;
             if (cap[SL_LBLK]) launch_lin_lm(cap[SL_LBLK], s, sv, L(SL_LBLK));
@@ -967,7 +975,7 @@ struct limo_ba_batch : Executor {
         hipLaunchKernelGGL(k_cam_assemble, dim3(cap[SL_WIN]), dim3(kBlock), asm_bytes, s, sv, c, L(SL_WIN));
         LAUNCH_CHECK("linearisation kernels");
         // ---- trust-region step of the windows that iterate
-        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+        if (!fused_train && cap[SL_LBLK]) hipLaunchKernelGGL(k_lm_damp, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
         {
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_SCHUR, s) : nullptr;
             int span = c.schur_span, span_gp = c.schur_span_gp;
@@ -991,7 +999,12 @@ struct limo_ba_batch : Executor {
         hipLaunchKernelGGL(k_cam_solve, dim3(cap[SL_WIN]), dim3(kBlock), solve_bytes, s, sv, c, L(SL_WIN));
         if (cap[SL_LBLK]) hipLaunchKernelGGL(k_backsub, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
         hipLaunchKernelGGL(k_step_decide, dim3(cap[SL_WIN]), dim3(64), 0, s, sv, c, L(SL_WIN));
-        if (cap[SL_LBLK]) hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
+        if (cap[SL_LBLK]) {
+            if (fused_train)  // accepted landmarks / re-damping in one launch (kba_kernels.hip:k_after_step)
+                hipLaunchKernelGGL(k_after_step, dim3(cap[SL_LBLK]), dim3(kBlock), 0, s, sv, c, L(SL_LBLK));
+            else
+                hipLaunchKernelGGL(k_accept, dim3(cap[SL_LBLK]), dim3(256), 0, s, sv);
+        }
         LAUNCH_CHECK("step kernels");
         note(hipEventRecord(g.round_ev[round & 3], s), "record round");
     }
@@ -1119,13 +1132,16 @@ struct limo_ba_batch : Executor {
     int solve_streaming() {
         // two slot groups from 512 windows on (A/B at 256 .. 1536 windows: 5-9 % on the re-solve at every size; the FIRST solve of a batch
         // pays the second group's streams and events, which a one-shot batch of 256 windows does not earn back: 44 vs 36 ms)
-        int n_groups = P.n_win >= 512 ? 2 : 1;
+        // THREE groups once a group still holds ~1400 slots (4096 slots = batches of 16384 windows: 36.4 vs 35.8 k windows/s, alternating runs
+        // on one box; at 1024-2048 slots a third group costs 1-4 %, a fourth 7 % at 4096: profiles/r06_experiment_launch_train.txt)
+        int n_groups = stream_slots() >= 4096 ? 3 : P.n_win >= 512 ? 2 : 1;
         if (const char* e = std::getenv("KBA_GROUPS")) n_groups = std::max(1, std::min(4, std::atoi(e)));
         if (stream_setup(n_groups) != LIMO_OK) return LIMO_ERR_RUNTIME;
         set_span(P.n_win);
         hipStream_t s0 = ctx->stream;
         groups[0].stream = s0;
         HIP_TRY(ctx, hipMemsetAsync(d_sched_ctl, 0, sizeof(int32_t) * 8, s0));
+        fused_train = !(std::getenv("KBA_UNFUSED_TRAIN") && std::atoi(std::getenv("KBA_UNFUSED_TRAIN")) != 0);
         for (StreamGroup& g : groups) {
             HIP_TRY(ctx, hipMemsetAsync(g.d_slot_win, 0xFF, sizeof(int32_t) * std::max(1, g.n_slots), s0));
             for (int i = 0; i < 4; ++i) g.h_done[i] = 0;

@@ -77,3 +77,20 @@ def test_linearisation_variants_give_the_same_bits():
         assert len(lines) >= 3
         out.append(lines)
     assert out[0] == out[1] == out[2] == out[3]
+
+
+def test_fused_launch_train_gives_the_same_bits():
+    """The streaming solve's round since round 6: per-view constants inside k_sched_fill, accepted landmarks + re-damping in ONE launch
+    (k_after_step).  KBA_UNFUSED_TRAIN=1 runs k_view_consts, k_lm_damp and k_accept as launches of their own - the same device
+    functions in the same order per window: the same bits."""
+    out = []
+    for extra in ({}, {"KBA_UNFUSED_TRAIN": "1"}):
+        env = dict(os.environ, **extra)
+        env.pop("KBA_POISON", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_poison_check.py")], capture_output=True, text=True, timeout=900,
+                           env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if "checksum" in l]
+        assert len(lines) == 6
+        out.append(lines)
+    assert out[0] == out[1]
