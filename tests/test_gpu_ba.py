@@ -44,6 +44,30 @@ def test_evaluate_matches_oracle(ctx, oracle, apply_loss):
     assert np.abs(jl0 - jl1).max() <= 1e-9 * np.abs(jl0).max()
 
 
+@pytest.mark.parametrize("n_lm,depth_prob,n_kf,stereo", [
+    (1, 1.0, 3, 0.0), (8, 0.0, 2, 0.0), (64, 0.5, 3, 0.0), (65, 1.0, 3, 0.0), (70, 0.45, 3, 0.54), (129, 0.02, 4, 0.0),
+    (700, 0.9, 5, 0.0), (1300, 0.45, 3, 0.0), (3000, 0.2, 2, 0.54)])
+def test_evaluate_layout_edge_cases(ctx, oracle, n_lm, depth_prob, n_kf, stereo):
+    """The materialised pass writes the rows that exist through wave-sized chunks of 64-aligned observation ranges, compact depth
+    planes and a per-workgroup staging buffer (kba_kernels.hip:k_evaluate): windows whose views end ON a chunk boundary, one
+    observation past it, inside the first chunk; views of more than 1024 observations (two observation blocks); no depth at all, a
+    depth on every observation; two cameras per keyframe.  Every entry against the oracle's dual numbers, <= 1e-9, and the flags and
+    the total cost exactly as the oracle has them."""
+    w = synth.make_window(4000 + n_lm, n_kf=n_kf, n_lm=n_lm, depth_prob=depth_prob, stereo_baseline=stereo)
+    o = default_options()
+    for apply_loss in (True, False):
+        c0, r0, jp0, jl0, v0 = oracle.evaluate(w, o, apply_loss)
+        c1, r1, jp1, jl1, v1 = ctx.evaluate(w, o, apply_loss)
+        assert np.array_equal(v0, v1)
+        assert abs(c0 - c1) <= 1e-12 * max(1.0, abs(c0))
+        assert np.abs(r0 - r1).max() <= 1e-9 * max(1.0, np.abs(r0).max())
+        assert np.abs(jp0 - jp1).max() <= 1e-9 * max(1.0, np.abs(jp0).max())
+        assert np.abs(jl0 - jl1).max() <= 1e-9 * max(1.0, np.abs(jl0).max())
+        # a row that does not exist is zero: the depth row of an observation without a depth measurement
+        no_d = w.obs_d <= 0
+        assert not r1.reshape(-1, 3)[no_d, 2].any() and not jp1.reshape(-1, 18)[no_d, 12:].any() and not jl1.reshape(-1, 9)[no_d, 6:].any()
+
+
 def test_ground_and_regulariser_rows_match_oracle(ctx, oracle):
     """SURVEY §8 B3 / B4 per entry on the GPU: ground-plane height rows and every regulariser row (scale, normal / distance
     smoothness, plane motion, global normal, speed prior) with their tangent-space Jacobians, <= 1e-9 against the oracle's
