@@ -420,9 +420,19 @@ __device__ __forceinline__ void lin_lm_block(const BatchView& bv, const SolveCon
     const int gl = bv.lblk_lm0[b] + (in_block ? (int)threadIdx.x : n - 1);  // lanes past the end shadow the last landmark
     const int state = in_block ? bv.lm_state[gl] : 0;
     LinIn in;
-    in.p[0] = bv.lm[3 * (int64_t)gl];
-    in.p[1] = bv.lm[3 * (int64_t)gl + 1];
-    in.p[2] = bv.lm[3 * (int64_t)gl + 2];
+    // A window whose last step was ACCEPTED linearises at the candidate point: the landmark is read from lm_c and moves into lm
+    // right here (the streaming solve has no pass of its own for that: k_after_step; the other paths copy it themselves - the same
+    // values, so reading lm_c instead of lm changes nothing for them).
+    const bool take_candidate = st.accept != 0;  // (workgroup-uniform)
+    const double* lm_src = take_candidate ? bv.lm_c : bv.lm;
+    in.p[0] = lm_src[3 * (int64_t)gl];
+    in.p[1] = lm_src[3 * (int64_t)gl + 1];
+    in.p[2] = lm_src[3 * (int64_t)gl + 2];
+    if (take_candidate && in_block) {
+        bv.lm[3 * (int64_t)gl] = in.p[0];
+        bv.lm[3 * (int64_t)gl + 1] = in.p[1];
+        bv.lm[3 * (int64_t)gl + 2] = in.p[2];
+    }
     in.w = bv.lm_weight[gl];
     in.sw = sqrt(in.w);
     LmTailIn tail;  // (fetched here, in front of the view loop's stores: kba_items.hpp:LmTailIn)
@@ -1326,10 +1336,10 @@ __global__ void k_accept(BatchView bv) {
     for (int q = 0; q < 3; ++q) bv.lm[3 * (int64_t)l + q] = bv.lm_c[3 * (int64_t)l + q];
 }
 
-// Streaming solve: what the step decision asks of a window's landmarks, in ONE launch over the landmark workgroups of the iterating
-// windows (the former k_accept and - for the next round - k_lm_damp): accepted -> candidate becomes current; rejected -> the landmark
-// blocks are damped again with the new radius (before the next round's Schur complement; after an accepted step the relinearisation
-// damps).  (Tried and dropped: the decision itself REPLICATED in every landmark workgroup instead of k_step_decide's launch - eight
+// Streaming solve: what a REJECTED step asks of a window's landmarks - the landmark blocks are damped again with the new radius, before
+// the next round's Schur complement (the former k_lm_damp, at the end of the round instead of in the middle of the next one).  After
+// an ACCEPTED step there is nothing to do here: the relinearisation (lin_lm_block) reads the candidate landmarks, moves them into lm
+// and damps (the former k_accept: 48 B per landmark read and written by a pass of its own).  (Tried and dropped: the decision itself REPLICATED in every landmark workgroup instead of k_step_decide's launch - eight
 // workgroups per window each summing the ground-plane costs and evaluating the regulariser rows cost 70 us per round more than the
 // launch they saved: profiles/r06_experiment_launch_train.txt.)
 __global__ __launch_bounds__(kBlock) void k_after_step(BatchView bv, SolveConsts c, const int32_t* wl) {
@@ -1337,12 +1347,7 @@ __global__ __launch_bounds__(kBlock) void k_after_step(BatchView bv, SolveConsts
     if (b < 0) return;
     const int w = bv.lblk_win[b];
     const WinState& st = bv.st[w];
-    if (st.accept) {
-        if ((int)threadIdx.x < bv.lblk_n[b]) {
-            const int64_t l = bv.lblk_lm0[b] + threadIdx.x;
-            for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
-        }
-    } else if (st.active && st.redamp) {
+    if (!st.accept && st.active && st.redamp) {
         int fail = 0;
         if ((int)threadIdx.x < bv.lblk_n[b]) fail = lm_damp_lane(bv, c, w, bv.lblk_lm0[b] + threadIdx.x);
         const int any = __syncthreads_or(fail);
