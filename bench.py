@@ -43,6 +43,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # fp64 matrix peak: 256 CU x 4 SIMD x 32 FLOP/clk x
 # HBM bytes the counters see per launch and `roofline.traffic_frac` = traffic / time / 8 TB/s (round 5 printed that one as `frac`).
 FUSED_BYTES_PER_OBS = 52 + 16
 FUSED_BYTES_PER_LANDMARK = 72
+ACCEPT_MOVE_BYTES_PER_LANDMARK = 24  # the accepted step's landmark written into place by the relinearisation (k_accept's job until round 5)
 # The kernel is bound by the fp64 pipe, not by HBM, so the line also prices it there: `roofline.fp64` =
 # ALGORITHMIC fp64 flops / kernel time / 78.6 TF.  Per (landmark, view) pair the fused path is priced at ~300 multiply-adds whatever the
 # code looks like (the round-6 kernel executes ~240: its camera-side sums never form the 3 x 6 pose Jacobian - the count stays the review's, so
@@ -241,7 +242,10 @@ def main():
         # ---- roofline of the Jacobian evaluation (k_lin_lm): what one launch linearises, from the reports of this very run
         lin_obs = sum(r["num_linearizations"] * w.n_obs for r, w in zip(reps, windows)) * prof_steps
         lin_lms = sum(r["num_linearizations"] * w.n_lm for r, w in zip(reps, windows)) * prof_steps
-        alg_bytes = FUSED_BYTES_PER_OBS * lin_obs + FUSED_BYTES_PER_LANDMARK * lin_lms
+        # (round 6: the kernel also moves the landmarks of an accepted step from the candidate buffer into place - the former k_accept
+        # pass -: 24 B written per landmark and accepted step; every accepted step is followed by exactly one linearisation)
+        acc_lms = sum(r["successful_steps"] * w.n_lm for r, w in zip(reps, windows)) * prof_steps
+        alg_bytes = FUSED_BYTES_PER_OBS * lin_obs + FUSED_BYTES_PER_LANDMARK * lin_lms + ACCEPT_MOVE_BYTES_PER_LANDMARK * acc_lms
         launches = max(1, stats["linearize_launches"])
         lin_ms = stats["linearize_ms"]
         lin_s = max(1e-12, lin_ms * 1e-3)
@@ -294,7 +298,8 @@ def main():
                 "avg_launch_ms": lin_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "algorithmic_unit": "SURVEY 8d fused path: 52 B read per observation + 72 B (V, g) written per landmark, + the 16 B per observation of factored "
-                                    "Jacobian planes this design stores in place of W (144 B per pair); x the observations / landmarks this run linearised",
+                                    "Jacobian planes this design stores in place of W (144 B per pair), + 24 B per landmark and ACCEPTED step (the landmark moved into place by the "
+                                    "relinearisation since round 6); x the observations / landmarks this run linearised",
                 "fp64": {"achieved": FP64_FLOPS_PER_LINEARISED_OBS * lin_obs / lin_s / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": FP64_FLOPS_PER_LINEARISED_OBS * lin_obs / lin_s / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "algorithmic_flops_per_observation": FP64_FLOPS_PER_LINEARISED_OBS,

@@ -7,7 +7,8 @@
 //                                                    F^T F / F^T r camera sums; the landmark's ground-plane row
 //                                                    (GroundPlaneHeightRegularization, cost_functors_ceres.hpp:355-392); E^T E,
 //                                                    E^T r (SchurEliminator chunk), Jacobi column scale, damped 3x3 Cholesky
-// k_lm_damp       1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark after a REJECTED step
+// k_lm_damp /     1 per landmark             HBM     (E^T E + D^2) Cholesky inverse per landmark after a REJECTED step (k_after_step: the streaming
+// k_after_step                                       solve's form, at the end of the round)
 // k_schur_lean/_wide  wave / 512 lanes       MFMA    S -= sum_i Y'_i Y'_i^T   (v_mfma_f64_16x16x4_f64 SYRK from LDS tiles)
 // k_cam_assemble  workgroup per window       -       camera-camera blocks, regularisers, IterationZero / step tail
 // k_cam_solve     workgroup per window       -       reduced camera system: dense Cholesky in LDS, camera step
@@ -16,6 +17,8 @@
 //                                                    ground-plane row at the candidate
 // k_step_decide   1 per window               -       TrustRegionMinimizer step acceptance (kba_lm.hpp)
 // k_trim_*        1 per obs / lm / window    HBM     robust_optimization::solveTrimmed residual evaluation + quantile
+// k_evaluate      1 per obs, wave = 64       HBM     Problem::Evaluate: residuals, J_pose, J_point of every observation written out (the
+//                 aligned observations       stores  MATERIALISED pass SURVEY 8d grades); k_eval_rows: the ground-plane / regulariser rows
 //
 // Every workgroup first looks at its window's LM state and returns if the window is not iterating, so one launch
 // sequence serves a whole batch of windows that converge at different iterations.
