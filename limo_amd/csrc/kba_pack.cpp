@@ -741,27 +741,24 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         // first depth observation.
         P.echunk.clear();
         P.obs_rank.assign((size_t)std::max(1, P.TO), -1);
-        P.TD = 0;
-        for (int o = 0; o < P.TO; ++o)
-            if (P.obs_d[o] > 0.0f) P.obs_rank[o] = P.TD++;
+        std::vector<int32_t> before((size_t)P.TO + 1, 0);  // depth observations in front of observation o
+        for (int o = 0; o < P.TO; ++o) {
+            const bool dep = P.obs_d[o] > 0.0f;
+            if (dep) P.obs_rank[o] = before[o];
+            before[o + 1] = before[o] + (dep ? 1 : 0);
+        }
+        P.TD = before[P.TO];
         P.SD = pad64(std::max(1, P.TD)) + 64;
         for (int b = 0; b < P.n_blk; ++b) {
             const int o0 = P.blk_obs0[b], o1 = o0 + P.blk_n[b];
-            int next_rank = 0;  // rank of the first depth observation at or behind `a`
-            for (int o = o0; o < P.TO; ++o)
-                if (P.obs_rank[o] >= 0) {
-                    next_rank = P.obs_rank[o];
-                    break;
-                }
             for (int a = o0; a < o1; a += 64) {  // (o0 is a multiple of 64: views are aligned, blocks are 1024 apart inside one)
                 EvalChunk ch;
                 ch.base = a;
                 ch.view = P.blk_view[b];
                 ch.o0 = o0;
                 ch.o1 = o1;
-                ch.dep0 = next_rank;
+                ch.dep0 = before[a];
                 ch.pad = 0;
-                for (int o = a; o < std::min(o1, a + 64); ++o) next_rank += P.obs_rank[o] >= 0 ? 1 : 0;
                 P.echunk.push_back(ch);
             }
         }

@@ -238,8 +238,19 @@ struct limo_ba_batch : Executor {
                 if (e.init) std::memcpy(static_cast<char*>(ctx->staging) + e.off, e.init, e.bytes);
             if (init_total) HIP_TRY(ctx, hipMemcpyAsync(arena, ctx->staging, init_total, hipMemcpyHostToDevice, ctx->stream));
         } else {
-            for (const Ent& e : ents)
-                if (e.init) HIP_TRY(ctx, hipMemcpyAsync(arena + e.off, e.init, e.bytes, hipMemcpyHostToDevice, ctx->stream));
+            // (a host array that initialises several device buffers - the landmarks: current, candidate and pristine copy - crosses the
+            // bus ONCE and is copied on the device for the others: 96 MB of 390 less for 1024 C2 windows, 12.2 -> ~9 ms)
+            for (size_t i = 0; i < ents.size(); ++i) {
+                const Ent& e = ents[i];
+                if (!e.init) continue;
+                const Ent* first = nullptr;
+                for (size_t j = 0; j < i && !first; ++j)
+                    if (ents[j].init == e.init && ents[j].bytes == e.bytes) first = &ents[j];
+                if (first)
+                    HIP_TRY(ctx, hipMemcpyAsync(arena + e.off, arena + first->off, e.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                else
+                    HIP_TRY(ctx, hipMemcpyAsync(arena + e.off, e.init, e.bytes, hipMemcpyHostToDevice, ctx->stream));
+            }
         }
         if (zero_total) HIP_TRY(ctx, hipMemsetAsync(arena + init_total, 0, zero_total, ctx->stream));
         if (status != LIMO_OK) return status;
