@@ -1209,6 +1209,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     schur_lean_group<TM, GP, false>(bv, sb, span, span_gp, smem);
 }
 
+// The plain and the ground-plane groups of a round in ONE launch (workgroups [0, n_plain_cap) take the plain list, the others the
+// ground-plane list): for rounds with few windows in flight, where each of the two launches is one tile chain of latency (21 + 25 us
+// at 16 windows: scripts/gpu_round_timeline.py) and the two lists are independent.  The kernel carries the larger variant's registers
+// (218: two waves per SIMD), so it is only used while the batch drains (limo_hip.hip: kSchurPairBound); same device functions, same
+// slabs, same bits.
+template <int TMP, int TMG>
+__global__ __launch_bounds__(64) void k_schur_lean_pair(BatchView bv, const int32_t* wl_plain, int n_plain_cap, const int32_t* wl_gp, int span, int span_gp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x < n_plain_cap) {
+        const int sb = wl_at(bv, wl_plain, blockIdx.x);
+        if (sb >= 0) schur_lean_group<TMP, false, false>(bv, sb, span, span_gp, smem);
+    } else {
+        const int sb = wl_at(bv, wl_gp, blockIdx.x - n_plain_cap);
+        if (sb >= 0) schur_lean_group<TMG, true, false>(bv, sb, span, span_gp, smem);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ camera system
 // (three waves per SIMD = three windows per CU: 168 registers; the ground-plane Gram tile of round 5 took the allocation to 172)
 #ifndef KBA_CAM_ASM_WAVES

@@ -78,6 +78,8 @@ struct limo_ba_batch : Executor {
     const void* schur_fn_leangp = nullptr;
     int leangp_lds_bytes = 0;
     int schur_vp = 1, schur_vg = 1;  // the same choice as template arguments of the one-launch solve (k_solve_coop)
+    bool schur_pair_ok = false;      // the batch's variants are <2, false> / <3, true>: k_schur_lean_pair<2, 3> exists for them
+    static constexpr int kSchurPairBound = 384;  // windows in flight in a slot group up to which a round launches the pair kernel (192: -0.7 %, 768: -9 % at 1024 windows)
     std::vector<uint8_t> win_fast;  // per window: k_schur<.., true> applies (<= 4 keyframes with free slots, one view each)
     int avg_sblk = 0;
     int32_t* h_flags = nullptr;  // pinned
@@ -347,6 +349,9 @@ struct limo_ba_batch : Executor {
                 schur_fn_leangp = tg <= 1 ? (const void*)k_schur_lean<1, true, 3> : tg == 2 ? (const void*)k_schur_lean<2, true, 2> : (const void*)k_schur_lean<3, true, 2>;
                 leangp_lds_bytes = schur_lean_lds_bytes(max_nf + 1);
                 HIP_TRY(ctx, hipFuncSetAttribute(schur_fn_leangp, hipFuncAttributeMaxDynamicSharedMemorySize, leangp_lds_bytes));
+                schur_pair_ok = schur_vp == 2 && schur_vg == 3 && !(std::getenv("KBA_NO_SCHUR_PAIR") && std::atoi(std::getenv("KBA_NO_SCHUR_PAIR")) != 0);
+                if (schur_pair_ok)
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_schur_lean_pair<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(plain_lds_bytes, leangp_lds_bytes)));
             }
             if (any_gen) {
                 const int tiles = t_gen * (t_gen + 1) / 2, npw = (tiles + kWideWaves - 1) / kWideWaves;
@@ -990,12 +995,22 @@ struct limo_ba_batch : Executor {
         {
             EventPair* ep = time_kernels ? timed(LIMO_KERNEL_SCHUR, s) : nullptr;
             int span = c.schur_span, span_gp = c.schur_span_gp;
-            if (cap[SL_SPLAIN]) {
+            // few windows in flight (the batch drains): both fast-class lists in one launch (kba_kernels.hip:k_schur_lean_pair)
+            static const int pair_bound = std::getenv("KBA_SCHUR_PAIR_BOUND") ? std::atoi(std::getenv("KBA_SCHUR_PAIR_BOUND")) : kSchurPairBound;
+            const bool pair = schur_pair_ok && bound <= pair_bound && cap[SL_SPLAIN] && cap[SL_SFGP];
+            if (pair) {
+                const int32_t *wlp = L(SL_SPLAIN), *wlg = L(SL_SFGP);
+                int n_plain_cap = cap[SL_SPLAIN];
+                void* args[] = {(void*)&sv, (void*)&wlp, (void*)&n_plain_cap, (void*)&wlg, (void*)&span, (void*)&span_gp};
+                note(hipLaunchKernel((const void*)k_schur_lean_pair<2, 3>, dim3(cap[SL_SPLAIN] + cap[SL_SFGP]), dim3(64), args, std::max(plain_lds_bytes, leangp_lds_bytes), s),
+                     "launch k_schur_lean_pair");
+            }
+            if (!pair && cap[SL_SPLAIN]) {
                 const int32_t* wlp = L(SL_SPLAIN);
                 void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
                 note(hipLaunchKernel(schur_fn_plain, dim3(cap[SL_SPLAIN]), dim3(64), args, plain_lds_bytes, s), "launch k_schur_lean");
             }
-            if (cap[SL_SFGP]) {
+            if (!pair && cap[SL_SFGP]) {
                 const int32_t* wlp = L(SL_SFGP);
                 void* args[] = {(void*)&sv, (void*)&wlp, (void*)&span, (void*)&span_gp};
                 note(hipLaunchKernel(schur_fn_leangp, dim3(cap[SL_SFGP]), dim3(64), args, leangp_lds_bytes, s), "launch k_schur_lean (gp)");

@@ -84,7 +84,7 @@ def test_fused_launch_train_gives_the_same_bits():
     (k_after_step).  KBA_UNFUSED_TRAIN=1 runs k_view_consts, k_lm_damp and k_accept as launches of their own - the same device
     functions in the same order per window: the same bits."""
     out = []
-    for extra in ({}, {"KBA_UNFUSED_TRAIN": "1"}):
+    for extra in ({}, {"KBA_UNFUSED_TRAIN": "1"}, {"KBA_NO_SCHUR_PAIR": "1"}):
         env = dict(os.environ, **extra)
         env.pop("KBA_POISON", None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_poison_check.py")], capture_output=True, text=True, timeout=900,
@@ -93,4 +93,4 @@ def test_fused_launch_train_gives_the_same_bits():
         lines = [l for l in r.stdout.splitlines() if "checksum" in l]
         assert len(lines) == 6
         out.append(lines)
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]  # (KBA_NO_SCHUR_PAIR=1: the draining rounds' two Schur lists as two launches instead of k_schur_lean_pair)
