@@ -22,6 +22,46 @@
 
 namespace kba {
 
+// ---- the arena of the big pack arrays (kba_pack.hpp:PackArena)
+namespace {
+thread_local PackArena* t_pack_arena = nullptr;
+std::mutex g_arena_ranges_m;
+std::vector<std::pair<const char*, size_t>> g_arena_ranges;
+std::atomic<int> g_arena_range_count{0};  // (pack_arena_owns is on every deallocation path: no lock while no arena exists)
+}  // namespace
+void pack_arena_lend(PackArena* a) { t_pack_arena = a; }
+void pack_arena_register(const void* base, size_t cap, bool add) {
+    std::lock_guard<std::mutex> lk(g_arena_ranges_m);
+    if (add) {
+        g_arena_ranges.emplace_back(static_cast<const char*>(base), cap);
+    } else {
+        for (size_t i = 0; i < g_arena_ranges.size(); ++i)
+            if (g_arena_ranges[i].first == base) {
+                g_arena_ranges.erase(g_arena_ranges.begin() + i);
+                break;
+            }
+    }
+    g_arena_range_count.store((int)g_arena_ranges.size(), std::memory_order_release);
+}
+bool pack_arena_owns(const void* p) {
+    if (g_arena_range_count.load(std::memory_order_acquire) == 0) return false;
+    std::lock_guard<std::mutex> lk(g_arena_ranges_m);
+    const char* q = static_cast<const char*>(p);
+    for (const auto& r : g_arena_ranges)
+        if (q >= r.first && q < r.first + r.second) return true;
+    return false;
+}
+void* pack_arena_take(size_t bytes) {
+    PackArena* a = t_pack_arena;
+    if (!a) return nullptr;
+    const size_t need = (bytes + 255) / 256 * 256;
+    a->wanted += need;
+    if (!a->base || a->used + need > a->cap) return nullptr;
+    void* p = a->base + a->used;
+    a->used += need;
+    return p;
+}
+
 namespace {
 inline int64_t pad64(int64_t n) {
     return (n + 63) / 64 * 64;
@@ -176,6 +216,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         err = "no windows";
         return LIMO_ERR_INVALID;
     }
+    const auto t_p0 = std::chrono::steady_clock::now();
     P = PackedBatch();
     P.n_win = n;
     P.n_shards = std::max(1, po.shards);
@@ -288,6 +329,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         P.TV += nv;
         P.TO += d.n_obs;
     }
+    const auto t_p0b = std::chrono::steady_clock::now();
     P.SO = pad64(std::max(1, P.TO)) + kObsBlock;  // + a dump area: lanes past the end of a partial block store there (k_linearize)
     P.SL = pad64(std::max(1, P.TL));
     P.pose.resize((size_t)P.TK * 7);
@@ -304,9 +346,9 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
     P.lm.resize((size_t)P.TL * 3);
     P.lm_win.resize(P.TL);
     P.lm_id.resize(P.TL);
-    P.lm_gp.assign(P.TL, -1);
+    P.lm_gp.resize(P.TL);  // (-1 / 0 per window in pass 2: first touch by the thread that fills the window)
     P.lm_weight.resize(P.TL);
-    P.lm_state.assign(P.TL, 0);
+    P.lm_state.resize(P.TL);
     P.lm_slot.resize((size_t)std::max(1, P.Vmax) * P.SL);  // filled with -1 per window in pass 2, padding here
     for (int v = 0; v < std::max(1, P.Vmax); ++v)
         for (int64_t l = P.TL; l < P.SL; ++l) P.lm_slot[(size_t)v * P.SL + l] = -1;
@@ -507,6 +549,7 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         d.n_depth = depth_blocks;
         d.n_repr = W.n_obs;
         for (int l = 0; l < W.n_lm; ++l) P.lm_state[d.lm0 + l] = lm_nobs[l] > 0 ? (po.pose_only ? 2 : 1) : 0;
+        for (int l = 0; l < W.n_lm; ++l) P.lm_gp[d.lm0 + l] = -1;
 
         // ---- ground-plane rows
         d.gp0 = (int)L.gp_lm.size();
@@ -727,7 +770,8 @@ int pack_windows(int32_t n, const limo_ba_window* windows, const limo_ba_options
         L = Local();
     });
     if (std::getenv("KBA_PACK_TRACE"))
-        std::fprintf(stderr, "[kba] pack: fill %.1f ms, merge %.1f ms\n", std::chrono::duration<double, std::milli>(t_p2 - t_p1).count(),
+        std::fprintf(stderr, "[kba] pack: views + sizes %.1f ms, arrays %.1f ms, fill %.1f ms, merge %.1f ms\n", std::chrono::duration<double, std::milli>(t_p0b - t_p0).count(),
+                     std::chrono::duration<double, std::milli>(t_p1 - t_p0b).count(), std::chrono::duration<double, std::milli>(t_p2 - t_p1).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
     P.TG = (int)P.gp_lm.size();
     P.SG = pad64(std::max(1, P.TG));

@@ -19,12 +19,38 @@ namespace kba {
 // std::vector whose resize() leaves trivially-constructible elements uninitialised: the big per-observation /
 // per-landmark arrays are written exactly once by the (threaded) packing, zero-filling them first only costs a
 // serial pass of page faults.
+// The big arrays may come out of an ARENA the caller lends to one pack_windows call (the HIP library: a pinned host block the
+// context keeps between batches - no page faults on first touch, and the upload is a DMA straight out of where the pack wrote).
+// A bump allocator: requests of kPackArenaMin bytes or more are carved from it while it has room, everything else (and everything
+// when no arena is lent) comes from the heap; memory of an arena is never freed piecewise - its owner recycles the block when the
+// PackedBatch is gone (pack_arena_owns: deallocate() of such a pointer is a no-op).
+struct PackArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    size_t wanted = 0;  // bytes the arena-sized requests of this pack added up to (what the arena should hold next time)
+};
+constexpr size_t kPackArenaMin = 64u << 10;
+void pack_arena_lend(PackArena* a);              // this thread's pack_windows carves from *a until pack_arena_lend(nullptr)
+void pack_arena_register(const void* base, size_t cap, bool add);  // the ranges pack_arena_owns knows (process-wide)
+bool pack_arena_owns(const void* p);
+void* pack_arena_take(size_t bytes);             // nullptr: no arena lent / no room
+
 template <typename T>
 struct default_init_allocator : std::allocator<T> {
     template <typename U>
     struct rebind {
         using other = default_init_allocator<U>;
     };
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= kPackArenaMin)
+            if (void* p = pack_arena_take(bytes)) return static_cast<T*>(p);
+        return static_cast<T*>(::operator new(bytes));
+    }
+    void deallocate(T* p, size_t) noexcept {
+        if (pack_arena_owns(p)) return;
+        ::operator delete(p);
+    }
     template <typename U>
     void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
         ::new (static_cast<void*>(p)) U;
@@ -52,11 +78,11 @@ struct PackedBatch {
     std::vector<int32_t> kf_win, kf_blk0, kf_nblk, kf_gp0, kf_ngp;
     std::vector<uint8_t> cmask, cpresent;
     std::vector<int32_t> cslot;
-    std::vector<int32_t> lm_gp;
+    uvec<int32_t> lm_gp;
     uvec<int32_t> lm_win, lm_slot;
     uvec<int32_t> lm_id;  // packed landmark -> index in the caller's window
     uvec<double> lm_weight;
-    std::vector<uint8_t> lm_state;
+    uvec<uint8_t> lm_state;
     std::vector<int32_t> view_kf, view_win;
     std::vector<double> view_cam;
     std::vector<int32_t> blk_view, blk_obs0, blk_n;

@@ -49,6 +49,7 @@ struct EventPair {
 struct limo_ba_batch : Executor {
     limo_ctx* ctx = nullptr;
     PackedBatch P;
+    bool holds_pack_arena = false;  // P's big arrays live in ctx->pack_arena
     BatchView bv;
     SolveConsts c;
     limo_ba_options opts;
@@ -131,6 +132,10 @@ struct limo_ba_batch : Executor {
     double last_solve_sec = 0.0;
 
     ~limo_ba_batch() override {
+        // (the arrays of P that live in the context's pinned pack arena are not freed one by one - kba_pack.hpp:PackArena -, the arena
+        // is free for the next batch from here on; whatever of this batch's upload is still in flight only feeds device blocks that
+        // go back to the pool below and are rewritten, in stream order, by their next user)
+        if (holds_pack_arena) ctx->pack_arena_busy = false;
         for (auto& a : allocs) ctx->pool_free(a.first, a.second);
         if (h_active) ctx->host_free(h_active, 64);
         if (h_flags) ctx->host_free(h_flags, h_flags_bytes);
@@ -1332,7 +1337,47 @@ static int batch_create_impl(limo_ctx* ctx, int32_t n, const limo_ba_window* win
     b->opts = o;
     b->c = make_consts(o);
     const auto t_c0 = std::chrono::steady_clock::now();
+    // Large batches pack into the context's pinned arena when no other live batch holds it (limo_ctx.hpp:pack_arena; KBA_NO_PACK_ARENA=1
+    // keeps the heap).  The first large batch of a context only measures what it would have needed; the arena is made right behind its
+    // packing, for the next one.
+    static const bool arena_off = std::getenv("KBA_NO_PACK_ARENA") && std::atoi(std::getenv("KBA_NO_PACK_ARENA")) != 0;
+    PackArena lend;
+    const bool lending = !arena_off && n >= 128 && !ctx->pack_arena_busy && hipSetDevice(ctx->device) == hipSuccess;
+    auto arena_resize = [&](size_t wanted) {  // (only while no batch holds the arena)
+        const size_t step = size_t(64) << 20;
+        const size_t cap = std::min(limo_ctx::kPackArenaMax, (wanted + wanted / 8 + step - 1) / step * step);
+        if (cap <= ctx->pack_arena_cap) return;
+        if (ctx->pack_arena) {
+            pack_arena_register(ctx->pack_arena, ctx->pack_arena_cap, false);
+            (void)hipHostFree(ctx->pack_arena);
+            ctx->pack_arena = nullptr;
+            ctx->pack_arena_cap = 0;
+        }
+        if (hipHostMalloc(&ctx->pack_arena, cap) == hipSuccess) {
+            ctx->pack_arena_cap = cap;
+            pack_arena_register(ctx->pack_arena, cap, true);
+        } else {
+            (void)hipGetLastError();
+            ctx->pack_arena = nullptr;
+        }
+    };
+    if (lending) {
+        if (ctx->pack_arena && ctx->pack_arena_wanted > ctx->pack_arena_cap) arena_resize(ctx->pack_arena_wanted);  // the last batch did not fit
+        lend.base = static_cast<char*>(ctx->pack_arena);
+        lend.cap = ctx->pack_arena_cap;
+        pack_arena_lend(&lend);
+    }
     int rc = pack_windows(n, windows, o, po, b->P, ctx->err);
+    pack_arena_lend(nullptr);
+    if (lending) {
+        ctx->pack_arena_wanted = std::max(ctx->pack_arena_wanted, lend.wanted);
+        if (lend.used > 0) {
+            ctx->pack_arena_busy = true;
+            b->holds_pack_arena = true;
+        } else if (!ctx->pack_arena && lend.wanted > 0) {
+            arena_resize(lend.wanted);  // the first large batch of the context: ready for the next one
+        }
+    }
     const auto t_c1 = std::chrono::steady_clock::now();
     if (rc == LIMO_OK) {
         if (hipSetDevice(ctx->device) != hipSuccess) rc = LIMO_ERR_NO_DEVICE;
