@@ -162,7 +162,9 @@ int limo_abi_version(void);
  * the context for the next call and are freed by limo_ctx_destroy: up to 32 MB a few per power-of-two size class, larger ones
  * (the arena of a big batch) one per 64 MB class and at most 16 GB altogether (environment KBA_POOL_LARGE_MB sets that cap, 0
  * keeps none).  Idle blocks never cost an allocation: when the device is out of memory they are released, largest first, and
- * the allocation is tried again. */
+ * the allocation is tried again.  HOST side: a context that has created a batch of 128 windows or more keeps ONE page-locked
+ * arena (sized for that batch, at most 1 GB) that the flattened arrays of its next large batches are written into and uploaded
+ * from - one live batch at a time holds it, the others use the heap; environment KBA_NO_PACK_ARENA=1 switches it off. */
 int limo_ctx_create(int device, limo_ctx** out);
 void limo_ctx_destroy(limo_ctx* ctx);
 /* Use an existing hipStream_t (e.g. the host framework's current stream); NULL = the context's own. */
