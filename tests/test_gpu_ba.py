@@ -394,3 +394,31 @@ def test_window_of_the_drive_with_a_failed_landmark_cholesky(ctx, oracle):
     rg, ro, _, _ = check_solve_parity(ctx, oracle, w, default_options())
     assert ro["termination"] == 0 and rg["termination"] == 0
     assert rg["iterations_total"] > 40  # the long plateau is what makes the radius grow
+
+
+def test_large_batches_and_the_contexts_pack_arena(ctx):
+    """Batches of 128 windows or more are packed into a pinned host arena the context keeps (limo_ctx.hpp:pack_arena): made behind the
+    first such batch, lent to ONE live batch at a time - a second large batch created while the first is alive packs into the heap -,
+    recycled when its holder is destroyed, even with that batch's upload still in flight.  Whatever memory a batch was packed into,
+    its results are the same bits."""
+    o = default_options()
+    ws = [synth.make_window(8100 + i, n_kf=3 + i % 3, n_lm=120 + 7 * (i % 40)) for i in range(160)]
+
+    def solved(batch):
+        batch.solve(o)
+        batch.download()
+        return [(w.kf_pose.tobytes(), w.lm_pos.tobytes()) for w in batch.windows]
+
+    a = ba.Batch(ctx, [w.copy() for w in ws])       # (first large batch of this test: measures or holds the arena)
+    b = ba.Batch(ctx, [w.copy() for w in ws])       # created while a is alive: heap
+    ra, rb = solved(a), solved(b)
+    assert ra == rb
+    a.close()
+    c = ba.Batch(ctx, [w.copy() for w in ws])       # the arena is free again
+    c2 = ba.Batch(ctx, [w.copy() for w in ws[:130]])  # ... and taken: heap
+    c.close()                                        # destroyed right behind its creation: its upload may still be in flight
+    d = ba.Batch(ctx, [w.copy() for w in ws])       # packed over c's arrays
+    rd, rc2 = solved(d), solved(c2)
+    assert rd == ra and rc2 == ra[:130]
+    for x in (b, c2, d):
+        x.close()
