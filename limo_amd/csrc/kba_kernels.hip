@@ -2004,14 +2004,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_coop(BatchView bv, SolveConsts
             KBA_CTICK(10);
             KBA_GSYNC();
             KBA_CTICK(11);
-            // ---- the landmark part of k_accept: every workgroup moves the landmarks it linearises next
-            if (st.accept) {
-                for (int b = lb0 + g; b < lb1; b += G)
-                    if (tid < bv.lblk_n[b]) {
-                        const int64_t l = bv.lblk_lm0[b] + tid;
-                        for (int q = 0; q < 3; ++q) bv.lm[3 * l + q] = bv.lm_c[3 * l + q];
-                    }
-            }
+            // (the landmark part of k_accept is inside the relinearisation since round 6: lin_lm_block reads the candidate landmarks of
+            // an accepted step and moves them into place - the workgroup that linearises a block is the one that used to copy it)
         }
         if (retry && wd.do_trim) {  // trim(): k_trim_residual, k_trim_max, k_trim_select
             KBA_GSYNC();
